@@ -1,0 +1,87 @@
+// Internal header of libfalcon_hip.so (gfx950 only).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/falcon_hip.h"
+
+namespace fal {
+
+void set_error(const char* fmt, ...);
+
+#define FAL_CHECK_HIP(expr)                                                          \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            fal::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,        \
+                           hipGetErrorString(_e));                                   \
+            return (_e == hipErrorOutOfMemory) ? FAL_ENOMEM : FAL_EHIP;              \
+        }                                                                            \
+    } while (0)
+
+#define FAL_REQUIRE(cond, code, ...)                                                 \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            fal::set_error(__VA_ARGS__);                                             \
+            return (code);                                                           \
+        }                                                                            \
+    } while (0)
+
+#define FAL_TRY(expr)                                                                \
+    do {                                                                             \
+        int _r = (expr);                                                             \
+        if (_r != FAL_OK) return _r;                                                 \
+    } while (0)
+
+constexpr int kNumStages = 8;
+enum Stage { ST_VECTORIZE = 0, ST_BUILD = 1, ST_COARSE = 2, ST_SCAN = 3, ST_SELECT = 4,
+             ST_FILTER = 5, ST_DBSCAN = 6, ST_TAIL = 7 };
+
+// A device buffer that only ever grows; lives in the context.
+struct Scratch {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace fal
+
+struct fal_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    bool timing = false;
+    // per-stage accumulated event pairs for the LAST call of that stage
+    struct StageTimer {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        size_t used = 0;
+    } timers[fal::kNumStages];
+    fal::Scratch scratch[16];
+
+    int reserve(int slot, size_t bytes, void** out);
+    void stage_reset(int stage);
+    int stage_begin(int stage, hipEvent_t* stop_out);
+    int stage_end(hipEvent_t stop);
+};
+
+namespace fal {
+
+// RAII-less helper: time one kernel (or a group) when ctx->timing is on.
+struct StageScope {
+    fal_ctx* c;
+    hipEvent_t stop = nullptr;
+    bool on;
+    StageScope(fal_ctx* ctx, int stage) : c(ctx), on(ctx->timing) {
+        if (on) c->stage_begin(stage, &stop);
+    }
+    ~StageScope() {
+        if (on && stop) c->stage_end(stop);
+    }
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace fal

@@ -1,0 +1,170 @@
+// Context, error reporting and the two host-side helpers (a1 get_dim, a3 hash table).
+#include <math.h>
+#include <stdarg.h>
+#include "common.h"
+#include "hash.h"
+
+namespace fal {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace fal
+
+int fal_ctx::reserve(int slot, size_t bytes, void** out) {
+    fal::Scratch& s = scratch[slot];
+    if (bytes > s.cap) {
+        if (s.ptr) {
+            FAL_CHECK_HIP(hipStreamSynchronize(stream));
+            FAL_CHECK_HIP(hipFree(s.ptr));
+            s.ptr = nullptr;
+            s.cap = 0;
+        }
+        size_t want = bytes + bytes / 8 + 256;
+        FAL_CHECK_HIP(hipMalloc(&s.ptr, want));
+        s.cap = want;
+    }
+    *out = s.ptr;
+    return FAL_OK;
+}
+
+void fal_ctx::stage_reset(int stage) { timers[stage].used = 0; }
+
+int fal_ctx::stage_begin(int stage, hipEvent_t* stop_out) {
+    StageTimer& t = timers[stage];
+    if (t.used == t.ev.size()) {
+        hipEvent_t a, b;
+        FAL_CHECK_HIP(hipEventCreate(&a));
+        FAL_CHECK_HIP(hipEventCreate(&b));
+        t.ev.push_back({a, b});
+    }
+    FAL_CHECK_HIP(hipEventRecord(t.ev[t.used].first, stream));
+    *stop_out = t.ev[t.used].second;
+    t.used++;
+    return FAL_OK;
+}
+
+int fal_ctx::stage_end(hipEvent_t stop) {
+    FAL_CHECK_HIP(hipEventRecord(stop, stream));
+    return FAL_OK;
+}
+
+extern "C" {
+
+int fal_version(void) { return 100; }
+
+const char* fal_last_error(void) { return fal::g_err; }
+
+int fal_device_count(int* count) {
+    FAL_REQUIRE(count, FAL_EINVAL, "fal_device_count: NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    *count = n;
+    return FAL_OK;
+}
+
+int fal_ctx_create(int device, void* stream, fal_ctx** out) {
+    FAL_REQUIRE(out, FAL_EINVAL, "fal_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fal::set_error("fal_ctx_create: no HIP device visible (this library has no CPU fallback)");
+        return FAL_ENODEV;
+    }
+    FAL_REQUIRE(device >= 0 && device < n, FAL_EINVAL, "fal_ctx_create: device %d out of range [0,%d)", device, n);
+    FAL_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FAL_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fal::set_error("fal_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return FAL_ENODEV;
+    }
+    fal_ctx* c = new fal_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            fal::set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return FAL_EHIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return FAL_OK;
+}
+
+int fal_ctx_destroy(fal_ctx* c) {
+    if (!c) return FAL_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& s : c->scratch)
+        if (s.ptr) (void)hipFree(s.ptr);
+    for (auto& t : c->timers)
+        for (auto& p : t.ev) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return FAL_OK;
+}
+
+int fal_ctx_sync(fal_ctx* c) {
+    FAL_REQUIRE(c, FAL_EINVAL, "fal_ctx_sync: NULL ctx");
+    FAL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return FAL_OK;
+}
+
+int fal_ctx_enable_timing(fal_ctx* c, int on) {
+    FAL_REQUIRE(c, FAL_EINVAL, "NULL ctx");
+    c->timing = on != 0;
+    return FAL_OK;
+}
+
+int fal_ctx_stage_ms(fal_ctx* c, int stage, float* ms, int64_t* launches) {
+    FAL_REQUIRE(c && ms && stage >= 0 && stage < fal::kNumStages, FAL_EINVAL, "fal_ctx_stage_ms: bad argument");
+    FAL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    float total = 0.f;
+    auto& t = c->timers[stage];
+    for (size_t i = 0; i < t.used; ++i) {
+        float x = 0.f;
+        FAL_CHECK_HIP(hipEventElapsedTime(&x, t.ev[i].first, t.ev[i].second));
+        total += x;
+    }
+    *ms = total;
+    if (launches) *launches = (int64_t)t.used;
+    return FAL_OK;
+}
+
+// a1 -- reference spectrum.py:172-199: all float32 (numba signature f4,f4,f4 -> u4,f4,f4).
+int fal_get_dim(float min_mz, float max_mz, float bin_size, uint32_t* dim, float* start_dim, float* end_dim) {
+    FAL_REQUIRE(dim && start_dim && end_dim, FAL_EINVAL, "fal_get_dim: NULL output");
+    FAL_REQUIRE(bin_size > 0.f && max_mz >= min_mz, FAL_EINVAL, "fal_get_dim: need bin_size > 0 and max_mz >= min_mz");
+    volatile float s = min_mz - fmodf(min_mz, bin_size);
+    volatile float t = max_mz + bin_size;
+    volatile float e = t - fmodf(max_mz, bin_size);
+    volatile float w = e - s;
+    volatile float q = w / bin_size;
+    *start_dim = s;
+    *end_dim = e;
+    *dim = (uint32_t)ceilf(q);
+    return FAL_OK;
+}
+
+// a3 -- README.md:124-131: MurmurHash3_x86_32 of the int32 bin index, seed, unsigned, mod low_dim.
+int fal_hash_lookup(uint32_t n_bins, uint32_t low_dim, uint32_t seed, uint32_t* out_table) {
+    FAL_REQUIRE(out_table && low_dim > 0, FAL_EINVAL, "fal_hash_lookup: bad argument");
+    for (uint32_t i = 0; i < n_bins; ++i) out_table[i] = fal::murmur3_32(i, seed) % low_dim;
+    return FAL_OK;
+}
+
+}  // extern "C"

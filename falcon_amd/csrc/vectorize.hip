@@ -1,0 +1,174 @@
+// a2 + a3: CSR peak lists -> dense feature-hashed, L2-normalised vectors.
+//
+// Reference: falcon/cluster/spectrum.py:250-296 (_to_vector: bin index) and 202-247
+// (to_vector: projection + normalize_L2), hashing spec README.md:124-131.
+//
+// One 64-lane wave (= one workgroup) per spectrum, grid-stride.  HBM-bound:
+// 8 B/peak in, low_dim*4 (or *2) B/spectrum out.
+//   * lane p of a 64-peak chunk owns peak p: f64 bin index (bit-exact with the reference's
+//     float64 arithmetic), MurmurHash3 in-register (exact integer ops, no table gather);
+//   * colliding peaks are added in PEAK ORDER: each round every pending lane posts its lane id
+//     with an LDS atomic-min on tag[h]; the lowest lane per hash bin wins, adds, and clears the
+//     tag.  That makes the float32 sums independent of hardware atomic ordering and equal to
+//     the oracle's sequential adds bit for bit;
+//   * the sum of squares runs in float64 in a fixed tree (lane l owns elements 256p+4l+c, then
+//     an xor butterfly), so the norm is reproducible too; scale = (float)(1.0 / sqrtf(nr)) as
+//     faiss.normalize_L2 computes it;
+//   * rows leave as 16 B/lane (f32) or 8 B/lane (f16) coalesced stores straight from LDS.
+#include <hip/hip_fp16.h>
+#include "common.h"
+#include "hash.h"
+
+namespace {
+
+constexpr int kMaxPasses = FAL_MAX_LOW_DIM / 256;
+
+__device__ __forceinline__ double wave_xor_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ bool bin_of(float m, double min_mz, double bin_size, uint32_t n_bins, int32_t* bin) {
+    // spectrum.py:291: floor((mz - min_mz) / bin_size) with mz promoted to float64
+    double q = floor(__ddiv_rn((double)m - min_mz, bin_size));
+    if (q >= 0.0 && q < (double)n_bins) {
+        *bin = (int32_t)q;
+        return true;
+    }
+    return false;
+}
+
+template <int OUT_F16>
+__global__ __launch_bounds__(64) void vectorize_kernel(
+    const float* __restrict__ mz, const float* __restrict__ inten, const int64_t* __restrict__ indptr,
+    const int64_t* __restrict__ row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t passes = (d + 255) / 256;
+    float* acc = reinterpret_cast<float*>(smem);                 // passes*256 floats
+    uint32_t* tag = reinterpret_cast<uint32_t*>(acc + passes * 256);  // d entries
+    const uint32_t lane = threadIdx.x;
+
+    for (uint32_t i = lane; i < passes * 256; i += 64) acc[i] = 0.f;
+    for (uint32_t i = lane; i < d; i += 64) tag[i] = 0xFFFFFFFFu;
+    __syncthreads();
+
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const int64_t s = row_order ? row_order[r] : r;
+        const int64_t beg = indptr[s], end = indptr[s + 1];
+        for (int64_t p0 = beg; p0 < end; p0 += 64) {
+            const int64_t p = p0 + lane;
+            bool pending = false;
+            uint32_t h = 0;
+            float x = 0.f;
+            if (p < end) {
+                int32_t b;
+                x = inten[p];
+                if (bin_of(mz[p], min_mz, bin_size, n_bins, &b)) {
+                    pending = true;
+                    h = fal::murmur3_32((uint32_t)b, seed) % d;
+                }
+            }
+            while (__any(pending)) {
+                if (pending) atomicMin(&tag[h], lane);
+                __syncthreads();
+                const bool win = pending && tag[h] == lane;
+                __syncthreads();
+                if (win) {
+                    acc[h] += x;
+                    tag[h] = 0xFFFFFFFFu;
+                    pending = false;
+                }
+                __syncthreads();
+            }
+        }
+        // ---- norm (fixed-order float64 tree) and write-out ------------------------------
+        float4 v[kMaxPasses];
+        double part = 0.0;
+#pragma unroll
+        for (int p = 0; p < kMaxPasses; ++p) {
+            if ((uint32_t)p < passes) {
+                v[p] = *reinterpret_cast<const float4*>(&acc[256 * p + 4 * lane]);
+                *reinterpret_cast<float4*>(&acc[256 * p + 4 * lane]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                part += (double)v[p].x * (double)v[p].x;
+                part += (double)v[p].y * (double)v[p].y;
+                part += (double)v[p].z * (double)v[p].z;
+                part += (double)v[p].w * (double)v[p].w;
+            }
+        }
+        float inv = 1.f;
+        if (normalize) {
+            const double nr = wave_xor_sum(part);
+            inv = nr > 0.0 ? (float)__ddiv_rn(1.0, (double)__fsqrt_rn((float)nr)) : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < kMaxPasses; ++p) {
+            const uint32_t e = 256 * p + 4 * lane;
+            if ((uint32_t)p < passes && e < d) {
+                float4 o = make_float4(v[p].x * inv, v[p].y * inv, v[p].z * inv, v[p].w * inv);
+                if (OUT_F16) {
+                    __half2 a = __floats2half2_rn(o.x, o.y), b = __floats2half2_rn(o.z, o.w);
+                    uint2 pk;
+                    pk.x = *reinterpret_cast<uint32_t*>(&a);
+                    pk.y = *reinterpret_cast<uint32_t*>(&b);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out) + r * (int64_t)d + e) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void to_vector_indices_kernel(const float* __restrict__ mz, int64_t nnz, double min_mz,
+                                         double bin_size, int32_t* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (int32_t)floor(__ddiv_rn((double)mz[i] - min_mz, bin_size));
+}
+
+}  // namespace
+
+extern "C" {
+
+int fal_to_vector_indices(fal_ctx* ctx, const float* mz, int64_t nnz, double min_mz, double bin_size,
+                          int32_t* out_indices) {
+    FAL_REQUIRE(ctx && (nnz == 0 || (mz && out_indices)) && nnz >= 0 && bin_size > 0, FAL_EINVAL,
+                "fal_to_vector_indices: bad argument");
+    if (nnz == 0) return FAL_OK;
+    int grid = (int)std::min<int64_t>(fal::ceil_div(nnz, 256), (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(to_vector_indices_kernel, dim3(grid), dim3(256), 0, ctx->stream, mz, nnz, min_mz, bin_size,
+                       out_indices);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                  const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                  uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out) {
+    FAL_REQUIRE(ctx, FAL_EINVAL, "fal_vectorize: NULL ctx");
+    FAL_REQUIRE(n >= 0 && bin_size > 0 && n_bins > 0, FAL_EINVAL, "fal_vectorize: bad sizes");
+    FAL_REQUIRE(low_dim >= 8 && low_dim <= FAL_MAX_LOW_DIM && low_dim % 8 == 0, FAL_EUNSUPPORTED,
+                "fal_vectorize: low_dim must be a multiple of 8 in [8, %d] (got %u)", FAL_MAX_LOW_DIM, low_dim);
+    FAL_REQUIRE(out_dtype == FAL_DTYPE_F32 || out_dtype == FAL_DTYPE_F16, FAL_EINVAL, "fal_vectorize: bad out_dtype");
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(indptr && out, FAL_EINVAL, "fal_vectorize: NULL array");
+    ctx->stage_reset(fal::ST_VECTORIZE);
+    const uint32_t passes = (low_dim + 255) / 256;
+    const size_t lds = (size_t)(passes * 256 + low_dim) * 4;
+    const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 32);
+    {
+        fal::StageScope t(ctx, fal::ST_VECTORIZE);
+        if (out_dtype == FAL_DTYPE_F16)
+            hipLaunchKernelGGL(vectorize_kernel<1>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out);
+        else
+            hipLaunchKernelGGL(vectorize_kernel<0>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out);
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""Thin host wrapper over the C ABI: one `Context` per GPU.
+
+PyTorch is used for plumbing only -- device memory (`torch.empty(..., device=cuda)`),
+the stream the library enqueues on, and `torch.distributed` for the multi-GPU
+exchange.  Every kernel that touches the data is in libfalcon_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import FalconHipError, check
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class Context:
+    """Owns a `fal_ctx` bound to `cuda:<device>` and torch's current stream on it."""
+
+    def __init__(self, device: int = 0):
+        torch = _torch()
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise FalconHipError("no HIP device visible to torch; falcon_amd has no CPU fallback")
+        self.device = int(device)
+        self.tdev = torch.device("cuda", self.device)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        check(self.lib.fal_ctx_create(self.device, C.c_void_p(stream), C.byref(h)), "fal_ctx_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fal_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def to_dev(self, a, dtype=None):
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.tdev)
+            return t.to(dtype).contiguous() if dtype is not None else t.contiguous()
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.tdev)
+
+    def empty(self, shape, dtype):
+        return _torch().empty(shape, dtype=dtype, device=self.tdev)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+    def sync(self):
+        check(self.lib.fal_ctx_sync(self._h), "fal_ctx_sync")
+
+    def enable_timing(self, on: bool = True):
+        check(self.lib.fal_ctx_enable_timing(self._h, int(on)))
+
+    def stage_ms(self, stage: str):
+        ms, k = C.c_float(), C.c_int64()
+        check(self.lib.fal_ctx_stage_ms(self._h, _lib.STAGES[stage], C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+    # ------------------------------------------------------------------ a2 / a3
+    def to_vector_indices(self, mz, min_mz: float, bin_size: float):
+        torch = _torch()
+        mz = self.to_dev(mz, torch.float32)
+        out = self.empty((mz.numel(),), torch.int32)
+        check(self.lib.fal_to_vector_indices(self._h, self._p(mz), mz.numel(), min_mz, bin_size, self._p(out)),
+              "fal_to_vector_indices")
+        return out
+
+    def vectorize(self, mz, intensity, indptr, row_order, min_mz: float, bin_size: float, n_bins: int,
+                  low_dim: int, seed: int = 0, normalize: bool = True, dtype: str = "f32"):
+        torch = _torch()
+        mz = self.to_dev(mz, torch.float32)
+        intensity = self.to_dev(intensity, torch.float32)
+        indptr = self.to_dev(indptr, torch.int64)
+        row_order = None if row_order is None else self.to_dev(row_order, torch.int64)
+        n = indptr.numel() - 1
+        f16 = dtype in ("f16", "float16")
+        out = self.empty((n, low_dim), torch.float16 if f16 else torch.float32)
+        check(self.lib.fal_vectorize(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
+                                     n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
+                                     int(normalize), _lib.FAL_DTYPE_F16 if f16 else _lib.FAL_DTYPE_F32,
+                                     self._p(out)), "fal_vectorize")
+        return out
+
+
+def get_dim(min_mz: float, max_mz: float, bin_size: float):
+    """Reference spectrum.py:172-199 (float32 arithmetic), host side of the C ABI."""
+    lib = _lib.load()
+    dim, s, e = C.c_uint32(), C.c_float(), C.c_float()
+    check(lib.fal_get_dim(min_mz, max_mz, bin_size, C.byref(dim), C.byref(s), C.byref(e)), "fal_get_dim")
+    return int(dim.value), float(s.value), float(e.value)
+
+
+def hash_lookup(n_bins: int, low_dim: int, seed: int = 0) -> np.ndarray:
+    lib = _lib.load()
+    out = np.empty(n_bins, np.uint32)
+    check(lib.fal_hash_lookup(n_bins, low_dim, seed, out.ctypes.data_as(C.c_void_p)), "fal_hash_lookup")
+    return out

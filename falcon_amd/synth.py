@@ -1,0 +1,109 @@
+"""Deterministic synthetic MS/MS peak lists.
+
+Spectra arrive the way the hot path receives them from `process_spectrum`
+(reference spectrum.py:134-169): m/z inside [min_mz, max_mz], at most
+`max_peaks_used` (50, config.py:169-171) peaks sorted by m/z, intensities
+L2-normalised (spectrum.py:158).
+
+Block `b` of up to 1,000,000 spectra is drawn from `default_rng([seed, b])`
+(seed 42 = reference seed.py:6), so shards generate independently.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BLOCK = 1_000_000
+N_TEMPLATE_PEAKS = 50
+N_NOISE_PEAKS = 5
+MAX_PEAKS = 50
+
+
+def _block(n: int, block: int, seed: int, mz_lo: float, mz_hi: float):
+    rng = np.random.default_rng([seed, block])
+    f32 = np.float32
+    n_single = int(round(0.2 * n))
+    sizes = 1 + rng.poisson(7, size=max(16, int((n - n_single) / 7.5) + 64))
+    cs = np.cumsum(sizes)
+    n_cl = int(np.searchsorted(cs, n - n_single, side="left")) + 1
+    sizes = sizes[:n_cl].copy()
+    sizes[-1] -= cs[n_cl - 1] - (n - n_single)
+    if sizes[-1] <= 0:
+        sizes = sizes[:-1]
+    sizes = np.concatenate([sizes, np.ones(n - int(sizes.sum()), np.int64)])
+    n_t = len(sizes)
+    tmpl = np.repeat(np.arange(n_t), sizes)                      # template of every spectrum
+    assert len(tmpl) == n
+    # templates
+    t_pmz = rng.uniform(mz_lo, mz_hi, n_t).astype(f32)
+    t_charge = np.where(rng.random(n_t) < 0.7, 2, 3).astype(np.int8)
+    t_mz = np.sort(rng.uniform(101.0, 1500.0, (n_t, N_TEMPLATE_PEAKS)), axis=1).astype(f32)
+    t_int = rng.lognormal(0.0, 1.0, (n_t, N_TEMPLATE_PEAKS)).astype(f32)
+    # members
+    P = N_TEMPLATE_PEAKS + N_NOISE_PEAKS
+    mz = np.empty((n, P), f32)
+    it = np.empty((n, P), f32)
+    mz[:, :N_TEMPLATE_PEAKS] = t_mz[tmpl] + rng.normal(0.0, 0.005, (n, N_TEMPLATE_PEAKS)).astype(f32)
+    it[:, :N_TEMPLATE_PEAKS] = t_int[tmpl] * rng.lognormal(0.0, 0.2, (n, N_TEMPLATE_PEAKS)).astype(f32)
+    keep = rng.random((n, P)) >= 0.10                            # 10 % peak dropout
+    keep[:, N_TEMPLATE_PEAKS:] = True
+    base = np.max(np.where(keep[:, :N_TEMPLATE_PEAKS], it[:, :N_TEMPLATE_PEAKS], 0), axis=1, keepdims=True)
+    base = np.maximum(base, f32(1e-6))
+    mz[:, N_TEMPLATE_PEAKS:] = rng.uniform(101.0, 1500.0, (n, N_NOISE_PEAKS)).astype(f32)
+    it[:, N_TEMPLATE_PEAKS:] = (rng.uniform(0.0, 0.05, (n, N_NOISE_PEAKS)) * base).astype(f32)
+    keep &= (mz >= f32(101.0)) & (mz <= f32(1500.0))             # set_mz_range (spectrum.py:135)
+    # keep the MAX_PEAKS most intense (filter_intensity, spectrum.py:153)
+    it_k = np.where(keep, it, -1.0)
+    kth = np.partition(it_k, P - MAX_PEAKS, axis=1)[:, P - MAX_PEAKS][:, None]
+    keep &= it_k >= kth
+    # sort by m/z, invalid last
+    key = np.where(keep, mz, np.inf)
+    o = np.argsort(key, axis=1, kind="stable")
+    mz = np.take_along_axis(mz, o, 1)
+    it = np.take_along_axis(it, o, 1)
+    keep = np.take_along_axis(keep, o, 1)
+    it = np.where(keep, it, 0)
+    nrm = np.sqrt((it.astype(np.float64) ** 2).sum(1, keepdims=True))
+    it = (it / np.maximum(nrm, 1e-30)).astype(f32)               # _norm_intensity (spectrum.py:55-70)
+    counts = keep.sum(1)
+    pmz = (t_pmz[tmpl].astype(np.float64) * (1.0 + rng.normal(0.0, 3e-6, n))).astype(f32)
+    rt = rng.uniform(0.0, 7200.0, n).astype(f32)
+    charge = t_charge[tmpl]
+    # shuffle so that nothing arrives pre-sorted
+    perm = rng.permutation(n)
+    keep, mz, it, counts = keep[perm], mz[perm], it[perm], counts[perm]
+    return dict(mz=mz[keep], intensity=it[keep], counts=counts.astype(np.int64),
+                precursor_mz=pmz[perm], retention_time=rt[perm], precursor_charge=charge[perm],
+                truth=tmpl[perm].astype(np.int64))
+
+
+def generate(n: int, seed: int = 42, first_block: int = 0, mz_lo: float = 400.0, mz_hi: float = 1200.0):
+    """-> dict(mz f32[nnz], intensity f32[nnz], indptr i64[n+1], precursor_mz f32[n],
+    retention_time f32[n], precursor_charge i8[n], truth i64[n])."""
+    parts, done, b, t_off = [], 0, first_block, 0
+    while done < n:
+        m = min(BLOCK, n - done)
+        p = _block(m, b, seed, mz_lo, mz_hi)
+        p["truth"] = p["truth"] + t_off
+        t_off = int(p["truth"].max()) + 1
+        parts.append(p)
+        done += m
+        b += 1
+    cat = lambda k: np.concatenate([p[k] for p in parts])
+    counts = cat("counts")
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    return dict(mz=cat("mz"), intensity=cat("intensity"), indptr=indptr,
+                precursor_mz=cat("precursor_mz"), retention_time=cat("retention_time"),
+                precursor_charge=cat("precursor_charge"), truth=cat("truth"))
+
+
+def select_charge(data: dict, charge: int) -> dict:
+    """Sub-dataset of one precursor charge (the per-charge partition of falcon.py:151-160)."""
+    sel = np.flatnonzero(data["precursor_charge"] == charge)
+    counts = np.diff(data["indptr"])[sel]
+    indptr = np.zeros(len(sel) + 1, np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    src = np.repeat(data["indptr"][:-1][sel] - indptr[:-1], counts) + np.arange(int(counts.sum()))
+    out = {k: data[k][sel] for k in ("precursor_mz", "retention_time", "precursor_charge", "truth")}
+    out.update(mz=data["mz"][src], intensity=data["intensity"][src], indptr=indptr, rows=sel)
+    return out

@@ -1,0 +1,168 @@
+/*
+ * falcon_hip.h -- C ABI of libfalcon_hip.so: falcon's vectorise -> ANN -> DBSCAN hot
+ * path as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (bittremieux/falcon @ 2024-12-23) is pure Python and has no FFI; the seam
+ * this library sits behind is the one call `cluster.generate_clusters(...)`
+ * (reference falcon/cluster/cluster.py:24-156, call site falcon/falcon.py:178-188).
+ * Each entry point below names the reference code (file:line) whose work it does.
+ * INTEGRATION.md shows the ctypes binding a falcon maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FAL_E* code and never throws or
+ *     aborts across the boundary; fal_last_error() returns a thread-local message;
+ *   - plain C types only; pointers marked [dev] are device (HBM) pointers valid on the
+ *     context's device (e.g. torch tensor .data_ptr()), [host] are host pointers;
+ *   - the CALLER allocates every input/output array; the library owns only the opaque
+ *     handles (fal_ctx, fal_ivf) and grow-only scratch inside the context;
+ *   - all device work is enqueued on the context's stream; outputs are valid after
+ *     fal_ctx_sync() (or any later call on the same context that reads them);
+ *   - one fal_ctx per device, not shared between threads;
+ *   - there is NO CPU fallback: a context can only be created on a HIP device.
+ */
+#ifndef FALCON_HIP_H
+#define FALCON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FAL_OK            0
+#define FAL_EINVAL       -1   /* bad argument */
+#define FAL_EHIP         -2   /* a HIP runtime call failed */
+#define FAL_ENOMEM       -3   /* device allocation failed */
+#define FAL_ENODEV       -4   /* no usable gfx950 device */
+#define FAL_EUNSUPPORTED -5   /* parameter outside the compiled limits */
+
+#define FAL_DTYPE_F32 0
+#define FAL_DTYPE_F16 1
+
+#define FAL_MAX_LOW_DIM   1024     /* multiple of 8 */
+#define FAL_MAX_K_ANN      256
+#define FAL_MAX_N_PROBE    128
+#define FAL_MAX_N_LIST  131072
+
+typedef struct fal_ctx fal_ctx;
+typedef struct fal_ivf fal_ivf;
+
+/* ---- library / context ------------------------------------------------------------- */
+int         fal_version(void);
+const char* fal_last_error(void);
+int fal_device_count(int* count);
+/* `stream` may be NULL (the library creates its own) or an existing hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream) the context will enqueue on. */
+int fal_ctx_create(int device, void* stream, fal_ctx** out);
+int fal_ctx_destroy(fal_ctx* ctx);
+int fal_ctx_sync(fal_ctx* ctx);
+/* Elapsed milliseconds (HIP events on the context's stream) of the kernels the LAST
+ * call of the named stage enqueued; used by bench.py for the roofline figure.
+ * stage: 0 vectorize, 1 kmeans/ivf build, 2 coarse probe, 3 fine scan (cosine kernel),
+ * 4 top-k select, 5 filter, 6 dbscan, 7 tail. */
+int fal_ctx_stage_ms(fal_ctx* ctx, int stage, float* ms, int64_t* launches);
+int fal_ctx_enable_timing(fal_ctx* ctx, int on);
+
+/* ---- a1  bin geometry: reference spectrum.py:172-199 `get_dim` (float32) --- [host] */
+int fal_get_dim(float min_mz, float max_mz, float bin_size,
+                uint32_t* dim, float* start_dim, float* end_dim);
+
+/* ---- a3  feature-hash lookup table: MurmurHash3_x86_32(int32 bin, seed) % low_dim;
+ *          spec reference README.md:124-131 ------------------------------------ [host] */
+int fal_hash_lookup(uint32_t n_bins, uint32_t low_dim, uint32_t seed, uint32_t* out_table);
+
+/* ---- a2  m/z -> bin index (the CSR `indices` of reference spectrum.py:250-296
+ *          `_to_vector`): floor(((double)mz - min_mz) / bin_size) as int32 ------ [dev] */
+int fal_to_vector_indices(fal_ctx* ctx, const float* mz, int64_t nnz,
+                          double min_mz, double bin_size, int32_t* out_indices);
+
+/* ---- a2+a3  CSR peaks -> dense low_dim vectors, L2-normalised: reference
+ *          spectrum.py:202-247 `to_vector` with the projection realised as feature
+ *          hashing.  Row r of `out` is spectrum row_order[r] (row_order may be NULL).
+ *          out: [n, low_dim] float32 or float16 (out_dtype).  Peaks whose bin lies
+ *          outside [0, n_bins) are ignored; an all-zero row stays zero. ---------- [dev] */
+int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity,
+                  const int64_t* indptr, const int64_t* row_order, int64_t n,
+                  double min_mz, double bin_size, uint32_t n_bins,
+                  uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out);
+
+/* ---- a5  precursor-m/z bucket boundaries: reference cluster.py:159-209
+ *          `_get_precursor_mz_splits` over the m/z-SORTED float32 precursor array,
+ *          plus (flags) the build's two extra rules: chunk the last block
+ *          too, and cut at fixed windows floor(mz / mz_interval).
+ *          splits_out [host] receives at most max_splits int64 boundaries
+ *          (first 0, last n); *n_splits = how many. -------------------------------- */
+int fal_precursor_splits(fal_ctx* ctx, const float* precursor_mz_sorted /*[dev]*/, int64_t n,
+                         double tol, int tol_is_da, int64_t batch_size,
+                         double mz_interval, int chunk_last,
+                         int64_t* splits_out /*[host]*/, int64_t max_splits, int64_t* n_splits);
+
+/* ---- a6  IVF build per bucket (k-means + inverted lists); the reference's only
+ *          statement is README.md:134-136 (Faiss IndexIVFFlat, un-vendored dep
+ *          setup.cfg:25).  X [dev] is [n, low_dim] float32 in precursor-sorted row order;
+ *          bucket_off [host] has n_buckets+1 row offsets; n_list [host] lists per bucket
+ *          (1 = flat).  Deterministic: init rows floor(i*n_b/n_list), `kmeans_iters`
+ *          x (argmax-IP assign, spherical mean in row order), final assign. ---------- */
+int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim,
+                  const int64_t* bucket_off, int64_t n_buckets, const int32_t* n_list,
+                  int kmeans_iters, fal_ivf** out);
+int fal_ivf_destroy(fal_ivf* ivf);
+int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists);
+/* Copy the index out for inspection (any pointer may be NULL): centroids
+ * [total_lists, low_dim] f32, list id of every row (bucket-local) i32[n], perm i32[n]
+ * (row ids in (bucket, list, row) order), list_off i64[total_lists+1]. --------- [dev] */
+int fal_ivf_export(fal_ctx* ctx, const fal_ivf* ivf, float* centroids, int32_t* assign,
+                   int32_t* perm, int64_t* list_off);
+
+/* ---- a7  n_probe query of every row against its bucket's index + top-k_ann by
+ *          (inner product desc, row id asc); reference spec README.md:107-113,137-142.
+ *          sim f32[n,k_ann] (pad -inf), idx i32[n,k_ann] (pad -1, ids = sorted rows). */
+int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
+                        float* sim, int32_t* idx);
+
+/* ---- a8  neighbour filter + distance: drop self / pads / neighbours outside the
+ *          precursor (and RT) tolerance, keep the first n_neighbors,
+ *          dist = clip(1 - sim, 0, 1): reference cluster.py:190-195 (mass_diff usage),
+ *          cluster.py:626, similarity.py:78.  rt may be NULL / rt_tol < 0 = no RT filter.
+ *          nb_idx i32[n,k] (pad -1), nb_dist f32[n,k] (pad +inf). ---------------- [dev] */
+int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int64_t n,
+                         int k_ann, const float* precursor_mz_sorted, const float* rt_sorted,
+                         double tol, int tol_is_da, double rt_tol, int n_neighbors,
+                         int32_t* nb_idx, float* nb_dist);
+
+/* ---- a9  DBSCAN(eps, min_samples = 2 as reference cluster.py:66) on the sparse
+ *          neighbour graph; spec README.md:143-146.  Order-independent form:
+ *          clusters = components of core points, border -> lowest-index core
+ *          in-neighbour, clusters numbered by lowest core row, noise = -1. -------- [dev] */
+int fal_dbscan(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k,
+               float eps, int32_t* labels, int64_t* n_clusters /*[host]*/);
+
+/* ---- a10 precursor / RT refinement of every DBSCAN cluster: reference
+ *          cluster.py:362-455 `_postprocess_cluster` + cluster.py:458-509 `_linkage`
+ *          (1-D complete linkage cut at the tolerance; groups < 2 -> noise);
+ *          final clusters numbered in (DBSCAN label, first member) order like
+ *          cluster.py:293-313.  labels in/out i32[n] (sorted-row space). ---------- [dev] */
+int fal_refine_clusters(fal_ctx* ctx, int32_t* labels, int64_t n,
+                        const float* precursor_mz_sorted, const float* rt_sorted,
+                        double tol, int tol_is_da, double rt_tol,
+                        int64_t* n_clusters /*[host]*/);
+
+/* ---- a11+a12 medoids (reference cluster.py:512-553 on the sparse graph) and label
+ *          globalisation (cluster.py:556-590, 144-155): labels_sorted -> labels by DATASET
+ *          row with noise renumbered n_clusters.. in dataset-row order; medoids[c] =
+ *          dataset row of cluster c's medoid (c < n_clusters), then the noise rows. [dev] */
+int fal_finalize(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, int64_t n_clusters,
+                 const int64_t* row_order, const int32_t* nb_idx, const float* nb_dist, int k,
+                 int32_t* labels_out, int32_t* medoids_out, int64_t* n_labels /*[host]*/);
+
+/* ---- sort by precursor m/z (reference cluster.py:73-85 `.sort_values`): stable.
+ *          order_out i64[n] (dataset row of sorted position), mz_sorted_out f32[n]. [dev] */
+int fal_sort_by_precursor(fal_ctx* ctx, const float* precursor_mz, int64_t n,
+                          int64_t* order_out, float* mz_sorted_out);
+/* out[i] = src[order[i]] for float arrays (retention times). -------------------- [dev] */
+int fal_gather_f32(fal_ctx* ctx, const float* src, const int64_t* order, int64_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FALCON_HIP_H */

@@ -1,0 +1,24 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ref_golden():
+    return np.load(os.path.join(GOLDEN, "reference_functions.npz"))
+
+
+@pytest.fixture(scope="session")
+def dbscan_golden():
+    return np.load(os.path.join(GOLDEN, "sklearn_dbscan.npz"))
