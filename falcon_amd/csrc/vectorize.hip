@@ -12,8 +12,8 @@
 //     tag.  That makes the float32 sums independent of hardware atomic ordering and equal to
 //     the oracle's sequential adds bit for bit;
 //   * the sum of squares runs in float64 in a fixed tree (lane l owns elements 256p+4l+c, then
-//     an xor butterfly), so the norm is reproducible too; scale = (float)(1.0 / sqrtf(nr)) as
-//     faiss.normalize_L2 computes it;
+//     an xor butterfly), so the norm is reproducible too; scale = (float)(1.0 / sqrt(nr)) with the
+//     sqrt and the divide in float64 (both correctly rounded on gfx950; the f32 v_sqrt is not);
 //   * rows leave as 16 B/lane (f32) or 8 B/lane (f16) coalesced stores straight from LDS.
 #include <hip/hip_fp16.h>
 #include "common.h"
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
         float inv = 1.f;
         if (normalize) {
             const double nr = wave_xor_sum(part);
-            inv = nr > 0.0 ? (float)__ddiv_rn(1.0, (double)__fsqrt_rn((float)nr)) : 0.f;
+            inv = nr > 0.0 ? (float)__ddiv_rn(1.0, __dsqrt_rn(nr)) : 0.f;
         }
 #pragma unroll
         for (int p = 0; p < kMaxPasses; ++p) {

@@ -108,11 +108,12 @@ def l2_norm_sq_tree(V: np.ndarray) -> np.ndarray:
 
 def l2_normalize_rows(V: np.ndarray) -> np.ndarray:
     """Row-wise L2 normalisation in the spirit of faiss.normalize_L2 (spectrum.py:246):
-    inv = (float)(1.0 / sqrtf(nr)); x *= inv; all-zero rows are left untouched."""
+    inv = (float)(1.0 / sqrt(nr)) with nr, sqrt and the divide in float64 (correctly
+    rounded on both CPU and gfx950); x *= inv; all-zero rows are left untouched."""
     nr = l2_norm_sq_tree(V)
     out = V.astype(f32).copy()
     nz = nr > 0
-    inv = (f64(1.0) / np.sqrt(nr[nz].astype(f32)).astype(f64)).astype(f32)
+    inv = (f64(1.0) / np.sqrt(nr[nz])).astype(f32)
     out[nz] = out[nz] * inv[:, None]
     return out
 
