@@ -29,7 +29,7 @@ _SIGNATURES = {
     "fal_version": ([], c_int),
     "fal_last_error": ([], C.c_char_p),
     "fal_device_count": ([P(c_int)], c_int),
-    "fal_ctx_create": ([c_int, c_void_p, P(c_void_p)], c_int),
+    "fal_ctx_create": ([c_int, c_void_p, c_int, P(c_void_p)], c_int),
     "fal_ctx_destroy": ([c_void_p], c_int),
     "fal_ctx_sync": ([c_void_p], c_int),
     "fal_ctx_stage_ms": ([c_void_p, c_int, P(c_float), P(c_int64)], c_int),

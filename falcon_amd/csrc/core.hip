@@ -67,7 +67,7 @@ int fal_device_count(int* count) {
     return FAL_OK;
 }
 
-int fal_ctx_create(int device, void* stream, fal_ctx** out) {
+int fal_ctx_create(int device, void* stream, int own_stream, fal_ctx** out) {
     FAL_REQUIRE(out, FAL_EINVAL, "fal_ctx_create: out is NULL");
     *out = nullptr;
     int n = 0;
@@ -86,7 +86,7 @@ int fal_ctx_create(int device, void* stream, fal_ctx** out) {
     fal_ctx* c = new fal_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
-    if (stream) {
+    if (!own_stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;
     } else {

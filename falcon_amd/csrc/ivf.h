@@ -1,0 +1,35 @@
+// The index handle behind the opaque `fal_ivf` of the C ABI.
+#pragma once
+#include <vector>
+#include "common.h"
+
+namespace fal {
+// context scratch slots
+enum { SLOT_JOBS = 0, SLOT_SIMS = 1, SLOT_PROBES = 2, SLOT_PROBE_SIM = 3, SLOT_QOFF = 4, SLOT_JOBS2 = 5,
+       SLOT_MISC = 6, SLOT_MISC2 = 7, SLOT_SORT = 8, SLOT_SORT2 = 9, SLOT_TAIL = 10, SLOT_TAIL2 = 11,
+       SLOT_TAIL3 = 12, SLOT_TAIL4 = 13, SLOT_TAIL5 = 14, SLOT_TAIL6 = 15 };
+// out[0..n] = exclusive prefix sums of in[0..n) (out has n + 1 entries)
+int launch_exclusive_scan(fal_ctx* ctx, const int64_t* in, int64_t n, int64_t* out);
+}
+
+struct fal_ivf {
+    fal_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int d = 0;
+    const float* X = nullptr;        // caller's vectors, precursor-sorted rows (borrowed)
+    const float* Xl = nullptr;       // the same rows in (bucket, list, row) order (== X when all flat)
+    float* Xl_owned = nullptr;
+    std::vector<int64_t> bucket_off; // host, n_buckets + 1
+    std::vector<int32_t> n_list;     // host, per bucket
+    std::vector<int64_t> list_base;  // host, global id of each bucket's list 0
+    int64_t total_lists = 0;
+    int n_ivf_buckets = 0;
+    int64_t ivf_waves = 0;
+    float* centroids = nullptr;      // [total_lists, d]
+    int32_t* assign = nullptr;       // [n] bucket-local list of each sorted row
+    int32_t* perm = nullptr;         // [n] list-order position -> sorted row
+    int64_t* list_off = nullptr;     // [total_lists + 1] list-order positions
+    int64_t* counts = nullptr;       // [total_lists + 1]
+    void* bk_dev = nullptr;          // BucketDev[n_ivf_buckets]
+    int64_t* q_list_base = nullptr;  // [n] per list-order position: global id of its bucket's list 0
+};

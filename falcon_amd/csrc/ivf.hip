@@ -1,0 +1,366 @@
+// a6 IVF build (deterministic k-means + inverted lists) and a7 search orchestration.
+//
+// Reference: README.md:132-142 is the only statement of this stage in the snapshot (Faiss
+// IndexIVFFlat over inner product, un-vendored dependency setup.cfg:25); the conventions are the
+// build's own and are restated on the CPU in oracle/falcon_oracle.py (ivf_train / ivf_build /
+// ivf_search).  Everything is batched over ALL buckets of a charge partition: one launch per
+// step, never one launch per bucket.
+#include <algorithm>
+#include <math.h>
+#include <stdlib.h>
+#include "common.h"
+#include "scan.h"
+#include "ivf.h"
+
+namespace fal {
+
+// ------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------
+struct BucketDev {       // one per IVF (n_list > 1) bucket
+    int64_t row0;        // first sorted row
+    int64_t list0;       // global id of its list 0
+    int32_t n;           // rows
+    int32_t n_list;
+    int64_t wave0;       // index of its first (bucket, list) wave in per-list launches
+};
+
+__device__ __forceinline__ int find_bucket(const BucketDev* __restrict__ b, int nb, int64_t w) {
+    int lo = 0, hi = nb - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (b[mid].wave0 <= w) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// init: centroid i of a bucket = row floor(i * n / n_list)   (one wave per centroid)
+__global__ __launch_bounds__(64) void kmeans_init_kernel(const float* __restrict__ X, int d,
+                                                         const BucketDev* __restrict__ bk, int nb,
+                                                         float* __restrict__ C) {
+    const BucketDev b = bk[find_bucket(bk, nb, blockIdx.x)];
+    const int i = (int)(blockIdx.x - b.wave0);
+    const int64_t src = b.row0 + ((int64_t)i * b.n) / b.n_list;
+    const float4* s = reinterpret_cast<const float4*>(X + src * d);
+    float4* o = reinterpret_cast<float4*>(C + (b.list0 + i) * d);
+    for (int e = threadIdx.x; e < d / 4; e += 64) o[e] = s[e];
+}
+
+__device__ __forceinline__ double wave_xor_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// update: one wave per (bucket, list).  The wave walks the bucket's assignment array in row
+// order, 64 rows per step; members are found with a ballot and added one by one IN ROW ORDER
+// (float32), so the sum does not depend on scheduling.  Then spherical normalisation with the
+// same fixed-order float64 tree as the vectorise kernel.  Empty lists keep their centroid.
+// WRITE_PERM: instead of updating, record the members (stable) at perm[list_off[L] ...].
+template <int MODE>   // 0 = update centroid, 1 = count members, 2 = write perm
+__global__ __launch_bounds__(64) void list_walk_kernel(const float* __restrict__ X, int d,
+                                                       const int32_t* __restrict__ assign,
+                                                       const BucketDev* __restrict__ bk, int nb,
+                                                       float* __restrict__ C, int64_t* __restrict__ counts,
+                                                       const int64_t* __restrict__ list_off,
+                                                       int32_t* __restrict__ perm) {
+    const BucketDev b = bk[find_bucket(bk, nb, blockIdx.x)];
+    const int li = (int)(blockIdx.x - b.wave0);
+    const int lane = threadIdx.x;
+    constexpr int P = FAL_MAX_LOW_DIM / 256;
+    const int passes = (d + 255) / 256;
+    float4 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t cnt = 0;
+    int64_t wbase = (MODE == 2) ? list_off[b.list0 + li] : 0;
+    for (int r0 = 0; r0 < b.n; r0 += 64) {
+        const int r = r0 + lane;
+        const bool mine = r < b.n && assign[b.row0 + r] == li;
+        uint64_t mask = __ballot(mine);
+        if (MODE == 2) {
+            if (mine) perm[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(b.row0 + r);
+            wbase += __popcll(mask);
+        } else if (MODE == 1) {
+            cnt += __popcll(mask);
+        } else {
+            cnt += __popcll(mask);
+            while (mask) {
+                const int j = __ffsll((unsigned long long)mask) - 1;
+                mask &= mask - 1;
+                const float4* row = reinterpret_cast<const float4*>(X + (b.row0 + r0 + j) * d);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int e = 64 * p + lane;        // float4 index
+                    if (p < passes && e < d / 4) {
+                        const float4 v = row[e];
+                        acc[p].x += v.x;
+                        acc[p].y += v.y;
+                        acc[p].z += v.z;
+                        acc[p].w += v.w;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 1) {
+        if (lane == 0) counts[b.list0 + li] = cnt;
+        return;
+    }
+    if (MODE == 2) return;
+    if (cnt == 0) return;   // keep the previous centroid
+    double part = 0.0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (p < passes) {
+            part += (double)acc[p].x * (double)acc[p].x;
+            part += (double)acc[p].y * (double)acc[p].y;
+            part += (double)acc[p].z * (double)acc[p].z;
+            part += (double)acc[p].w * (double)acc[p].w;
+        }
+    }
+    const double nr = wave_xor_sum_d(part);
+    const float inv = nr > 0.0 ? (float)__ddiv_rn(1.0, __dsqrt_rn(nr)) : 0.f;
+    float4* o = reinterpret_cast<float4*>(C + (b.list0 + li) * d);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int e = 64 * p + lane;
+        if (p < passes && e < d / 4)
+            o[e] = make_float4(acc[p].x * inv, acc[p].y * inv, acc[p].z * inv, acc[p].w * inv);
+    }
+}
+
+// exclusive scan of int64 counts -> offsets (single workgroup; n up to a few hundred thousand)
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int64_t* __restrict__ in, int64_t n,
+                                                              int64_t* __restrict__ out) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n ? in[i] : 0;
+        int64_t x = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        int64_t pre = carry_s;
+        for (int j = 0; j < w; ++j) pre += wsum[j];
+        if (i < n) out[i] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = pre + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+__global__ void iota_i32_kernel(int32_t* out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (int32_t)i;
+}
+
+// Xl[p] = X[perm[p]]   (one wave per row, 16 B per lane)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, const int32_t* __restrict__ perm,
+                                                          int64_t n, int d, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = blockIdx.x * 4ll + (threadIdx.x >> 6); p < n; p += (int64_t)gridDim.x * 4) {
+        const float4* s = reinterpret_cast<const float4*>(X + (int64_t)perm[p] * d);
+        float4* o = reinterpret_cast<float4*>(out + p * d);
+        for (int e = lane; e < d / 4; e += 64) o[e] = s[e];
+    }
+}
+
+int launch_exclusive_scan(fal_ctx* ctx, const int64_t* in, int64_t n, int64_t* out) {
+    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, in, n, out);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+}  // namespace fal
+
+using namespace fal;
+
+// ------------------------------------------------------------------------------------------
+// build
+// ------------------------------------------------------------------------------------------
+static int dev_alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    FAL_CHECK_HIP(hipMalloc(p, bytes));
+    return FAL_OK;
+}
+
+extern "C" {
+
+int fal_ivf_destroy(fal_ivf* ivf) {
+    if (!ivf) return FAL_OK;
+    if (ivf->ctx) (void)hipStreamSynchronize(ivf->ctx->stream);
+    void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts,
+                    ivf->bk_dev, ivf->q_list_base};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete ivf;
+    return FAL_OK;
+}
+
+int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists) {
+    FAL_REQUIRE(ivf && total_lists, FAL_EINVAL, "fal_ivf_total_lists: NULL");
+    *total_lists = ivf->total_lists;
+    return FAL_OK;
+}
+
+int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const int64_t* bucket_off,
+                  int64_t n_buckets, const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
+    FAL_REQUIRE(ctx && out, FAL_EINVAL, "fal_ivf_build: NULL ctx/out");
+    *out = nullptr;
+    FAL_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "fal_ivf_build: n must be < 2^31 per partition");
+    FAL_REQUIRE(low_dim >= 8 && low_dim <= FAL_MAX_LOW_DIM && low_dim % 8 == 0, FAL_EUNSUPPORTED,
+                "fal_ivf_build: low_dim must be a multiple of 8 in [8, %d]", FAL_MAX_LOW_DIM);
+    FAL_REQUIRE(n_buckets >= 0 && (n_buckets == 0 || (bucket_off && n_list)), FAL_EINVAL, "fal_ivf_build: NULL bucket arrays");
+    FAL_REQUIRE(kmeans_iters >= 0, FAL_EINVAL, "fal_ivf_build: kmeans_iters < 0");
+    FAL_REQUIRE(n == 0 || X, FAL_EINVAL, "fal_ivf_build: NULL X");
+    if (n_buckets > 0) {
+        FAL_REQUIRE(bucket_off[0] == 0 && bucket_off[n_buckets] == n, FAL_EINVAL,
+                    "fal_ivf_build: bucket_off must start at 0 and end at n");
+    } else {
+        FAL_REQUIRE(n == 0, FAL_EINVAL, "fal_ivf_build: no buckets but n > 0");
+    }
+    fal_ivf* ivf = new fal_ivf();
+    ivf->ctx = ctx;
+    ivf->n = n;
+    ivf->d = low_dim;
+    ivf->X = X;
+    ivf->bucket_off.assign(bucket_off, bucket_off + n_buckets + 1 * (n_buckets > 0));
+    if (n_buckets == 0) ivf->bucket_off.assign(1, 0);
+    ivf->n_list.assign(n_list, n_list + n_buckets);
+    ivf->list_base.resize(n_buckets + 1);
+    std::vector<BucketDev> bk;
+    int64_t total = 0, waves = 0;
+    for (int64_t b = 0; b < n_buckets; ++b) {
+        const int64_t nb = bucket_off[b + 1] - bucket_off[b];
+        if (nb < 0 || n_list[b] < 1 || n_list[b] > FAL_MAX_N_LIST || (nb > 0 && n_list[b] > nb) || nb > INT32_MAX) {
+            set_error("fal_ivf_build: bucket %lld: size %lld, n_list %d invalid", (long long)b, (long long)nb, n_list[b]);
+            delete ivf;
+            return FAL_EINVAL;
+        }
+        ivf->list_base[b] = total;
+        if (n_list[b] > 1) {
+            bk.push_back({bucket_off[b], total, (int32_t)nb, n_list[b], waves});
+            waves += n_list[b];
+        }
+        total += n_list[b];
+    }
+    ivf->list_base[n_buckets] = total;
+    ivf->total_lists = total;
+    ivf->n_ivf_buckets = (int)bk.size();
+    ivf->ivf_waves = waves;
+    hipStream_t st = ctx->stream;
+    int rc = FAL_OK;
+    auto fail = [&](int code) {
+        fal_ivf_destroy(ivf);
+        return code;
+    };
+#define B_TRY(e) do { rc = (e); if (rc != FAL_OK) return fail(rc); } while (0)
+#define B_HIP(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s:%d %s: %s", __FILE__, __LINE__, #e, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? FAL_ENOMEM : FAL_EHIP); } } while (0)
+
+    B_TRY(dev_alloc((void**)&ivf->perm, sizeof(int32_t) * (size_t)n));
+    B_TRY(dev_alloc((void**)&ivf->assign, sizeof(int32_t) * (size_t)n));
+    B_TRY(dev_alloc((void**)&ivf->list_off, sizeof(int64_t) * (size_t)(total + 1)));
+    B_TRY(dev_alloc((void**)&ivf->counts, sizeof(int64_t) * (size_t)(total + 1)));
+    B_TRY(dev_alloc((void**)&ivf->centroids, sizeof(float) * (size_t)total * low_dim));
+    B_TRY(dev_alloc((void**)&ivf->q_list_base, sizeof(int64_t) * (size_t)n));
+    ctx->stage_reset(ST_BUILD);
+
+    // counts: flat buckets hold all their rows in their single list
+    {
+        std::vector<int64_t> cnt_host(total + 1, 0), qlb;
+        for (int64_t b = 0; b < n_buckets; ++b)
+            if (n_list[b] == 1) cnt_host[ivf->list_base[b]] = bucket_off[b + 1] - bucket_off[b];
+        B_HIP(hipMemcpyAsync(ivf->counts, cnt_host.data(), sizeof(int64_t) * (total + 1), hipMemcpyHostToDevice, st));
+        B_HIP(hipStreamSynchronize(st));   // cnt_host goes out of scope
+    }
+    B_HIP(hipMemsetAsync(ivf->assign, 0, sizeof(int32_t) * (size_t)n, st));
+    B_HIP(hipMemsetAsync(ivf->centroids, 0, sizeof(float) * (size_t)total * low_dim, st));
+    if (n > 0) {
+        hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, st,
+                           ivf->perm, n);
+        B_HIP(hipGetLastError());
+    }
+    if (!bk.empty()) {
+        B_TRY(dev_alloc((void**)&ivf->bk_dev, sizeof(BucketDev) * bk.size()));
+        B_HIP(hipMemcpyAsync(ivf->bk_dev, bk.data(), sizeof(BucketDev) * bk.size(), hipMemcpyHostToDevice, st));
+        // dense jobs: rows of the bucket x centroids of the bucket
+        std::vector<DenseJob> jobs;
+        int64_t tiles = 0;
+        for (const BucketDev& b : bk) {
+            jobs.push_back({b.row0, b.list0, 0, tiles, b.n, b.n_list});
+            tiles += ceil_div(b.n, 32);
+        }
+        DenseJob* jobs_dev = nullptr;
+        B_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * jobs.size(), (void**)&jobs_dev));
+        B_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(DenseJob) * jobs.size(), hipMemcpyHostToDevice, st));
+        B_HIP(hipStreamSynchronize(st));   // host vectors are about to go away / be reused
+        const BucketDev* bkd = (const BucketDev*)ivf->bk_dev;
+        const int nbk = (int)bk.size();
+        {
+            StageScope ts(ctx, ST_BUILD);
+            hipLaunchKernelGGL(kmeans_init_kernel, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, bkd, nbk,
+                               ivf->centroids);
+        B_HIP(hipGetLastError());
+        }
+        for (int it = 0; it <= kmeans_iters; ++it) {
+            B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, jobs_dev, (int)jobs.size(), 0,
+                               tiles, nullptr, 0, ivf->assign));
+            if (it == kmeans_iters) break;   // final assignment against the final centroids
+            StageScope ts(ctx, ST_BUILD);
+            hipLaunchKernelGGL(list_walk_kernel<0>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign,
+                               bkd, nbk, ivf->centroids, nullptr, nullptr, nullptr);
+        B_HIP(hipGetLastError());
+        }
+        StageScope ts(ctx, ST_BUILD);
+        hipLaunchKernelGGL(list_walk_kernel<1>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
+                           nbk, nullptr, ivf->counts, nullptr, nullptr);
+        B_HIP(hipGetLastError());
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, ivf->counts, total, ivf->list_off);
+        B_HIP(hipGetLastError());
+        hipLaunchKernelGGL(list_walk_kernel<2>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
+                           nbk, nullptr, nullptr, ivf->list_off, ivf->perm);
+        B_HIP(hipGetLastError());
+        B_TRY(dev_alloc((void**)&ivf->Xl_owned, sizeof(float) * (size_t)n * low_dim));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), ctx->num_cus * 16)),
+                           dim3(256), 0, st, X, ivf->perm, n, low_dim, ivf->Xl_owned);
+        B_HIP(hipGetLastError());
+        ivf->Xl = ivf->Xl_owned;
+    } else {
+        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, ivf->counts, total, ivf->list_off);
+        B_HIP(hipGetLastError());
+        ivf->Xl = X;
+    }
+    B_HIP(hipGetLastError());
+#undef B_TRY
+#undef B_HIP
+    *out = ivf;
+    return FAL_OK;
+}
+
+int fal_ivf_export(fal_ctx* ctx, const fal_ivf* ivf, float* centroids, int32_t* assign, int32_t* perm,
+                   int64_t* list_off) {
+    FAL_REQUIRE(ctx && ivf, FAL_EINVAL, "fal_ivf_export: NULL");
+    hipStream_t st = ctx->stream;
+    if (centroids)
+        FAL_CHECK_HIP(hipMemcpyAsync(centroids, ivf->centroids, sizeof(float) * (size_t)ivf->total_lists * ivf->d,
+                                     hipMemcpyDeviceToDevice, st));
+    if (assign) FAL_CHECK_HIP(hipMemcpyAsync(assign, ivf->assign, sizeof(int32_t) * (size_t)ivf->n, hipMemcpyDeviceToDevice, st));
+    if (perm) FAL_CHECK_HIP(hipMemcpyAsync(perm, ivf->perm, sizeof(int32_t) * (size_t)ivf->n, hipMemcpyDeviceToDevice, st));
+    if (list_off)
+        FAL_CHECK_HIP(hipMemcpyAsync(list_off, ivf->list_off, sizeof(int64_t) * (size_t)(ivf->total_lists + 1),
+                                     hipMemcpyDeviceToDevice, st));
+    return FAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Internal interface of scan.hip / ivf_fine.hip (launchers shared with ivf.hip).
+#pragma once
+#include "common.h"
+#include "simtile.h"
+
+namespace fal {
+
+enum { EPI_STORE = 0, EPI_ARGMAX = 1 };
+enum { MODE_DENSE = 0, MODE_IVF = 1 };
+
+struct SelectArgs {
+    const float* sims;       // sims buffer of the current batch
+    int64_t sims_base;       // float index the buffer starts at
+    int k;                   // how many to keep
+    float* out_sim;          // [rows, k]
+    int32_t* out_idx;        // [rows, k]
+    // MODE_DENSE: queries are the rows of dense tiles [tile_begin, ...)
+    const DenseJob* jobs;
+    int n_jobs;
+    int64_t tile_begin;
+    int ids_are_rows;        // ids = job.c_row0 + position (else position)
+    // MODE_IVF: queries are the rows of IVF tiles (jobs: q_row0 = first list-order position of
+    // the bucket, c_row0 = global id of its list 0, nc = its n_list)
+    int n_probe;
+    const int32_t* probes;       // [n, n_probe] bucket-local list ids (-1 = none)
+    const int64_t* list_off;     // [total_lists + 1] positions in list order
+    const int64_t* q_sim_off;    // [n] where the query's sims start (float index)
+    const int32_t* perm;         // [n] list-order position -> sorted row
+};
+
+struct FineArgs {
+    const float* Xl;             // vectors in (bucket, list, row) order
+    int d;
+    const DenseJob* jobs;        // as for MODE_IVF above
+    int n_jobs;
+    int64_t tile_begin, n_tiles;
+    int n_probe;
+    const int32_t* probes;
+    const int64_t* list_off;
+    const int64_t* q_sim_off;
+    float* sims;
+    int64_t sims_base;
+    int bm_words;                // LDS bitmap words  (>= max n_list / 32)
+    int u_cap;                   // LDS union capacity (>= min(32 * n_probe, max n_list))
+};
+
+int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,
+                 int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base, int32_t* assign);
+int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks);
+int launch_fine(fal_ctx* ctx, const FineArgs& a);
+
+}  // namespace fal

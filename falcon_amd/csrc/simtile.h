@@ -1,0 +1,98 @@
+// Shared device pieces of the cosine kernels (a6 assign, a7 coarse + fine scan).
+//
+// One 64-lane wave owns a tile of 32 query rows, kept ENTIRELY IN REGISTERS for the whole
+// tile (d/2 floats per lane: lane (r = l&31, h = l>>5) holds query r's k-half h), and streams
+// candidate rows 32 at a time straight from global memory / L2 into VGPRs with 16-byte loads
+// (each lane reads ITS OWN candidate row, so candidates may be any gather of rows).  The inner
+// products run on the fp32 matrix cores: v_mfma_f32_32x32x2_f32, one chain of d/2 MFMAs per
+// 32x32 block.  The k-slot of MFMA step kk is {k = kk (lanes 0-31), k = d/2 + kk (lanes 32-63)};
+// since both operands use the same slot->k map the result is the plain inner product, summed
+// as the chain  fma(a[d/2+kk] , b[d/2+kk], fma(a[kk], b[kk], acc)),  kk = 0 .. d/2-1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fal {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Which output row (0..31) of a 32x32 MFMA result lives in accumulator register `reg` of a
+// lane in half `h` (guide: row = (reg & 3) + 8 * (reg >> 2) + 4 * h; column = lane & 31).
+__device__ __forceinline__ int mfma32_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// Load one lane's k-half of a row into registers; slots beyond the real half are zero.
+template <int DH4>
+__device__ __forceinline__ void load_half_row(float (&q)[DH4 * 4], const float* __restrict__ row_half, int dh4) {
+    const float4* p = reinterpret_cast<const float4*>(row_half);
+#pragma unroll
+    for (int j = 0; j < DH4; ++j) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < dh4) v = p[j];
+        q[4 * j + 0] = v.x;
+        q[4 * j + 1] = v.y;
+        q[4 * j + 2] = v.z;
+        q[4 * j + 3] = v.w;
+    }
+}
+
+// acc[32x32] += rows(a-side) x rows(b-side)^T over the wave's k-slots.
+// QUERY_IS_A = true : D[query][cand]  (lane: candidate = lane&31, 16 query rows in registers)
+// QUERY_IS_A = false: D[cand][query]  (lane: query = lane&31, 16 candidate rows in registers)
+template <int DH4, bool QUERY_IS_A>
+__device__ __forceinline__ f32x16 tile_dot(const float (&q)[DH4 * 4], const float* __restrict__ cand_half, int dh4) {
+    const float4* p = reinterpret_cast<const float4*>(cand_half);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < DH4; ++j) {
+        // padded slots re-read the last real float4: q is zero there, so they add nothing
+        const float4 a = p[j < dh4 ? j : dh4 - 1];
+        if (QUERY_IS_A) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 0], a.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 1], a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 2], a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 3], a.w, acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * j + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * j + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * j + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * j + 3], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+// float -> uint32 whose unsigned order equals the float order (and back).
+__device__ __forceinline__ uint32_t f32_sortable(float f) {
+    uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float sortable_f32(uint32_t u) {
+    uint32_t b = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(b);
+}
+
+// One unit of dense work: the queries [q_row0, q_row0+nq) of array Q against the candidates
+// [c_row0, c_row0+nc) of array C.  Tiles of 32 queries; tile0 = index of the job's first tile
+// in the launch; obase = where the job's [nq, nc] block of sims starts (float index).
+struct DenseJob {
+    int64_t q_row0;
+    int64_t c_row0;
+    int64_t obase;
+    int64_t tile0;
+    int32_t nq;
+    int32_t nc;
+};
+
+// binary search: last job whose tile0 <= t
+__device__ __forceinline__ int find_job(const DenseJob* __restrict__ jobs, int n_jobs, int64_t t) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+}  // namespace fal

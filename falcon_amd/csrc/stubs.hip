@@ -3,11 +3,6 @@
 #define NOTYET(name) fal::set_error(name ": not implemented yet"); return FAL_EUNSUPPORTED
 extern "C" {
 int fal_precursor_splits(fal_ctx*, const float*, int64_t, double, int, int64_t, double, int, int64_t*, int64_t, int64_t*) { NOTYET("fal_precursor_splits"); }
-int fal_ivf_build(fal_ctx*, const float*, int64_t, int, const int64_t*, int64_t, const int32_t*, int, fal_ivf**) { NOTYET("fal_ivf_build"); }
-int fal_ivf_destroy(fal_ivf*) { NOTYET("fal_ivf_destroy"); }
-int fal_ivf_total_lists(const fal_ivf*, int64_t*) { NOTYET("fal_ivf_total_lists"); }
-int fal_ivf_export(fal_ctx*, const fal_ivf*, float*, int32_t*, int32_t*, int64_t*) { NOTYET("fal_ivf_export"); }
-int fal_ivf_search_topk(fal_ctx*, const fal_ivf*, int, int, float*, int32_t*) { NOTYET("fal_ivf_search_topk"); }
 int fal_filter_neighbors(fal_ctx*, const float*, const int32_t*, int64_t, int, const float*, const float*, double, int, double, int, int32_t*, float*) { NOTYET("fal_filter_neighbors"); }
 int fal_dbscan(fal_ctx*, const int32_t*, const float*, int64_t, int, float, int32_t*, int64_t*) { NOTYET("fal_dbscan"); }
 int fal_refine_clusters(fal_ctx*, int32_t*, int64_t, const float*, const float*, double, int, double, int64_t*) { NOTYET("fal_refine_clusters"); }

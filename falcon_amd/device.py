@@ -33,7 +33,7 @@ class Context:
         torch.cuda.set_device(self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         h = C.c_void_p()
-        check(self.lib.fal_ctx_create(self.device, C.c_void_p(stream), C.byref(h)), "fal_ctx_create")
+        check(self.lib.fal_ctx_create(self.device, C.c_void_p(stream), 0, C.byref(h)), "fal_ctx_create")
         self._h = h
 
     def close(self):
@@ -100,6 +100,63 @@ class Context:
                                      int(normalize), _lib.FAL_DTYPE_F16 if f16 else _lib.FAL_DTYPE_F32,
                                      self._p(out)), "fal_vectorize")
         return out
+
+
+    # ------------------------------------------------------------------ a6 / a7
+    def ivf_build(self, X, bucket_off: np.ndarray, n_list: np.ndarray, kmeans_iters: int = 10) -> "IvfIndex":
+        torch = _torch()
+        assert X.dtype == torch.float32 and X.is_contiguous() and X.device == self.tdev
+        n, d = X.shape
+        bo = np.ascontiguousarray(bucket_off, np.int64)
+        nl = np.ascontiguousarray(n_list, np.int32)
+        h = C.c_void_p()
+        check(self.lib.fal_ivf_build(self._h, self._p(X), n, d, bo.ctypes.data_as(C.c_void_p), len(nl),
+                                     nl.ctypes.data_as(C.c_void_p), int(kmeans_iters), C.byref(h)), "fal_ivf_build")
+        return IvfIndex(self, h, X, bo, nl)
+
+
+class IvfIndex:
+    """Opaque `fal_ivf` handle (keeps the vectors alive: the index borrows them)."""
+
+    def __init__(self, ctx: Context, handle, X, bucket_off, n_list):
+        self.ctx, self._h, self.X = ctx, handle, X
+        self.bucket_off, self.n_list = bucket_off, n_list
+        self.n, self.d = X.shape
+        t = C.c_int64()
+        check(ctx.lib.fal_ivf_total_lists(self._h, C.byref(t)))
+        self.total_lists = int(t.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx.lib.fal_ivf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def export(self):
+        """-> centroids [total_lists, d], assign [n], perm [n], list_off [total_lists+1] (device)."""
+        torch = _torch()
+        c = self.ctx
+        cent = c.empty((self.total_lists, self.d), torch.float32)
+        asg = c.empty((self.n,), torch.int32)
+        perm = c.empty((self.n,), torch.int32)
+        off = c.empty((self.total_lists + 1,), torch.int64)
+        check(c.lib.fal_ivf_export(c._h, self._h, c._p(cent), c._p(asg), c._p(perm), c._p(off)), "fal_ivf_export")
+        return cent, asg, perm, off
+
+    def search(self, n_probe: int, k_ann: int):
+        """-> sim f32[n, k_ann] (pad -inf), idx i32[n, k_ann] (pad -1), rows = sorted rows."""
+        torch = _torch()
+        c = self.ctx
+        sim = c.empty((self.n, k_ann), torch.float32)
+        idx = c.empty((self.n, k_ann), torch.int32)
+        check(c.lib.fal_ivf_search_topk(c._h, self._h, int(n_probe), int(k_ann), c._p(sim), c._p(idx)),
+              "fal_ivf_search_topk")
+        return sim, idx
 
 
 def get_dim(min_mz: float, max_mz: float, bin_size: float):

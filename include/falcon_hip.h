@@ -51,9 +51,10 @@ typedef struct fal_ivf fal_ivf;
 int         fal_version(void);
 const char* fal_last_error(void);
 int fal_device_count(int* count);
-/* `stream` may be NULL (the library creates its own) or an existing hipStream_t
- * (e.g. torch.cuda.current_stream().cuda_stream) the context will enqueue on. */
-int fal_ctx_create(int device, void* stream, fal_ctx** out);
+/* own_stream != 0: the library creates (and later destroys) a private stream and `stream`
+ * is ignored.  own_stream == 0: the context enqueues on the caller's hipStream_t `stream`
+ * (e.g. torch.cuda.current_stream().cuda_stream; NULL is the legacy default stream). */
+int fal_ctx_create(int device, void* stream, int own_stream, fal_ctx** out);
 int fal_ctx_destroy(fal_ctx* ctx);
 int fal_ctx_sync(fal_ctx* ctx);
 /* Elapsed milliseconds (HIP events on the context's stream) of the kernels the LAST
