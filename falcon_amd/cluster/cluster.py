@@ -1,0 +1,155 @@
+"""Drop-in for `falcon.cluster.cluster.generate_clusters` (reference
+falcon/cluster/cluster.py:24-156; call site falcon/falcon.py:178-188) with the
+distance + linkage core replaced by the README's vectorise -> ANN -> DBSCAN path,
+every stage of which runs in libfalcon_hip.so on one MI355X.
+
+Host logic only: argument handling, the per-bucket `n_list` rule and the order of the
+C-ABI calls.  No CPU fallback exists.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .. import device as _device
+
+logger = logging.getLogger("falcon")
+
+FLAT_MAX = 100           # buckets up to this size use a flat (single list) index
+MIN_PTS_PER_LIST = 39    # [SURVEY App. A] Faiss' minimum points per centroid
+MAX_N_LIST = 1 << 17
+
+
+@dataclass
+class AnnParams:
+    """The README's nearest-neighbour options (README.md:73-79, 107-117) plus the build's."""
+    eps: float = 0.1
+    low_dim: int = 400
+    n_probe: int = 16
+    n_neighbors: int = 64
+    n_neighbors_ann: int = 128
+    mz_interval: float = 1.0      # fixed precursor windows in m/z (0 = off) [SURVEY 8(d)]
+    kmeans_iters: int = 10        # Faiss IVF default (cp.niter = 10)
+    hash_seed: int = 0
+    min_mz: float = 101.0
+    max_mz: float = 1500.0
+    dtype: str = "f32"
+
+
+def n_list_rule(sizes: np.ndarray, n_probe: int) -> np.ndarray:
+    """lists per bucket: flat for tiny buckets, else 2^floor(log2(n/39)) [SURVEY App. A];
+    a bucket whose lists would ALL be probed (n_list <= n_probe) is searched exhaustively
+    anyway, so it is kept flat and k-means is skipped (same result)."""
+    sizes = np.asarray(sizes, np.int64)
+    nl = np.ones(len(sizes), np.int64)
+    big = sizes > FLAT_MAX
+    if big.any():
+        nl[big] = 2 ** np.floor(np.log2(sizes[big] / MIN_PTS_PER_LIST)).astype(np.int64)
+    nl = np.minimum(nl, MAX_N_LIST)
+    nl[nl <= n_probe] = 1
+    return nl.astype(np.int32)
+
+
+class SpectrumDataset:
+    """The five columns `generate_clusters` reads (cluster.py:73-85) in CSR form:
+    precursor_mz f32[N], retention_time f32[N], mz f32[nnz], intensity f32[nnz],
+    indptr i64[N+1].  Arrays may be numpy (uploaded) or tensors already on the GPU."""
+
+    def __init__(self, precursor_mz, retention_time, mz, intensity, indptr, precursor_charge=None):
+        self.precursor_mz, self.retention_time = precursor_mz, retention_time
+        self.mz, self.intensity, self.indptr = mz, intensity, indptr
+        self.precursor_charge = precursor_charge
+
+    def __len__(self):
+        return int(self.precursor_mz.shape[0])
+
+    @classmethod
+    def from_table(cls, table):
+        """pyarrow Table / pandas DataFrame with the Lance schema of falcon.py:275-285."""
+        if hasattr(table, "to_pandas"):
+            table = table.to_pandas()
+        mzs = [np.asarray(x, np.float32) for x in table["mz"]]
+        its = [np.asarray(x, np.float32) for x in table["intensity"]]
+        indptr = np.zeros(len(mzs) + 1, np.int64)
+        np.cumsum([len(x) for x in mzs], out=indptr[1:])
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.float32)
+        return cls(np.asarray(table["precursor_mz"], np.float32), np.asarray(table["retention_time"], np.float32),
+                   cat(mzs), cat(its), indptr,
+                   np.asarray(table["precursor_charge"]) if "precursor_charge" in table else None)
+
+
+class ClusterPipeline:
+    """vectorise -> sort -> buckets -> IVF -> search -> filter -> DBSCAN -> refine -> medoids,
+    device-resident from the first call to the last."""
+
+    def __init__(self, ctx: Optional[_device.Context] = None, device: int = 0):
+        self.ctx = ctx or _device.Context(device)
+        self.last = {}
+
+    def run(self, ds: SpectrumDataset, precursor_tol_mass: float, precursor_tol_mode: str,
+            rt_tol: Optional[float], fragment_tol: float, batch_size: int, p: AnnParams,
+            keep_intermediates: bool = False):
+        """-> (labels_dev i32[N], medoids_dev i32[n_labels]) as device tensors."""
+        import torch
+        c = self.ctx
+        n = len(ds)
+        if n == 0:
+            return c.empty((0,), torch.int32), c.empty((0,), torch.int32)
+        n_bins, start, _ = _device.get_dim(p.min_mz, p.max_mz, fragment_tol)      # falcon.py:124-126
+        pmz = c.to_dev(ds.precursor_mz, torch.float32)
+        order, mzs = c.sort_by_precursor(pmz)                                      # cluster.py:73-85
+        rts = c.gather_f32(ds.retention_time, order) if (rt_tol is not None and ds.retention_time is not None) else None
+        splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
+        X = c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
+                        p.hash_seed, True, "f32")
+        n_list = n_list_rule(np.diff(splits), p.n_probe)
+        index = c.ivf_build(X, splits, n_list, p.kmeans_iters)
+        sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
+        nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
+                                             p.n_neighbors)
+        db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)
+        if keep_intermediates:
+            self.last = dict(order=order, mz_sorted=mzs, rt_sorted=rts, splits=splits, X=X, n_list=n_list,
+                             sim=sim, idx=idx, nb_idx=nb_idx, nb_dist=nb_dist, db=db.clone(), n_db=n_db, index=index)
+        lab, n_cl = c.refine_clusters(db, n_db, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol)
+        if keep_intermediates:
+            self.last.update(lab_sorted=lab, n_clusters=n_cl)
+        labels, medoids = c.finalize(lab, n_cl, order, nb_idx, nb_dist)
+        if not keep_intermediates:
+            index.close()
+        return labels, medoids
+
+
+_default_pipeline: Optional[ClusterPipeline] = None
+
+
+def generate_clusters(dataset, linkage: str, distance_threshold: float, min_matches: int,
+                      precursor_tol_mass: float, precursor_tol_mode: str, rt_tol: Optional[float],
+                      fragment_tol: float, batch_size: int, *, ann: Optional[AnnParams] = None,
+                      pipeline: Optional[ClusterPipeline] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Same call as the reference (cluster.py:24-34).  `distance_threshold` is the cosine
+    distance threshold and plays the role of DBSCAN's eps (README.md:73-79); `linkage` and
+    `min_matches` belong to the snapshot's exact-cosine path and are accepted but unused.
+
+    Returns (labels int32[N] by dataset row with noise renumbered as singletons --
+    cluster.py:144-155 --, medoids int32[n_labels]: medoids[c] = dataset row representing
+    cluster c, usable as `dataset.take(medoids)`, falcon.py:198-203)."""
+    global _default_pipeline
+    if not isinstance(dataset, SpectrumDataset):
+        dataset = SpectrumDataset.from_table(
+            dataset.to_table(columns=["precursor_mz", "precursor_charge", "retention_time", "mz", "intensity"])
+            if hasattr(dataset, "to_table") else dataset)
+    p = ann or AnnParams()
+    if ann is None:
+        p.eps = distance_threshold
+    pipe = pipeline or _default_pipeline
+    if pipe is None:
+        pipe = _default_pipeline = ClusterPipeline()
+    logger.info("Cluster %d spectra: low_dim=%d n_probe=%d n_neighbors=%d/%d eps=%.3f", len(dataset), p.low_dim,
+                p.n_probe, p.n_neighbors, p.n_neighbors_ann, p.eps)
+    labels, medoids = pipe.run(dataset, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, batch_size, p)
+    return labels.cpu().numpy(), medoids.cpu().numpy()

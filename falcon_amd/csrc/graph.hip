@@ -1,0 +1,194 @@
+// a8 neighbour filter + distance, a9 DBSCAN(min_samples = 2) on the sparse neighbour graph.
+//
+// Reference: tolerance arithmetic as cluster.py:190-195 uses spectrum_utils.mass_diff;
+// distance = 1 - sim (cluster.py:626) clamped to [0, 1] (similarity.py:78); min_samples = 2
+// (cluster.py:66); DBSCAN itself is README.md:143-146.  HBM-bound integer/graph work: one pass
+// over the [n, k_ann] search result, two passes over the [n, k] neighbour lists.
+#include <math.h>
+#include "common.h"
+#include "ivf.h"
+#include "util.h"
+
+namespace fal {
+
+// ------------------------------------------------------------------------------------------
+// a8: one wave per row; the row is already sorted by descending similarity
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ sim, const int32_t* __restrict__ idx,
+                                                     int64_t n, int k_ann, const float* __restrict__ pmz,
+                                                     const float* __restrict__ rt, double tol, int is_da,
+                                                     double rt_tol, int k, int32_t* __restrict__ nb_idx,
+                                                     float* __restrict__ nb_dist) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float qmz = pmz[row];
+    const float qrt = rt ? rt[row] : 0.f;
+    int kept = 0;
+    for (int c0 = 0; c0 < k_ann && kept < k; c0 += 64) {
+        const int c = c0 + lane;
+        bool ok = false;
+        int32_t j = -1;
+        float s = 0.f;
+        if (c < k_ann) {
+            j = idx[row * k_ann + c];
+            s = sim[row * k_ann + c];
+            if (j >= 0 && (int64_t)j != row) {
+                const float nmz = pmz[j];
+                const float diff = qmz - nmz;     // mass_diff(query, neighbour)
+                const double md = is_da ? (double)diff : (double)(diff / nmz) * 1e6;
+                ok = fabs(md) <= tol;
+                if (ok && rt && rt_tol >= 0.0) ok = fabs((double)(qrt - rt[j])) <= rt_tol;
+            }
+        }
+        const uint64_t mask = __ballot(ok);
+        const int pos = kept + __popcll(mask & ((1ull << lane) - 1ull));
+        if (ok && pos < k) {
+            nb_idx[row * k + pos] = j;
+            nb_dist[row * k + pos] = fminf(fmaxf(1.0f - s, 0.f), 1.f);
+        }
+        kept += __popcll(mask);
+    }
+    kept = min(kept, k);
+    for (int c = kept + lane; c < k; c += 64) {
+        nb_idx[row * k + c] = -1;
+        nb_dist[row * k + c] = INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a9
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool edge_ok(int32_t j, float dist, int64_t i, float eps) {
+    return j >= 0 && (int64_t)j != i && dist <= eps;
+}
+
+// core(i) <=> row i stores a neighbour within eps (the point itself is the other sample)
+__global__ void dbscan_core_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist, int64_t n,
+                                   int k, float eps, int32_t* __restrict__ core, int32_t* __restrict__ parent,
+                                   int32_t* __restrict__ border_src) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        bool c = false;
+        for (int s = 0; s < k && !c; ++s) c = edge_ok(nb_idx[i * k + s], nb_dist[i * k + s], i, eps);
+        core[i] = c;
+        parent[i] = (int32_t)i;
+        border_src[i] = 0x7fffffff;
+    }
+}
+
+__device__ __forceinline__ int32_t uf_find(int32_t* parent, int32_t x) {
+    // path halving; parent links only ever point to smaller ids
+    int32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        const int32_t g = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g != p) __hip_atomic_store(&parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p;
+        p = g;
+    }
+    return x;
+}
+
+// hook the larger root under the smaller one (so every component's root is its lowest core row)
+__device__ __forceinline__ void uf_union(int32_t* parent, int32_t a, int32_t b) {
+    while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int32_t t = a; a = b; b = t; }     // a > b
+        const int32_t old = atomicCAS(&parent[a], a, b);
+        if (old == a) return;
+    }
+}
+
+// one thread per stored edge: core->core edges are united, core->border edges vote for the
+// border point's lowest-index core in-neighbour
+__global__ void dbscan_edges_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist, int64_t n,
+                                    int k, float eps, const int32_t* __restrict__ core, int32_t* __restrict__ parent,
+                                    int32_t* __restrict__ border_src) {
+    const int64_t total = n * k;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / k;
+        if (!core[i]) continue;
+        const int32_t j = nb_idx[e];
+        if (!edge_ok(j, nb_dist[e], i, eps)) continue;
+        if (core[j]) uf_union(parent, (int32_t)i, j);
+        else atomicMin(&border_src[j], (int32_t)i);
+    }
+}
+
+__global__ void dbscan_roots_kernel(const int32_t* __restrict__ core, int32_t* __restrict__ parent, int64_t n,
+                                    int32_t* __restrict__ is_root) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int32_t r = 0;
+        if (core[i]) {
+            const int32_t root = uf_find(parent, (int32_t)i);
+            parent[i] = root;
+            r = root == (int32_t)i;
+        }
+        is_root[i] = r;
+    }
+}
+
+__global__ void dbscan_label_kernel(const int32_t* __restrict__ core, const int32_t* __restrict__ parent,
+                                    const int32_t* __restrict__ border_src, const int64_t* __restrict__ root_rank,
+                                    int64_t n, int32_t* __restrict__ labels) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int32_t lab = -1;
+        if (core[i]) lab = (int32_t)root_rank[parent[i]];
+        else if (border_src[i] != 0x7fffffff) lab = (int32_t)root_rank[parent[border_src[i]]];
+        labels[i] = lab;
+    }
+}
+
+}  // namespace fal
+
+using namespace fal;
+
+extern "C" {
+
+int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int64_t n, int k_ann,
+                         const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
+                         double rt_tol, int n_neighbors, int32_t* nb_idx, float* nb_dist) {
+    FAL_REQUIRE(ctx && n >= 0 && k_ann >= 1 && n_neighbors >= 1, FAL_EINVAL, "fal_filter_neighbors: bad argument");
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(sim && idx && precursor_mz_sorted && nb_idx && nb_dist, FAL_EINVAL, "fal_filter_neighbors: NULL array");
+    ctx->stage_reset(ST_FILTER);
+    StageScope ts(ctx, ST_FILTER);
+    hipLaunchKernelGGL(filter_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, sim, idx, n, k_ann,
+                       precursor_mz_sorted, rt_tol >= 0.0 ? rt_sorted : nullptr, tol, tol_is_da, rt_tol, n_neighbors,
+                       nb_idx, nb_dist);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+int fal_dbscan(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps, int32_t* labels,
+               int64_t* n_clusters) {
+    FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_dbscan: bad argument");
+    if (n_clusters) *n_clusters = 0;
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(nb_idx && nb_dist && labels, FAL_EINVAL, "fal_dbscan: NULL array");
+    int32_t* buf = nullptr;
+    int64_t* rank = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int32_t) * (size_t)n * 4, (void**)&buf));
+    FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(n + 1), (void**)&rank));
+    int32_t *core = buf, *parent = buf + n, *border = buf + 2 * n, *is_root = buf + 3 * n;
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
+    const int egrid = (int)std::min<int64_t>(ceil_div(n * k, 256), (int64_t)ctx->num_cus * 32);
+    ctx->stage_reset(ST_DBSCAN);
+    {
+        StageScope ts(ctx, ST_DBSCAN);
+        hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent, border);
+        hipLaunchKernelGGL(dbscan_edges_kernel, dim3(egrid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent, border);
+        hipLaunchKernelGGL(dbscan_roots_kernel, dim3(grid), dim3(256), 0, ctx->stream, core, parent, n, is_root);
+        FAL_TRY(device_scan_i32(ctx, is_root, n, rank, SLOT_TAIL3));
+        hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, ctx->stream, core, parent, border, rank, n, labels);
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    if (n_clusters) {
+        FAL_CHECK_HIP(hipMemcpyAsync(n_clusters, rank + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return FAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+// Plumbing around the hot path: stable sort by precursor m/z (reference cluster.py:73-85),
+// precursor-m/z bucket boundaries (cluster.py:159-209), gathers, device-wide scans.
+// The radix sort is rocPRIM's (AMD's own primitive library); everything else is hand-written.
+#include <cstring>
+#include <math.h>
+#include <algorithm>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "common.h"
+#include "ivf.h"
+#include "util.h"
+
+namespace fal {
+
+// ------------------------------------------------------------------------------------------
+// device-wide exclusive scan of int32 values (flags): out[i] = sum_{j<i} in[j]; *total_dev = sum
+// ------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 1024;
+
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                                     int64_t* __restrict__ block_sums) {
+    __shared__ int64_t ws[kScanBlock / 64];
+    const int64_t i = blockIdx.x * (int64_t)kScanBlock + threadIdx.x;
+    int64_t v = i < n ? in[i] : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t s = 0;
+        for (int j = 0; j < kScanBlock / 64; ++j) s += ws[j];
+        block_sums[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                                const int64_t* __restrict__ block_off,
+                                                                int64_t* __restrict__ out) {
+    __shared__ int64_t ws[kScanBlock / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x * (int64_t)kScanBlock + threadIdx.x;
+    const int64_t v = i < n ? in[i] : 0;
+    int64_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) ws[w] = x;
+    __syncthreads();
+    int64_t pre = block_off[blockIdx.x];
+    for (int j = 0; j < w; ++j) pre += ws[j];
+    if (i < n) out[i] = pre + x - v;
+}
+
+// out[0..n) exclusive prefix of in[0..n) ; out[n] = total.  tmp: ceil(n/1024)+1 int64 (x2).
+int device_scan_i32(fal_ctx* ctx, const int32_t* in, int64_t n, int64_t* out, int scratch_slot) {
+    if (n <= 0) {
+        FAL_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int64_t), ctx->stream));
+        return FAL_OK;
+    }
+    const int64_t nb = ceil_div(n, kScanBlock);
+    int64_t* tmp = nullptr;
+    FAL_TRY(ctx->reserve(scratch_slot, sizeof(int64_t) * (size_t)(2 * nb + 2), (void**)&tmp));
+    int64_t* sums = tmp;
+    int64_t* offs = tmp + nb + 1;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, sums);
+    FAL_TRY(launch_exclusive_scan(ctx, sums, nb, offs));
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, offs, out);
+    // total
+    FAL_CHECK_HIP(hipMemcpyAsync(out + n, offs + nb, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sort / gather
+// ------------------------------------------------------------------------------------------
+__global__ void iota_i64_kernel(int64_t* out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = i;
+}
+
+__global__ void gather_f32_kernel(const float* __restrict__ src, const int64_t* __restrict__ order, int64_t n,
+                                  float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = src[order[i]];
+}
+
+int sort_pairs_u32_i32(fal_ctx* ctx, const uint32_t* kin, uint32_t* kout, const int32_t* vin, int32_t* vout,
+                       int64_t n, int end_bit, int scratch_slot) {
+    size_t bytes = 0;
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, ctx->stream));
+    void* tmp = nullptr;
+    FAL_TRY(ctx->reserve(scratch_slot, bytes, &tmp));
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, ctx->stream));
+    return FAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// a5: flags where a new bucket may start
+// ------------------------------------------------------------------------------------------
+// bit 0: reference gap  mass_diff(mz[i], mz[i-1]) > tol  (cluster.py:186-197; float32 difference and
+//        division, float64 product with 10**6 -- the typing numba gives spectrum_utils.mass_diff)
+// bit 1: fixed-window cut  floor(mz[i] / w) != floor(mz[i-1] / w)   [build rule]
+__global__ void split_flags_kernel(const float* __restrict__ mz, int64_t n, double tol, int is_da, double window,
+                                   int32_t* __restrict__ flag) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int f = 0;
+        if (i > 0) {
+            const float a = mz[i], b = mz[i - 1];
+            const float diff = a - b;
+            const double md = is_da ? (double)diff : (double)(diff / b) * 1e6;
+            if (md > tol) f |= 1;
+            if (window > 0.0 && floor((double)a / window) != floor((double)b / window)) f |= 2;
+        }
+        flag[i] = f;
+    }
+}
+
+__global__ void compact_flags_kernel(const int32_t* __restrict__ flag, const int64_t* __restrict__ pos, int64_t n,
+                                     int64_t* __restrict__ out_idx, int32_t* __restrict__ out_flag) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (flag[i]) {
+            out_idx[pos[i]] = i;
+            out_flag[pos[i]] = flag[i];
+        }
+    }
+}
+
+__global__ void nonzero_i32_kernel(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i] != 0;
+}
+
+}  // namespace fal
+
+using namespace fal;
+
+extern "C" {
+
+int fal_sort_by_precursor(fal_ctx* ctx, const float* precursor_mz, int64_t n, int64_t* order_out, float* mz_sorted_out) {
+    FAL_REQUIRE(ctx && n >= 0, FAL_EINVAL, "fal_sort_by_precursor: bad argument");
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(precursor_mz && order_out && mz_sorted_out, FAL_EINVAL, "fal_sort_by_precursor: NULL array");
+    int64_t* iota = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_SORT, sizeof(int64_t) * (size_t)n, (void**)&iota));
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(iota_i64_kernel, dim3(grid), dim3(256), 0, ctx->stream, iota, n);
+    size_t bytes = 0;
+    // LSD radix sort is stable: equal m/z keep dataset order (the oracle sorts with kind="stable")
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, precursor_mz, mz_sorted_out, iota, order_out, (size_t)n, 0, 32,
+                                            ctx->stream));
+    void* tmp = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_SORT2, bytes, &tmp));
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs(tmp, bytes, precursor_mz, mz_sorted_out, iota, order_out, (size_t)n, 0, 32,
+                                            ctx->stream));
+    return FAL_OK;
+}
+
+int fal_gather_f32(fal_ctx* ctx, const float* src, const int64_t* order, int64_t n, float* out) {
+    FAL_REQUIRE(ctx && n >= 0, FAL_EINVAL, "fal_gather_f32: bad argument");
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(src && order && out, FAL_EINVAL, "fal_gather_f32: NULL array");
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(gather_f32_kernel, dim3(grid), dim3(256), 0, ctx->stream, src, order, n, out);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+int fal_precursor_splits(fal_ctx* ctx, const float* mz, int64_t n, double tol, int tol_is_da, int64_t batch_size,
+                         double mz_interval, int chunk_last, int64_t* splits_out, int64_t max_splits,
+                         int64_t* n_splits) {
+    FAL_REQUIRE(ctx && splits_out && n_splits && n >= 0 && batch_size >= 1 && max_splits >= 2, FAL_EINVAL,
+                "fal_precursor_splits: bad argument");
+    *n_splits = 0;
+    std::vector<int64_t> gap_idx;
+    std::vector<int32_t> gap_flag;
+    if (n > 1) {
+        FAL_REQUIRE(mz, FAL_EINVAL, "fal_precursor_splits: NULL mz");
+        int32_t *flag = nullptr, *nz = nullptr, *cflag = nullptr;
+        int64_t *pos = nullptr, *cidx = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int32_t) * (size_t)n * 2, (void**)&flag));
+        nz = flag + n;
+        FAL_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * (size_t)(n + 1), (void**)&pos));
+        const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+        hipLaunchKernelGGL(split_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, mz, n, tol, tol_is_da, mz_interval, flag);
+        hipLaunchKernelGGL(nonzero_i32_kernel, dim3(grid), dim3(256), 0, ctx->stream, flag, n, nz);
+        FAL_TRY(device_scan_i32(ctx, nz, n, pos, SLOT_SORT));
+        int64_t total = 0;
+        FAL_CHECK_HIP(hipMemcpyAsync(&total, pos + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (total > 0) {
+            FAL_TRY(ctx->reserve(SLOT_SORT2, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)total, (void**)&cidx));
+            cflag = reinterpret_cast<int32_t*>(cidx + total);
+            hipLaunchKernelGGL(compact_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, flag, pos, n, cidx, cflag);
+            gap_idx.resize(total);
+            gap_flag.resize(total);
+            FAL_CHECK_HIP(hipMemcpyAsync(gap_idx.data(), cidx, sizeof(int64_t) * total, hipMemcpyDeviceToHost, ctx->stream));
+            FAL_CHECK_HIP(hipMemcpyAsync(gap_flag.data(), cflag, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx->stream));
+            FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    // reference cluster.py:183-208 over the gap positions (host; a few entries per bucket)
+    std::vector<int64_t> splits(1, 0);
+    auto chunk_block = [&](int64_t block) {
+        const int64_t n_chunks = (block + batch_size - 1) / batch_size;
+        const int64_t chunk = block / n_chunks;
+        for (int64_t c = 0; c < block % n_chunks; ++c) splits.push_back(splits.back() + chunk + 1);
+        for (int64_t c = 0; c < n_chunks - (block % n_chunks); ++c) splits.push_back(splits.back() + chunk);
+    };
+    for (size_t g = 0; g < gap_idx.size(); ++g) {
+        if (!(gap_flag[g] & 1)) continue;
+        const int64_t i = gap_idx[g], block = i - splits.back();
+        if (block < batch_size) splits.push_back(i); else chunk_block(block);
+    }
+    if (chunk_last && n - splits.back() >= batch_size) chunk_block(n - splits.back());   // [build rule]
+    if (splits.back() != n || n == 0) splits.push_back(n);
+    // [build rule] fixed windows
+    std::vector<int64_t> all(splits);
+    for (size_t g = 0; g < gap_idx.size(); ++g)
+        if (gap_flag[g] & 2) all.push_back(gap_idx[g]);
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    FAL_REQUIRE((int64_t)all.size() <= max_splits, FAL_EINVAL, "fal_precursor_splits: %zu boundaries do not fit max_splits %lld",
+                all.size(), (long long)max_splits);
+    memcpy(splits_out, all.data(), sizeof(int64_t) * all.size());
+    *n_splits = (int64_t)all.size();
+    return FAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,452 @@
+// a10 precursor / RT refinement of the DBSCAN clusters, a11 medoids, a12 label globalisation.
+//
+// Reference: falcon/cluster/cluster.py:362-455 (_postprocess_cluster), 458-509 (_linkage),
+// 512-553 (_get_cluster_medoids), 556-590 + 144-155 (global labels), with the flat cut
+// scipy.cluster.hierarchy.fcluster(Z, t, "distance") restated (cluster numbering included, it
+// matters for the m/z x RT combination of cluster.py:418-429).
+//
+// One wave per DBSCAN cluster.  Members are the cluster's rows in ascending (precursor-sorted)
+// row order.  All per-cluster working arrays live in a global scratch slab at the cluster's own
+// offsets (clusters are tiny on average, so this stays in L2); every loop is strided over the
+// 64 lanes, so one huge cluster costs O(m^2 / 64), not O(m^2).
+#include <math.h>
+#include "common.h"
+#include "ivf.h"
+#include "util.h"
+
+namespace fal {
+
+struct RefineScratch {
+    float* val;      // [n] the values being linked (m/z, then RT) in member order
+    int32_t* ord;    // [n] member index by ascending value (stable)
+    float* smin;     // [n] current segments, left to right
+    float* smax;
+    int32_t* sid;    // linkage node id of the segment (leaf = member index, merged = m + it)
+    int32_t* zl;     // [n] linkage rows: left child, right child, max height in subtree
+    int32_t* zr;
+    double* zmd;
+    int32_t* t_a;    // [n] flat cluster number of each member from m/z
+    int32_t* t_b;    // [n] ... from RT
+    int32_t* stack;  // [n] traversal stack / scratch
+    int32_t* visit;  // [n] traversal visited flags / scratch
+};
+
+__device__ __forceinline__ double link_dist(float hi, float lo, bool ppm) {
+    const float diff = hi - lo;                           // cluster.py:488 (float32)
+    return ppm ? (double)(diff / lo) * 1e6 : (double)diff;   // cluster.py:489-490
+}
+
+// Complete-linkage dendrogram of the m values val[0..m) (cluster.py:458-509) and its flat cut at
+// threshold t numbered like scipy's fcluster (minus 1), into T[0..m).
+// exact = false: stop at the first merge above t and number the segments left to right (same
+// partition; the numbering is then irrelevant to the caller).
+__device__ void flat_cut_1d(const RefineScratch& S, int64_t o, int m, double t, bool ppm, bool exact,
+                            int32_t* __restrict__ T, int lane) {
+    const float* val = S.val + o;
+    int32_t* ord = S.ord + o;
+    float *smin = S.smin + o, *smax = S.smax + o;
+    int32_t *sid = S.sid + o, *zl = S.zl + o, *zr = S.zr + o, *stack = S.stack + o, *visit = S.visit + o;
+    double* zmd = S.zmd + o;
+    // stable argsort by counting
+    for (int e = lane; e < m; e += 64) {
+        const float v = val[e];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const float w = val[j];
+            rank += (w < v) || (w == v && j < e);
+        }
+        ord[rank] = e;
+    }
+    __syncthreads();
+    for (int s = lane; s < m; s += 64) {
+        const int e = ord[s];
+        smin[s] = smax[s] = val[e];
+        sid[s] = e;
+    }
+    __syncthreads();
+    int nseg = m, n_merge = 0;
+    for (int it = 0; it < m - 1; ++it) {
+        // leftmost minimum of dist(s) = smax[s+1] - smin[s]  (cluster.py:486-492)
+        double best = INFINITY;
+        int bs = 0x7fffffff;
+        for (int s = lane; s < nseg - 1; s += 64) {
+            const double dd = link_dist(smax[s + 1], smin[s], ppm);
+            if (dd < best) {
+                best = dd;
+                bs = s;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int os = __shfl_xor(bs, off, 64);
+            if (ob < best || (ob == best && os < bs)) {
+                best = ob;
+                bs = os;
+            }
+        }
+        if (bs == 0x7fffffff) bs = 0;           // all distances NaN: take the first pair like np.inf init would not; keep going
+        if (!exact && !(best <= t)) break;
+        if (lane == 0) {
+            const int l = sid[bs], r = sid[bs + 1];
+            double md = best;
+            if (l >= m) md = fmax(md, zmd[l - m]);
+            if (r >= m) md = fmax(md, zmd[r - m]);
+            zl[it] = l;
+            zr[it] = r;
+            zmd[it] = md;
+            smax[bs] = smax[bs + 1];
+            sid[bs] = m + it;
+        }
+        __syncthreads();
+        // delete segment bs+1: shift the tail left by one, 64 at a time in ascending order
+        for (int s0 = bs + 1; s0 < nseg - 1; s0 += 64) {
+            const int s = s0 + lane;
+            float a = 0.f, b = 0.f;
+            int c = 0;
+            const bool on = s < nseg - 1;
+            if (on) {
+                a = smin[s + 1];
+                b = smax[s + 1];
+                c = sid[s + 1];
+            }
+            __syncthreads();
+            if (on) {
+                smin[s] = a;
+                smax[s] = b;
+                sid[s] = c;
+            }
+            __syncthreads();
+        }
+        --nseg;
+        ++n_merge;
+    }
+    if (!exact) {
+        // Surviving segments are contiguous runs of the sorted order; number them left to right.
+        // The run length of a segment = number of leaves under its linkage node.
+        if (lane == 0) {
+            for (int it = 0; it < n_merge; ++it) {
+                const int l = zl[it], r = zr[it];
+                stack[it] = (l >= m ? stack[l - m] : 1) + (r >= m ? stack[r - m] : 1);
+            }
+            int p = 0;
+            for (int s = 0; s < nseg; ++s) {
+                const int id = sid[s];
+                const int sz = id >= m ? stack[id - m] : 1;
+                for (int q = 0; q < sz; ++q) visit[p++] = s;
+            }
+        }
+        __syncthreads();
+        for (int p = lane; p < m; p += 64) T[ord[p]] = visit[p];
+        __syncthreads();
+        return;
+    }
+    // scipy _hierarchy.cluster_monocrit(Z, MD, T, cutoff, n): depth-first from the root, left
+    // child first; a subtree whose max height <= cutoff becomes one flat cluster; numbers are
+    // handed out in visiting order.
+    if (lane == 0) {
+        for (int i = 0; i < m - 1; ++i) visit[i] = 0;
+        int k = 0, n_cluster = 0, leader = -1;
+        stack[0] = 2 * m - 2;
+        while (k >= 0) {
+            const int root = stack[k] - m;
+            const int lc = zl[root], rc = zr[root];
+            if (leader == -1 && zmd[root] <= t) {
+                leader = root;
+                ++n_cluster;
+            }
+            if (lc >= m && !visit[lc - m]) {
+                visit[lc - m] = 1;
+                stack[++k] = lc;
+                continue;
+            }
+            if (rc >= m && !visit[rc - m]) {
+                visit[rc - m] = 1;
+                stack[++k] = rc;
+                continue;
+            }
+            if (lc < m) {
+                if (leader == -1) ++n_cluster;
+                T[lc] = n_cluster - 1;
+            }
+            if (rc < m) {
+                if (leader == -1) ++n_cluster;
+                T[rc] = n_cluster - 1;
+            }
+            if (leader == root) leader = -1;
+            --k;
+        }
+    }
+    __syncthreads();
+}
+
+// one wave per DBSCAN cluster c: rows[seg[c] .. seg[c+1]) are its members (ascending rows)
+__global__ __launch_bounds__(64) void refine_kernel(const int32_t* __restrict__ rows, const int64_t* __restrict__ seg,
+                                                    const float* __restrict__ mz, const float* __restrict__ rt,
+                                                    double tol, int is_da, double rt_tol, RefineScratch S,
+                                                    int32_t* __restrict__ sub, int32_t* __restrict__ n_sub) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t o = seg[c];
+    const int m = (int)(seg[c + 1] - o);
+    const bool use_rt = rt != nullptr && rt_tol >= 0.0;
+    int32_t* out = sub + o;
+    if (m < 2) {                                   // cluster.py:399-402 (min_samples = 2)
+        for (int e = lane; e < m; e += 64) out[e] = -1;
+        if (lane == 0) n_sub[c] = 0;
+        return;
+    }
+    int32_t* A = S.t_a + o;
+    for (int e = lane; e < m; e += 64) S.val[o + e] = mz[rows[o + e]];
+    __syncthreads();
+    flat_cut_1d(S, o, m, tol, !is_da, use_rt, A, lane);
+    if (use_rt) {
+        int32_t* B = S.t_b + o;
+        for (int e = lane; e < m; e += 64) S.val[o + e] = rt[rows[o + e]];
+        __syncthreads();
+        flat_cut_1d(S, o, m, rt_tol, false, true, B, lane);
+        // cluster.py:423-429: np.unique(a * 2 + b * 3, return_inverse=True)[1]
+        int32_t* V = S.stack + o;
+        int32_t* first = S.visit + o;
+        for (int e = lane; e < m; e += 64) V[e] = A[e] * 2 + B[e] * 3;
+        __syncthreads();
+        for (int e = lane; e < m; e += 64) {
+            bool f = true;
+            for (int j = 0; j < e && f; ++j) f = V[j] != V[e];
+            first[e] = f;
+        }
+        __syncthreads();
+        for (int e = lane; e < m; e += 64) {
+            int r = 0;
+            for (int j = 0; j < m; ++j) r += first[j] && V[j] < V[e];
+            A[e] = r;
+        }
+        __syncthreads();
+    }
+    // number of flat clusters = max + 1
+    int mx = 0;
+    for (int e = lane; e < m; e += 64) mx = max(mx, A[e]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+    const int n_flat = mx + 1;
+    if (n_flat == 1) {                              // cluster.py:433-435
+        for (int e = lane; e < m; e += 64) out[e] = 0;
+        if (lane == 0) n_sub[c] = 1;
+        return;
+    }
+    if (n_flat == m) {                              // cluster.py:436-439
+        for (int e = lane; e < m; e += 64) out[e] = -1;
+        if (lane == 0) n_sub[c] = 0;
+        return;
+    }
+    // cluster.py:441-454: groups with < 2 members -> -1, the others numbered by first occurrence
+    int32_t* fo = S.ord + o;      // first occurrence (member index) of the member's group, or -1 if group too small
+    for (int e = lane; e < m; e += 64) {
+        int cnt = 0, f = -1;
+        for (int j = 0; j < m; ++j) {
+            if (A[j] == A[e]) {
+                if (f < 0) f = j;
+                ++cnt;
+            }
+        }
+        fo[e] = cnt >= 2 ? f : -1;
+    }
+    __syncthreads();
+    int total = 0;
+    for (int e = lane; e < m; e += 64) {
+        int id = -1;
+        if (fo[e] >= 0) {
+            id = 0;
+            for (int j = 0; j < fo[e]; ++j) id += fo[j] == j;     // kept groups that start earlier
+        }
+        out[e] = id;
+        total += fo[e] == e;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
+    if (lane == 0) n_sub[c] = total;
+}
+
+__global__ void label_keys_kernel(const int32_t* __restrict__ labels, int64_t n, int32_t n_clusters,
+                                  uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t l = labels[i];
+        keys[i] = l < 0 ? (uint32_t)n_clusters : (uint32_t)l;
+        vals[i] = (int32_t)i;
+    }
+}
+
+// seg[c] = first sorted position with key c (keys 0..n_clusters; every cluster id occurs)
+__global__ void seg_start_kernel(const uint32_t* __restrict__ keys, int64_t n, int32_t n_clusters,
+                                 int64_t* __restrict__ seg) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i == n) {
+            // positions after the last cluster: noise block start (or n)
+            if (n == 0 || keys[n - 1] != (uint32_t)n_clusters) seg[n_clusters] = n;
+            continue;
+        }
+        if (i == 0 || keys[i] != keys[i - 1]) seg[keys[i]] = i;
+    }
+}
+
+__global__ void relabel_kernel(const int32_t* __restrict__ rows, const uint32_t* __restrict__ keys, int64_t n,
+                               int32_t n_clusters, const int32_t* __restrict__ sub, const int64_t* __restrict__ base,
+                               int32_t* __restrict__ labels) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = keys[p];
+        int32_t lab = -1;
+        if (c < (uint32_t)n_clusters && sub[p] >= 0) lab = (int32_t)(base[c] + sub[p]);
+        labels[rows[p]] = lab;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a11 / a12
+// ------------------------------------------------------------------------------------------
+__global__ void cluster_size_kernel(const int32_t* __restrict__ labels, int64_t n, int32_t* __restrict__ size,
+                                    const int64_t* __restrict__ row_order, int32_t* __restrict__ noise_by_dataset_row) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t l = labels[i];
+        if (l >= 0) atomicAdd(&size[l], 1);
+        noise_by_dataset_row[row_order[i]] = l < 0;
+    }
+}
+
+// score_i = sum (float32, stored order) of dist to stored same-cluster neighbours + 1.0 per
+// member the row does not store (cluster.py:536-550 on the sparse graph); argmin per cluster
+// with ties to the lowest row, via a 64-bit atomic min of (score bits, row).
+__global__ void medoid_score_kernel(const int32_t* __restrict__ labels, int64_t n, const int32_t* __restrict__ nb_idx,
+                                    const float* __restrict__ nb_dist, int k, const int32_t* __restrict__ size,
+                                    unsigned long long* __restrict__ best) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t l = labels[i];
+        if (l < 0) continue;
+        float s = 0.f;
+        int same = 0;
+        for (int c = 0; c < k; ++c) {
+            const int32_t j = nb_idx[i * k + c];
+            if (j >= 0 && (int64_t)j != i && labels[j] == l) {
+                s += nb_dist[i * k + c];
+                ++same;
+            }
+        }
+        s += (float)(size[l] - 1 - same);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(uint32_t)i;
+        atomicMin(&best[l], key);
+    }
+}
+
+__global__ void finalize_kernel(const int32_t* __restrict__ labels, int64_t n, int64_t n_clusters,
+                                const int64_t* __restrict__ row_order, const int64_t* __restrict__ noise_rank,
+                                const unsigned long long* __restrict__ best, int32_t* __restrict__ labels_out,
+                                int32_t* __restrict__ medoids_out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ds = row_order[i];
+        const int32_t l = labels[i];
+        if (l >= 0) {
+            labels_out[ds] = l;
+        } else {
+            const int64_t r = n_clusters + noise_rank[ds];
+            labels_out[ds] = (int32_t)r;
+            medoids_out[r] = (int32_t)ds;
+        }
+        if (i < n_clusters) medoids_out[i] = (int32_t)row_order[(uint32_t)(best[i] & 0xFFFFFFFFull)];
+    }
+}
+
+}  // namespace fal
+
+using namespace fal;
+
+extern "C" {
+
+int fal_refine_clusters(fal_ctx* ctx, int32_t* labels, int64_t n, const float* precursor_mz_sorted,
+                        const float* rt_sorted, double tol, int tol_is_da, double rt_tol, int64_t* n_clusters) {
+    FAL_REQUIRE(ctx && n_clusters && n >= 0 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_refine_clusters: bad argument");
+    const int64_t C = *n_clusters;
+    FAL_REQUIRE(C >= 0 && C <= n, FAL_EINVAL, "fal_refine_clusters: *n_clusters must hold the DBSCAN cluster count");
+    if (n == 0 || C == 0) {
+        *n_clusters = 0;
+        return FAL_OK;
+    }
+    FAL_REQUIRE(labels && precursor_mz_sorted, FAL_EINVAL, "fal_refine_clusters: NULL array");
+    hipStream_t st = ctx->stream;
+    // sort rows by (label, row): stable radix sort on the label
+    uint32_t *keys = nullptr, *keys_s = nullptr;
+    int32_t *vals = nullptr, *rows = nullptr, *sub = nullptr, *n_sub = nullptr;
+    int64_t *seg = nullptr, *base = nullptr;
+    unsigned char* slab = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int32_t) * (size_t)n * 5 + 64, (void**)&keys));
+    keys_s = keys + n;
+    vals = reinterpret_cast<int32_t*>(keys + 2 * n);
+    rows = vals + n;
+    sub = rows + n;
+    FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(2 * (C + 2)) + sizeof(int32_t) * (size_t)(C + 2), (void**)&seg));
+    base = seg + (C + 2);
+    n_sub = reinterpret_cast<int32_t*>(base + (C + 2));
+    const size_t per = 4 * 11 + 8;   // 11 4-byte arrays + 1 double array
+    FAL_TRY(ctx->reserve(SLOT_TAIL4, per * (size_t)n + 256, (void**)&slab));
+    RefineScratch S;
+    S.zmd = reinterpret_cast<double*>(slab);
+    float* f = reinterpret_cast<float*>(slab + 8 * (size_t)n);
+    S.val = f;            S.smin = f + n;       S.smax = f + 2 * n;
+    int32_t* q = reinterpret_cast<int32_t*>(f + 3 * n);
+    S.ord = q;            S.sid = q + n;        S.zl = q + 2 * n;     S.zr = q + 3 * n;
+    S.t_a = q + 4 * n;    S.t_b = q + 5 * n;    S.stack = q + 6 * n;  S.visit = q + 7 * n;
+    const int grid = (int)std::min<int64_t>(ceil_div(n + 1, 256), (int64_t)ctx->num_cus * 16);
+    ctx->stage_reset(ST_TAIL);
+    {
+        StageScope ts(ctx, ST_TAIL);
+        hipLaunchKernelGGL(label_keys_kernel, dim3(grid), dim3(256), 0, st, labels, n, (int32_t)C, keys, vals);
+        int bits = 1;
+        while ((1ll << bits) <= C) ++bits;
+        FAL_TRY(sort_pairs_u32_i32(ctx, keys, keys_s, vals, rows, n, bits, SLOT_TAIL3));
+        hipLaunchKernelGGL(seg_start_kernel, dim3(grid), dim3(256), 0, st, keys_s, n, (int32_t)C, seg);
+        hipLaunchKernelGGL(refine_kernel, dim3((unsigned)C), dim3(64), 0, st, rows, seg, precursor_mz_sorted,
+                           rt_tol >= 0.0 ? rt_sorted : nullptr, tol, tol_is_da, rt_tol, S, sub, n_sub);
+        FAL_TRY(device_scan_i32(ctx, n_sub, C, base, SLOT_TAIL3));
+        hipLaunchKernelGGL(relabel_kernel, dim3(grid), dim3(256), 0, st, rows, keys_s, n, (int32_t)C, sub, base, labels);
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    FAL_CHECK_HIP(hipMemcpyAsync(n_clusters, base + C, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    FAL_CHECK_HIP(hipStreamSynchronize(st));
+    return FAL_OK;
+}
+
+int fal_finalize(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, int64_t n_clusters, const int64_t* row_order,
+                 const int32_t* nb_idx, const float* nb_dist, int k, int32_t* labels_out, int32_t* medoids_out,
+                 int64_t* n_labels) {
+    FAL_REQUIRE(ctx && n >= 0 && n_clusters >= 0 && n_clusters <= n && k >= 1, FAL_EINVAL, "fal_finalize: bad argument");
+    if (n_labels) *n_labels = 0;
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(labels_sorted && row_order && nb_idx && nb_dist && labels_out && medoids_out, FAL_EINVAL,
+                "fal_finalize: NULL array");
+    hipStream_t st = ctx->stream;
+    int32_t *size = nullptr, *noise = nullptr;
+    unsigned long long* best = nullptr;
+    int64_t* rank = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int32_t) * (size_t)(n + n_clusters + 2), (void**)&size));
+    noise = size + n_clusters + 1;
+    FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(unsigned long long) * (size_t)(n_clusters + 1), (void**)&best));
+    FAL_TRY(ctx->reserve(SLOT_TAIL4, sizeof(int64_t) * (size_t)(n + 1), (void**)&rank));
+    FAL_CHECK_HIP(hipMemsetAsync(size, 0, sizeof(int32_t) * (size_t)(n_clusters + 1), st));
+    FAL_CHECK_HIP(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * (size_t)(n_clusters + 1), st));
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
+    {
+        StageScope ts(ctx, ST_TAIL);
+        hipLaunchKernelGGL(cluster_size_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, size, row_order, noise);
+        hipLaunchKernelGGL(medoid_score_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, size, best);
+        FAL_TRY(device_scan_i32(ctx, noise, n, rank, SLOT_TAIL3));
+        hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, n_clusters, row_order, rank,
+                           best, labels_out, medoids_out);
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    if (n_labels) {
+        int64_t n_noise = 0;
+        FAL_CHECK_HIP(hipMemcpyAsync(&n_noise, rank + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        FAL_CHECK_HIP(hipStreamSynchronize(st));
+        *n_labels = n_clusters + n_noise;
+    }
+    return FAL_OK;
+}
+
+}  // extern "C"

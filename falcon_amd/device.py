@@ -115,6 +115,81 @@ class Context:
         return IvfIndex(self, h, X, bo, nl)
 
 
+    # ------------------------------------------------------------------ sort / a5
+    def sort_by_precursor(self, precursor_mz):
+        """stable sort (reference cluster.py:73-85) -> order i64[n], mz_sorted f32[n]"""
+        torch = _torch()
+        pmz = self.to_dev(precursor_mz, torch.float32)
+        n = pmz.numel()
+        order = self.empty((n,), torch.int64)
+        mzs = self.empty((n,), torch.float32)
+        check(self.lib.fal_sort_by_precursor(self._h, self._p(pmz), n, self._p(order), self._p(mzs)),
+              "fal_sort_by_precursor")
+        return order, mzs
+
+    def gather_f32(self, src, order):
+        torch = _torch()
+        src = self.to_dev(src, torch.float32)
+        out = self.empty((order.numel(),), torch.float32)
+        check(self.lib.fal_gather_f32(self._h, self._p(src), self._p(order), order.numel(), self._p(out)),
+              "fal_gather_f32")
+        return out
+
+    def precursor_splits(self, mz_sorted, tol: float, mode: str, batch_size: int, mz_interval: float = 1.0,
+                         chunk_last: bool = True) -> np.ndarray:
+        """reference cluster.py:159-209 (+ the build's two extra rules) -> int64 boundaries (host)"""
+        torch = _torch()
+        mzs = self.to_dev(mz_sorted, torch.float32)
+        n = mzs.numel()
+        cap = n + 2
+        out = np.empty(cap, np.int64)
+        k = C.c_int64()
+        check(self.lib.fal_precursor_splits(self._h, self._p(mzs), n, float(tol), int(mode == "Da"), int(batch_size),
+                                            float(mz_interval or 0.0), int(chunk_last),
+                                            out.ctypes.data_as(C.c_void_p), cap, C.byref(k)), "fal_precursor_splits")
+        return out[:k.value].copy()
+
+    # ------------------------------------------------------------------ a8 .. a12
+    def filter_neighbors(self, sim, idx, mz_sorted, rt_sorted, tol: float, mode: str, rt_tol, n_neighbors: int):
+        torch = _torch()
+        n, k_ann = idx.shape
+        nb_idx = self.empty((n, n_neighbors), torch.int32)
+        nb_dist = self.empty((n, n_neighbors), torch.float32)
+        check(self.lib.fal_filter_neighbors(self._h, self._p(sim), self._p(idx), n, k_ann, self._p(mz_sorted),
+                                            self._p(rt_sorted), float(tol), int(mode == "Da"),
+                                            -1.0 if rt_tol is None else float(rt_tol), int(n_neighbors),
+                                            self._p(nb_idx), self._p(nb_dist)), "fal_filter_neighbors")
+        return nb_idx, nb_dist
+
+    def dbscan(self, nb_idx, nb_dist, eps: float):
+        torch = _torch()
+        n, k = nb_idx.shape
+        labels = self.empty((n,), torch.int32)
+        nc = C.c_int64()
+        check(self.lib.fal_dbscan(self._h, self._p(nb_idx), self._p(nb_dist), n, k, float(eps), self._p(labels),
+                                  C.byref(nc)), "fal_dbscan")
+        return labels, int(nc.value)
+
+    def refine_clusters(self, labels, n_clusters: int, mz_sorted, rt_sorted, tol: float, mode: str, rt_tol):
+        nc = C.c_int64(int(n_clusters))
+        check(self.lib.fal_refine_clusters(self._h, self._p(labels), labels.numel(), self._p(mz_sorted),
+                                           self._p(rt_sorted), float(tol), int(mode == "Da"),
+                                           -1.0 if rt_tol is None else float(rt_tol), C.byref(nc)),
+              "fal_refine_clusters")
+        return labels, int(nc.value)
+
+    def finalize(self, labels_sorted, n_clusters: int, order, nb_idx, nb_dist):
+        torch = _torch()
+        n, k = nb_idx.shape
+        labels = self.empty((n,), torch.int32)
+        medoids = self.empty((n,), torch.int32)
+        nl = C.c_int64()
+        check(self.lib.fal_finalize(self._h, self._p(labels_sorted), n, int(n_clusters), self._p(order),
+                                    self._p(nb_idx), self._p(nb_dist), k, self._p(labels), self._p(medoids),
+                                    C.byref(nl)), "fal_finalize")
+        return labels, medoids[:int(nl.value)]
+
+
 class IvfIndex:
     """Opaque `fal_ivf` handle (keeps the vectors alive: the index borrows them)."""
 

@@ -567,14 +567,18 @@ def medoid_scores_sparse(labels: np.ndarray, nb_idx: np.ndarray, nb_dist: np.nda
     member that row i does not store (a missing pair has cosine 0 -> distance 1,
     cluster.py:621-626)."""
     n, k = nb_idx.shape
+    labels = np.asarray(labels)
+    valid = labels >= 0                                  # noise rows (-1) score +inf
     j = np.where(nb_idx < 0, 0, nb_idx)
-    same = (nb_idx >= 0) & (labels[j] == labels[:, None]) & (nb_idx != np.arange(n)[:, None])
+    same = ((nb_idx >= 0) & valid[:, None] & (labels[j] == labels[:, None])
+            & (nb_idx != np.arange(n)[:, None]))
     s = np.zeros(n, f32)
     for c in range(k):
         s = np.where(same[:, c], (s + nb_dist[:, c]).astype(f32), s)
-    size = np.bincount(labels, minlength=labels.max() + 1)[labels]
+    n_lab = int(labels.max()) + 1 if valid.any() else 0
+    size = np.bincount(labels[valid], minlength=max(n_lab, 1))[np.where(valid, labels, 0)]
     missing = (size - 1 - same.sum(1)).astype(f32)
-    return (s + missing).astype(f32)
+    return np.where(valid, (s + missing).astype(f32), np.inf).astype(f32)
 
 
 # -------------------------------------------------------------------------- a12
@@ -656,8 +660,7 @@ def generate_clusters(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
     if n_clusters:
         member = lab_sorted >= 0
         safe = np.where(member, lab_sorted, 0)
-        score = medoid_scores_sparse(safe, nb_idx, nb_dist)
-        score = np.where(member, score, np.inf)
+        score = medoid_scores_sparse(lab_sorted, nb_idx, nb_dist)
         o = np.lexsort((np.arange(N), score, safe))
         o = o[member[o]]
         first = np.concatenate([[True], safe[o][1:] != safe[o][:-1]])

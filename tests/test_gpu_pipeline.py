@@ -1,0 +1,210 @@
+"""GPU parity of the whole hot path, stage by stage and end to end.
+
+Each stage is compared with the oracle run on the SAME inputs (the GPU's own upstream
+output), so a discrepancy is pinned to one kernel: integer / index work must be
+bit-exact, float entries within north_star's 1e-5.  The end-to-end check is the
+north_star gate: ARI >= 0.99 against the oracle's labels."""
+import numpy as np
+import pytest
+
+from oracle import falcon_oracle as fo
+from tests.util import assert_topk_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from falcon_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _dataset(n, seed=42, charge=2, **kw):
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import SpectrumDataset
+    d = synth.select_charge(synth.generate(n, seed=seed, **kw), charge)
+    return d, SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+
+
+def _check_stages(ctx, d, ds, tol, mode, rt_tol, batch_size, p):
+    from falcon_amd.cluster.cluster import ClusterPipeline
+    pipe = ClusterPipeline(ctx)
+    labels, medoids = pipe.run(ds, tol, mode, rt_tol, 0.05, batch_size, p, keep_intermediates=True)
+    L = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in pipe.last.items() if k != "index"}
+    labels, medoids = labels.cpu().numpy(), medoids.cpu().numpy()
+    N = len(ds)
+    # sort (cluster.py:73-85) -- stable
+    order = np.argsort(d["precursor_mz"], kind="stable")
+    assert np.array_equal(L["order"], order)
+    mzs = d["precursor_mz"][order]
+    assert np.array_equal(L["mz_sorted"], mzs)
+    rts = d["retention_time"][order] if rt_tol is not None else None
+    # a5 buckets
+    assert np.array_equal(L["splits"], fo.bucket_splits(mzs, tol, mode, batch_size, p.mz_interval))
+    # a1-a3 vectors, bit-exact
+    nb, start, _ = fo.get_dim(p.min_mz, p.max_mz, 0.05)
+    X = fo.vectorize(d["mz"], d["intensity"], d["indptr"], start, 0.05, nb, p.low_dim, p.hash_seed, True, order)
+    assert np.array_equal(L["X"], X)
+    # a6/a7 on the GPU's own index
+    cent, asg, perm, loff = [t.cpu().numpy() for t in pipe.last["index"].export()]
+    lb = np.concatenate([[0], np.cumsum(L["n_list"])])
+    bad = 0
+    for b, (a, e) in enumerate(zip(L["splits"][:-1], L["splits"][1:])):
+        if e - a == 0:
+            continue
+        rs, ri = fo.ivf_search(X[a:e], cent[lb[b]:lb[b + 1]], asg[a:e], perm[a:e] - a,
+                               loff[lb[b]:lb[b + 1] + 1] - a, p.n_probe, p.n_neighbors_ann, base=a)
+        try:
+            assert_topk_close(L["sim"][a:e], L["idx"][a:e], rs, ri, X[a:e], base=a, what=f"bucket {b}")
+        except AssertionError:
+            if L["n_list"][b] == 1:
+                raise
+            bad += int((L["idx"][a:e] != ri).any(1).sum())      # coarse near-ties (IVF only)
+    assert bad <= 0.002 * N, bad
+    # a8 filter: same inputs -> bit-exact
+    ni, nd = fo.filter_neighbors(L["sim"], L["idx"], mzs, rts, tol, mode, rt_tol, p.n_neighbors)
+    assert np.array_equal(L["nb_idx"], ni)
+    assert np.array_equal(L["nb_dist"], nd)
+    # a9 DBSCAN: bit-exact vs the order-independent restatement, ARI vs sklearn's order
+    db = fo.dbscan_components(ni, nd, p.eps)
+    assert np.array_equal(L["db"], db)
+    assert L["n_db"] == db.max() + 1
+    from sklearn.metrics import adjusted_rand_score
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert adjusted_rand_score(fo.dbscan_sklearn_order(ni, nd, p.eps), db) >= 0.99
+    # a10 refinement + numbering
+    lab = fo.refine_and_number(db, None, mzs, rts, tol, mode, rt_tol)
+    assert np.array_equal(L["lab_sorted"], lab)
+    n_cl = int(lab.max()) + 1
+    assert L["n_clusters"] == n_cl
+    # a11 medoids + a12 labels
+    member = lab >= 0
+    safe = np.where(member, lab, 0)
+    score = fo.medoid_scores_sparse(lab, ni, nd)
+    o = np.lexsort((np.arange(N), score, safe))
+    o = o[member[o]]
+    first = np.concatenate([[True], safe[o][1:] != safe[o][:-1]]) if len(o) else np.zeros(0, bool)
+    ref_labels = np.empty(N, np.int32)
+    ref_labels[order] = lab
+    noise = ref_labels == -1
+    ref_labels[noise] = np.arange(n_cl, n_cl + noise.sum())
+    ref_med = np.concatenate([order[o[first]], np.flatnonzero(noise)]).astype(np.int32)
+    assert np.array_equal(labels, ref_labels)
+    assert np.array_equal(medoids, ref_med)
+    # contract of the seam (cluster.py:152-156): no -1 left, labels dense, medoid belongs to its cluster
+    assert labels.min() == 0 and labels.max() == len(medoids) - 1
+    assert np.array_equal(labels[medoids], np.arange(len(medoids)))
+    return labels, medoids
+
+
+def test_stages_flat_buckets(ctx):
+    """default options: 1 m/z windows -> small flat buckets (the C2 regime of SURVEY 8d)."""
+    from falcon_amd.cluster.cluster import AnnParams
+    d, ds = _dataset(12000)
+    labels, _ = _check_stages(ctx, d, ds, 20.0, "ppm", None, 2 ** 15, AnnParams())
+    # end to end vs the oracle's own run
+    ref, _ = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"])
+    from sklearn.metrics import adjusted_rand_score
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert adjusted_rand_score(ref, labels) >= 0.99
+    assert np.array_equal(ref, labels)
+
+
+def test_stages_ivf_buckets_and_rt(ctx):
+    """no windows + small batch_size -> real IVF buckets (n_list > n_probe); RT tolerance on;
+    clean synthetic spectra so that clusters form and get split by m/z and RT."""
+    from falcon_amd.cluster.cluster import AnnParams
+    d, ds = _dataset(16000, seed=5, mz_lo=500.0, mz_hi=520.0)
+    p = AnnParams(n_probe=4, n_neighbors=16, n_neighbors_ann=48, mz_interval=0.0, kmeans_iters=3, eps=0.3)
+    labels, _ = _check_stages(ctx, d, ds, 20.0, "ppm", 900.0, 4096, p)
+    ref, _ = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"],
+                                  eps=0.3, rt_tol=900.0, batch_size=4096, n_probe=4, n_neighbors=16,
+                                  n_neighbors_ann=48, mz_interval=0.0, kmeans_iters=3)
+    from sklearn.metrics import adjusted_rand_score
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert adjusted_rand_score(ref, labels) >= 0.99
+
+
+def test_stages_da_tolerance_low_dim(ctx):
+    from falcon_amd.cluster.cluster import AnnParams
+    d, ds = _dataset(5000, seed=9, charge=3)
+    _check_stages(ctx, d, ds, 0.05, "Da", None, 512, AnnParams(low_dim=64, n_neighbors=8, n_neighbors_ann=20, eps=0.4))
+
+
+def test_generate_clusters_seam(ctx):
+    """the drop-in call itself (reference signature) incl. empty and single-spectrum datasets."""
+    from falcon_amd.cluster.cluster import generate_clusters, SpectrumDataset, ClusterPipeline
+    pipe = ClusterPipeline(ctx)
+    d, ds = _dataset(3000, seed=3)
+    labels, medoids = generate_clusters(ds, "complete", 0.1, 0, 20.0, "ppm", None, 0.05, 2 ** 15, pipeline=pipe)
+    assert labels.dtype == np.int32 and labels.shape == (len(ds),) and medoids.dtype == np.int32
+    ref, rmed, im = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"],
+                                         d["retention_time"], return_intermediates=True)
+    assert np.array_equal(labels, ref)
+    # medoids: identical unless two members tie within the float tolerance (the oracle's BLAS
+    # inner products are not symmetric to the last ulp, the GPU's fmaf chain is)
+    score = fo.medoid_scores_sparse(im["lab_sorted"], im["nb_idx"], im["nb_dist"])
+    inv = np.empty(len(ref), np.int64)
+    inv[im["order"]] = np.arange(len(ref))
+    diff = np.flatnonzero(medoids != rmed)
+    assert np.array_equal(labels[medoids], np.arange(len(medoids)))
+    assert np.all(np.abs(score[inv[medoids[diff]]] - score[inv[rmed[diff]]]) <= 1e-5 * 64)
+    assert len(diff) <= 0.05 * len(medoids)
+    one = SpectrumDataset(d["precursor_mz"][:1], d["retention_time"][:1], d["mz"][:d["indptr"][1]],
+                          d["intensity"][:d["indptr"][1]], d["indptr"][:2])
+    l1, m1 = generate_clusters(one, "complete", 0.1, 0, 20.0, "ppm", None, 0.05, 2 ** 15, pipeline=pipe)
+    assert list(l1) == [0] and list(m1) == [0]
+    empty = SpectrumDataset(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32),
+                            np.zeros(0, np.float32), np.zeros(1, np.int64))
+    l0, m0 = generate_clusters(empty, "complete", 0.1, 0, 20.0, "ppm", None, 0.05, 2 ** 15, pipeline=pipe)
+    assert len(l0) == 0 and len(m0) == 0
+
+
+def test_precursor_splits_golden(ctx, ref_golden):
+    """a5 against the reference's own `_get_precursor_mz_splits` (both extra rules off)."""
+    g = ref_golden
+    for i in range(int(g["splits_n"])):
+        tol, is_da, batch = g[f"splits{i}_par"]
+        s = ctx.precursor_splits(g[f"splits{i}_mz"], tol, "Da" if is_da else "ppm", int(batch), 0.0, False)
+        assert np.array_equal(s, g[f"splits{i}_out"]), i
+
+
+def test_refine_golden(ctx, ref_golden):
+    """a10 against the reference's own `_postprocess_cluster` (one DBSCAN cluster each)."""
+    import torch
+    g = ref_golden
+    for i in range(int(g["pp_n"])):
+        tol, is_da, rt_tol, ms, sl = g[f"pp{i}_par"]
+        mz, rt = g[f"pp{i}_mz"], g[f"pp{i}_rt"]
+        m = len(mz)
+        lab = torch.zeros(m, dtype=torch.int32, device=ctx.tdev)
+        out, n = ctx.refine_clusters(lab, 1, ctx.to_dev(mz, torch.float32), ctx.to_dev(rt, torch.float32), tol,
+                                     "Da" if is_da else "ppm", None if rt_tol < 0 else rt_tol)
+        exp = g[f"pp{i}_labels"].astype(np.int64)
+        exp = np.where(exp >= 0, exp - int(sl), -1)
+        assert n == int(g[f"pp{i}_n"]), i
+        assert np.array_equal(out.cpu().numpy(), exp), i
+
+
+def test_dbscan_golden(ctx, dbscan_golden):
+    """a9 against scikit-learn's DBSCAN on sparse precomputed graphs: identical noise set,
+    every sklearn cluster inside one GPU cluster, exact agreement for k >= 8."""
+    g = dbscan_golden
+    import torch
+    for i in range(int(g["db_n"])):
+        idx, dist, eps, ref = g[f"db{i}_idx"], g[f"db{i}_dist"], float(g[f"db{i}_eps"]), g[f"db{i}_labels"]
+        lab, nc = ctx.dbscan(ctx.to_dev(idx, torch.int32), ctx.to_dev(dist, torch.float32), eps)
+        lab = lab.cpu().numpy()
+        assert np.array_equal(lab, fo.dbscan_components(idx, dist, eps))
+        assert np.array_equal(lab == -1, ref == -1)
+        if idx.shape[1] >= 8:
+            m = {}
+            assert all(m.setdefault(int(a), int(b)) == int(b) for a, b in zip(ref, lab))
