@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectra clustered / second through the whole hot path
+(vectorise -> buckets -> IVF/flat cosine scan -> top-k -> filter -> DBSCAN -> refine ->
+medoids/labels) on synthetic peak lists, plus the cosine kernel's roofline fraction.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over this rank's shard (default 1,000,000 synthetic
+spectra = BASELINE.json configs[1]; both charge partitions, like falcon.py:151-193).
+Inputs are resident in HBM before the timed region; the step ends with the labels on the
+host.  Weak scaling: every rank owns an independent shard (its own 1M-spectrum block of
+the generator = its own (charge, bucket) units); the only collective is the result
+all-gatherv (neighbour lists by default, `--exchange labels` for labels only).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0            # ... "HBM3E peak BW 8.0 TB/s spec"
+
+
+def cpu_baseline(data, params, seconds_target=20.0):
+    """The oracle (numpy restatement, kind "port") timed on this box's host cores on a bounded
+    sample of the SAME workload: the charge-2 spectra of a precursor-m/z slice, which keeps
+    the bucket density (and so the work per spectrum) of the full run."""
+    from oracle import falcon_oracle as fo
+    from falcon_amd import synth
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                    # pragma: no cover
+        threadpool_limits = None
+    c2 = synth.select_charge(data, 2)
+    pm = c2["precursor_mz"]
+    lo = 600.0
+    width = 16.0
+    sel = np.flatnonzero((pm >= lo) & (pm < lo + width))
+    if len(sel) < 256:
+        sel = np.arange(min(len(pm), 20000))
+    counts = np.diff(c2["indptr"])[sel]
+    indptr = np.zeros(len(sel) + 1, np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    src = np.repeat(c2["indptr"][:-1][sel] - indptr[:-1], counts) + np.arange(int(counts.sum()))
+    args = (c2["mz"][src], c2["intensity"][src], indptr, pm[sel], c2["retention_time"][sel])
+    kw = dict(eps=params.eps, low_dim=params.low_dim, n_probe=params.n_probe, n_neighbors=params.n_neighbors,
+              n_neighbors_ann=params.n_neighbors_ann, mz_interval=params.mz_interval,
+              kmeans_iters=params.kmeans_iters)
+    ctxm = threadpool_limits(limits=1) if threadpool_limits else None
+    t0 = time.perf_counter()
+    if ctxm:
+        with ctxm:
+            fo.generate_clusters(*args, **kw)
+    else:
+        fo.generate_clusters(*args, **kw)
+    dt = time.perf_counter() - t0
+    return {"value": len(sel) / dt, "unit": "spectra/s", "cores": 1, "kind": "port",
+            "sample": f"{len(sel)} charge-2 spectra with precursor m/z in [{lo:.0f},{lo + width:.0f}) of the "
+                      f"rank-0 shard (same bucket density), oracle/falcon_oracle.py, numpy 1 thread, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spectra", type=int, default=1_000_000, help="spectra per GPU")
+    ap.add_argument("--low_dim", type=int, default=400)
+    ap.add_argument("--n_probe", type=int, default=16)
+    ap.add_argument("--n_neighbors", type=int, default=64)
+    ap.add_argument("--n_neighbors_ann", type=int, default=128)
+    ap.add_argument("--eps", type=float, default=0.10)
+    ap.add_argument("--batch_size", type=int, default=2 ** 15)
+    ap.add_argument("--mz_interval", type=float, default=1.0)
+    ap.add_argument("--exchange", choices=["neighbors", "labels", "none"], default="neighbors")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from falcon_amd import synth
+    from falcon_amd import distributed as fdist
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    from falcon_amd.device import Context
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (falcon_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = Context(local_rank)
+    pipe = ClusterPipeline(ctx)
+    p = AnnParams(eps=args.eps, low_dim=args.low_dim, n_probe=args.n_probe, n_neighbors=args.n_neighbors,
+                  n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval)
+
+    # ---- this rank's shard: its own generator blocks, resident in HBM ------------------------
+    blocks_per_rank = (args.spectra + synth.BLOCK - 1) // synth.BLOCK
+    data = synth.generate(args.spectra, seed=42, first_block=rank * blocks_per_rank)
+    parts = []
+    for charge in (2, 3):                                       # falcon.py:151-160
+        c = synth.select_charge(data, charge)
+        parts.append(SpectrumDataset(ctx.to_dev(c["precursor_mz"], torch.float32),
+                                     ctx.to_dev(c["retention_time"], torch.float32),
+                                     ctx.to_dev(c["mz"], torch.float32), ctx.to_dev(c["intensity"], torch.float32),
+                                     ctx.to_dev(c["indptr"], torch.int64)))
+    n_local = sum(len(x) for x in parts)
+    row_offset = rank * args.spectra
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(collect=None):
+        labels_all, current = [], 0
+        nb_all = []
+        for ds in parts:
+            labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, args.batch_size, p,
+                                       keep_intermediates=(args.exchange == "neighbors" and world > 1))
+            labels_all.append(labels + current)                  # falcon.py:189-193
+            current += int(medoids.numel())
+            if args.exchange == "neighbors" and world > 1:
+                nb_all.append((pipe.last["nb_idx"], pipe.last["nb_dist"], pipe.last["order"]))
+                pipe.last["index"].close()
+            if collect is not None:
+                collect.append({k: ctx.stage_ms(k) for k in ("vectorize", "build", "coarse", "scan", "select",
+                                                              "filter", "dbscan", "tail")}
+                               | {"pairs": ctx.counter(0), "coarse_pairs": ctx.counter(1),
+                                  "scan_launches": ctx.counter(2), "sims_bytes": ctx.counter(3), "n": len(ds)})
+        labels = torch.cat(labels_all)
+        if world > 1 and args.exchange != "none":
+            if args.exchange == "neighbors":
+                # one all-gatherv of the sparse neighbour lists (ids -> global sorted rows of the job)
+                off = row_offset
+                gi, gd = [], []
+                for nb_idx, nb_dist, _ in nb_all:
+                    gi.append(torch.where(nb_idx >= 0, nb_idx + off, nb_idx))
+                    gd.append(nb_dist)
+                    off += nb_idx.shape[0]
+                g_idx, counts = fdist.allgatherv_rows(torch.cat(gi))
+                g_dist, _ = fdist.allgatherv_rows(torch.cat(gd), counts)
+                del g_idx, g_dist
+            labels, _ = fdist.allgatherv_labels(labels, current)
+        return labels.cpu()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel timing (HIP events on the kernels' own stream), outside the timed region --
+    ctx.enable_timing(True)
+    stages = []
+    step(stages)
+    ctx.enable_timing(False)
+
+    if rank == 0:
+        d = args.low_dim
+        pairs = sum(s["pairs"] for s in stages)
+        scan_ms = sum(s["scan"][0] for s in stages)
+        scan_launches = sum(s["scan"][1] for s in stages)
+        flops = 2.0 * d * pairs
+        achieved_tf = flops / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+        n_rows = sum(s["n"] for s in stages)
+        algo_bytes = n_rows * (2 * d * 4 + 8 * args.n_neighbors_ann)          # SURVEY 8(d) compulsory bytes
+        stage_ms = {k: round(sum(s[k][0] for s in stages), 3) for k in
+                    ("vectorize", "build", "coarse", "scan", "select", "filter", "dbscan", "tail")}
+        out = {
+            "metric": "spectra clustered/sec @1/2/4/8 GPU; cosine-kernel HBM GB/s vs roofline",
+            "value": n_local * world * args.steps / dt,
+            "unit": "spectra/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.spectra} synthetic spectra per GPU (charges 2+3), low_dim={d}, "
+                                   f"n_neighbors={args.n_neighbors}, n_neighbors_ann={args.n_neighbors_ann}, "
+                                   f"n_probe={args.n_probe}, eps={args.eps}, precursor_tol=20ppm, "
+                                   f"mz_interval={args.mz_interval}, batch_size={args.batch_size}",
+                       "exchange": args.exchange if world > 1 else "none",
+                       "parallelism": f"bucket-sharded x{world}"},
+            "roofline": {"kernel": "dense_kernel<.,STORE> / ivf_fine_kernel (cosine scan, fp32 MFMA 32x32x2)",
+                         "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                         "launches": scan_launches, "avg_launch_ms": scan_ms / max(scan_launches, 1),
+                         "pairs_per_step": pairs},
+            "roofline_hbm": {"kernel": "cosine scan", "bound": "hbm",
+                             "achieved": algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": (algo_bytes / (scan_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if scan_ms > 0 else 0.0,
+                             "algorithmic_bytes": algo_bytes},
+            "stage_ms": stage_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, p)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "fal_ctx_sync": ([c_void_p], c_int),
     "fal_ctx_stage_ms": ([c_void_p, c_int, P(c_float), P(c_int64)], c_int),
     "fal_ctx_enable_timing": ([c_void_p, c_int], c_int),
+    "fal_ctx_counter": ([c_void_p, c_int, P(c_int64)], c_int),
     "fal_get_dim": ([c_float, c_float, c_float, P(c_uint32), P(c_float), P(c_float)], c_int),
     "fal_hash_lookup": ([c_uint32, c_uint32, c_uint32, c_void_p], c_int),
     "fal_to_vector_indices": ([c_void_p, c_void_p, c_int64, c_double, c_double, c_void_p], c_int),

@@ -60,6 +60,7 @@ struct fal_ctx {
         size_t used = 0;
     } timers[fal::kNumStages];
     fal::Scratch scratch[16];
+    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     int reserve(int slot, size_t bytes, void** out);
     void stage_reset(int stage);

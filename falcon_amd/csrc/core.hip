@@ -130,6 +130,12 @@ int fal_ctx_enable_timing(fal_ctx* c, int on) {
     return FAL_OK;
 }
 
+int fal_ctx_counter(fal_ctx* c, int which, int64_t* value) {
+    FAL_REQUIRE(c && value && which >= 0 && which < 8, FAL_EINVAL, "fal_ctx_counter: bad argument");
+    *value = c->counters[which];
+    return FAL_OK;
+}
+
 int fal_ctx_stage_ms(fal_ctx* c, int stage, float* ms, int64_t* launches) {
     FAL_REQUIRE(c && ms && stage >= 0 && stage < fal::kNumStages, FAL_EINVAL, "fal_ctx_stage_ms: bad argument");
     FAL_CHECK_HIP(hipStreamSynchronize(c->stream));

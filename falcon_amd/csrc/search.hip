@@ -141,10 +141,16 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         sa.jobs = flat_dev; sa.n_jobs = (int)flat.size(); sa.tile_begin = t0; sa.ids_are_rows = 1;
         FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, (t1 - t0) * 32));
     }
+    ctx->counters[0] = 0;
+    for (const DenseJob& j : flat) ctx->counters[0] += (int64_t)j.nq * j.nc;
+    ctx->counters[1] = 0;
+    ctx->counters[2] = (int64_t)(flat_cuts.empty() ? 0 : flat_cuts.size() - 1);
+    ctx->counters[3] = (int64_t)(sizeof(float) * std::max(need_flat, need_coarse));
     if (coarse.empty()) {
         FAL_CHECK_HIP(hipStreamSynchronize(st));   // job vectors die with this frame
         return FAL_OK;
     }
+    for (const DenseJob& j : coarse) ctx->counters[1] += (int64_t)j.nq * j.nc;
 
     // ---- B. IVF buckets: coarse quantiser ------------------------------------------------------
     const int np = std::min(n_probe, max_n_list);
@@ -199,6 +205,9 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         }
         if (fine_cuts.back() != ivf_tiles) fine_cuts.push_back(ivf_tiles);
     }
+    ctx->counters[0] += qoff[(size_t)ivf->n];
+    ctx->counters[2] += (int64_t)fine_cuts.size() - 1;
+    ctx->counters[3] = std::max<int64_t>(ctx->counters[3], (int64_t)(sizeof(float) * need_fine));
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * std::max<size_t>(need_fine, 16), (void**)&sims));
     auto first_p_of_tile = [&](int64_t t) -> int64_t {
         size_t lo = 0, hi = coarse.size() - 1;

@@ -76,6 +76,11 @@ class Context:
         check(self.lib.fal_ctx_stage_ms(self._h, _lib.STAGES[stage], C.byref(ms), C.byref(k)))
         return ms.value, k.value
 
+    def counter(self, which: int) -> int:
+        v = C.c_int64()
+        check(self.lib.fal_ctx_counter(self._h, int(which), C.byref(v)))
+        return int(v.value)
+
     # ------------------------------------------------------------------ a2 / a3
     def to_vector_indices(self, mz, min_mz: float, bin_size: float):
         torch = _torch()

@@ -63,6 +63,12 @@ int fal_ctx_sync(fal_ctx* ctx);
  * 4 top-k select, 5 filter, 6 dbscan, 7 tail. */
 int fal_ctx_stage_ms(fal_ctx* ctx, int stage, float* ms, int64_t* launches);
 int fal_ctx_enable_timing(fal_ctx* ctx, int on);
+/* Work counters of the LAST fal_ivf_search_topk on this context (for roofline accounting):
+ * which = 0: (query, candidate) inner products the fine scan produced results for
+ *            (= sum over queries of candidates in their probed lists; n_b^2 per flat bucket);
+ * which = 1: (query, centroid) inner products of the coarse quantiser;
+ * which = 2: number of scan kernel launches (batches);  3: bytes of the sims scratch buffer. */
+int fal_ctx_counter(fal_ctx* ctx, int which, int64_t* value);
 
 /* ---- a1  bin geometry: reference spectrum.py:172-199 `get_dim` (float32) --- [host] */
 int fal_get_dim(float min_mz, float max_mz, float bin_size,
