@@ -115,14 +115,22 @@ __global__ __launch_bounds__(64, 1) void ivf_fine_kernel(FineArgs a) {
 
     // ---- stream the union's rows, 32 per step ----------------------------------------------
     int ucur = 0;   // wave-uniform: list containing stream row c0
-    for (int c0 = 0; c0 < R; c0 += 32) {
-        while (ucur + 1 < U && uoff[ucur + 1] <= c0) ++ucur;
-        // this lane's candidate row (as the MFMA A operand)
+    // this lane's candidate row (as the MFMA A operand) of the chunk starting at stream row c0
+    auto row_ptr = [&](int c0, int uhint) -> const float* {
         const int s = min(c0 + r, R - 1);
-        int u = ucur;
+        int u = uhint;
         while (u + 1 < U && uoff[u + 1] <= s) ++u;
         const int64_t crow = loff[ulist[u]] + (s - uoff[u]);
-        const f32x16 acc = tile_dot<DH4, false>(q, a.Xl + crow * d + (int64_t)h * dh, dh4);
+        return a.Xl + crow * d + (int64_t)h * dh;
+    };
+    CandStream<DH4> cs;
+    const float* cur = R > 0 ? row_ptr(0, 0) : a.Xl;
+    if (R > 0) cs.prime(cur, dh4);
+    for (int c0 = 0; c0 < R; c0 += 32) {
+        while (ucur + 1 < U && uoff[ucur + 1] <= c0) ++ucur;
+        const float* nxt = (c0 + 32 < R) ? row_ptr(c0 + 32, ucur) : cur;
+        const f32x16 acc = cs.template dot<false>(q, cur, nxt, dh4);
+        cur = nxt;
         // epilogue: lane = query r; registers = candidates c0 + mfma32_row(i, h)
         const int cend = min(c0 + 32, R);
         for (int us = ucur; us < U && uoff[us] < cend; ++us) {      // wave-uniform segment loop

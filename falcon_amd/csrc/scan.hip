@@ -41,11 +41,13 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
     float* out = nullptr;
     if (EPI == EPI_STORE) out = sims + (job.obase - sims_base) + (int64_t)(32 * lt) * nc;
 
+    CandStream<DH4> cs;
+    const float* cur = Cm + (job.c_row0 + min(r, nc - 1)) * d + (int64_t)h * dh;
+    cs.prime(cur, dh4);
     for (int c0 = 0; c0 < nc; c0 += 32) {
-        const int64_t crow = job.c_row0 + min(c0 + r, nc - 1);
-        const float* cp = Cm + crow * d + (int64_t)h * dh;
+        const float* nxt = Cm + (job.c_row0 + min(c0 + 32 + r, nc - 1)) * d + (int64_t)h * dh;
         if (EPI == EPI_STORE) {
-            const f32x16 acc = tile_dot<DH4, true>(q, cp, dh4);
+            const f32x16 acc = cs.template dot<true>(q, cur, nxt, dh4);
             const int c = c0 + r;
             if (c < nc) {
 #pragma unroll
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
                 }
             }
         } else {
-            const f32x16 acc = tile_dot<DH4, false>(q, cp, dh4);
+            const f32x16 acc = cs.template dot<false>(q, cur, nxt, dh4);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int c = c0 + mfma32_row(i, h);
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
                 }
             }
         }
+        cur = nxt;
     }
     if (EPI == EPI_ARGMAX) {
         const float ob = __shfl_xor(best, 32, 64);

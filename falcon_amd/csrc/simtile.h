@@ -35,33 +35,62 @@ __device__ __forceinline__ void load_half_row(float (&q)[DH4 * 4], const float* 
     }
 }
 
-// acc[32x32] += rows(a-side) x rows(b-side)^T over the wave's k-slots.
-// QUERY_IS_A = true : D[query][cand]  (lane: candidate = lane&31, 16 query rows in registers)
-// QUERY_IS_A = false: D[cand][query]  (lane: query = lane&31, 16 candidate rows in registers)
-template <int DH4, bool QUERY_IS_A>
-__device__ __forceinline__ f32x16 tile_dot(const float (&q)[DH4 * 4], const float* __restrict__ cand_half, int dh4) {
-    const float4* p = reinterpret_cast<const float4*>(cand_half);
-    f32x16 acc;
+// Candidate stream of one lane: an NB-deep ring of 16-byte loads that stays in flight ACROSS
+// 32-candidate chunks (the loads of chunk i+1 are issued while chunk i's MFMAs run), so the
+// matrix pipe never waits for an L2 round trip.  hipcc would otherwise serialise load -> wait ->
+// 4 MFMAs because the query registers leave it little room.
+// The ring depth divides DH4 so that slot (j % kRing) means the same step in every chunk.
+template <int DH4>
+struct CandStream {
+    static constexpr int kRing = (DH4 % 8 == 0) ? 8 : 10;
+    static_assert(DH4 % kRing == 0, "ring depth must divide the number of 16-byte steps per row half");
+    float4 ring[kRing];
+
+    __device__ __forceinline__ void prime(const float* __restrict__ row_half, int dh4) {
+        const float4* p = reinterpret_cast<const float4*>(row_half);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < DH4; ++j) {
-        // padded slots re-read the last real float4: q is zero there, so they add nothing
-        const float4 a = p[j < dh4 ? j : dh4 - 1];
-        if (QUERY_IS_A) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 0], a.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 1], a.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 2], a.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 3], a.w, acc, 0, 0, 0);
-        } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * j + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * j + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * j + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * j + 3], acc, 0, 0, 0);
-        }
+        for (int j = 0; j < kRing; ++j) ring[j] = p[j < dh4 ? j : dh4 - 1];
     }
-    return acc;
-}
+
+    // acc[32x32] = rows(a-side) x rows(b-side)^T over the wave's k-slots for the chunk whose
+    // row is already streaming; `next_half` = this lane's row of the NEXT chunk (any valid row
+    // when there is none).
+    // QUERY_IS_A = true : D[query][cand]  (lane: candidate = lane&31, 16 query rows in registers)
+    // QUERY_IS_A = false: D[cand][query]  (lane: query = lane&31, 16 candidate rows in registers)
+    template <bool QUERY_IS_A>
+    __device__ __forceinline__ f32x16 dot(const float (&q)[DH4 * 4], const float* __restrict__ cur_half,
+                                          const float* __restrict__ next_half, int dh4) {
+        const float4* pc = reinterpret_cast<const float4*>(cur_half);
+        const float4* pn = reinterpret_cast<const float4*>(next_half);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DH4; ++j) {
+            // padded slots re-read the last real float4: q is zero there, so they add nothing
+            const float4 a = ring[j % kRing];
+            const int jj = j + kRing;
+            if (jj < DH4) ring[j % kRing] = pc[jj < dh4 ? jj : dh4 - 1];
+            else ring[j % kRing] = pn[(jj - DH4) < dh4 ? (jj - DH4) : dh4 - 1];
+            if (QUERY_IS_A) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 0], a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 1], a.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 2], a.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 3], a.w, acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * j + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * j + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * j + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * j + 3], acc, 0, 0, 0);
+            }
+            // pin the schedule: one 16-byte load, then this step's four MFMAs (keeps kRing loads
+            // in flight instead of letting the scheduler sink them next to their use)
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        return acc;
+    }
+};
 
 // float -> uint32 whose unsigned order equals the float order (and back).
 __device__ __forceinline__ uint32_t f32_sortable(float f) {
