@@ -68,6 +68,10 @@ def load() -> C.CDLL:
         raise FalconHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C falcon_amd/csrc`). falcon_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7 (same soname as /opt/rocm's).  Whichever is loaded
+    # first serves the whole process, and a process that mixes the two HIP runtimes loses its
+    # device; torch owns the device memory and streams we use, so its runtime goes first.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (args, res) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale

@@ -71,12 +71,9 @@ def allgatherv_rows(t, counts: Optional[List[int]] = None):
     if t.shape[0] < mx:
         pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         pad[: t.shape[0]] = t
-    out = torch.empty((ws * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad.contiguous())
-    if all(c == mx for c in counts):
-        return out, counts
-    parts = [out[r * mx: r * mx + counts[r]] for r in range(ws)]
-    return torch.cat(parts, 0), counts
+    slots = [torch.empty((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for _ in range(ws)]
+    dist.all_gather(slots, pad.contiguous())          # one collective (RCCL: a single all-gather)
+    return torch.cat([slots[r][: counts[r]] for r in range(ws)], 0), counts
 
 
 def allgatherv_neighbors(nb_idx, nb_dist, row_offset: int):

@@ -1,0 +1,214 @@
+"""`falcon` command line entry point: same contract as reference falcon/falcon.py:33-244
+(`main(args) -> int`, console script `falcon = falcon.falcon:main`, setup.cfg:43-45):
+read peak files, preprocess, cluster every precursor charge independently through
+`cluster.generate_clusters` (the seam the HIP path sits behind), write `<out>.csv`
+(+ optional `<out>.mgf` of cluster representatives).
+
+Differences kept deliberately small and listed in DESIGN.md: spectra are held in memory /
+`.npz` files in `work_dir` instead of Lance datasets (lance is not available), and only
+MGF input is built (mzML / mzXML are host XML parsing, out of scope).
+"""
+from __future__ import annotations
+
+import glob
+import json
+import logging
+import os
+import re
+import shutil
+import sys
+import tempfile
+import threading
+from typing import Dict, List, Union
+
+import numpy as np
+
+from . import __version__, seed
+from .cluster import cluster, spectrum
+from .config import config
+from .ms_io import ms_io
+
+logger = logging.getLogger("falcon")
+
+seed.set_seeds()                                                    # falcon.py:30
+
+
+def _natural_key(s: str):
+    """natural sort key (natsort is absent): digit runs compare as numbers (falcon.py:206-208)."""
+    return [(0, int(t)) if t.isdigit() else (1, t) for t in re.split(r"(\d+)", str(s))]
+
+
+def main(args: Union[str, List[str], None] = None) -> int:
+    logging.captureWarnings(True)
+    root = logging.getLogger()
+    root.setLevel(logging.DEBUG)
+    handler = logging.StreamHandler(sys.stderr)
+    handler.setLevel(logging.DEBUG)
+    handler.setFormatter(logging.Formatter(
+        "{asctime} {levelname} [{name}/{processName}] {module}.{funcName} : {message}", style="{"))
+    root.addHandler(handler)
+    try:
+        return _run(args)
+    finally:
+        root.removeHandler(handler)
+
+
+def _option_lines() -> List[str]:
+    c = config
+    return [
+        f"work_dir = {c.work_dir}", f"overwrite = {c.overwrite}",
+        f"export_representatives = {c.export_representatives}",
+        f"precursor_tol = {c.precursor_tol[0]:.2f} {c.precursor_tol[1]}", f"rt_tol = {c.rt_tol}",
+        f"fragment_tol = {c.fragment_tol:.2f}", f"linkage = {c.linkage}",
+        f"distance_threshold = {c.distance_threshold:.3f}", f"min_matched_peaks = {c.min_matched_peaks}",
+        f"batch_size = {c.batch_size}", f"min_peaks = {c.min_peaks}", f"min_mz_range = {c.min_mz_range:.2f}",
+        f"min_mz = {c.min_mz:.2f}", f"max_mz = {c.max_mz:.2f}",
+        f"remove_precursor_tol = {c.remove_precursor_tol:.2f}", f"min_intensity = {c.min_intensity:.2f}",
+        f"max_peaks_used = {c.max_peaks_used}", f"scaling = {c.scaling}",
+        # nearest-neighbour options (README.md:101-117)
+        f"eps = {c.eps:.3f}", f"n_probe = {c.n_probe}", f"n_neighbors = {c.n_neighbors}",
+        f"n_neighbors_ann = {c.n_neighbors_ann}", f"low_dim = {c.low_dim}", f"mz_interval = {c.mz_interval}",
+    ]
+
+
+def _run(args) -> int:
+    config.parse(args)
+    logger.info("falcon version %s", str(__version__))
+    for line in _option_lines():
+        logger.debug(line)
+
+    rm_work_dir = False
+    if config.work_dir is None:
+        config.work_dir = tempfile.mkdtemp()
+        rm_work_dir = True
+    elif os.path.isdir(config.work_dir):
+        logging.warning("Working directory %s already exists, previous results might get overwritten",
+                        config.work_dir)
+    spectra_dir = os.path.join(config.work_dir, "spectra")
+    os.makedirs(spectra_dir, exist_ok=True)
+
+    # falcon.py:86-122: refuse to clobber existing outputs unless --overwrite
+    exit_exists = False
+    for ext, what in ((".csv", "cluster assignments"), (".mgf", "cluster representatives")):
+        fn = f"{config.output_filename}{ext}"
+        if os.path.isfile(fn):
+            if config.overwrite:
+                logger.warning("Output file %s (%s) already exists and will be overwritten", fn, what)
+                os.remove(fn)
+            else:
+                logger.error("Output file %s (%s) already exists, aborting...", fn, what)
+                exit_exists = True
+    if exit_exists:
+        return 1
+
+    _, min_mz, max_mz = spectrum.get_dim(config.min_mz, config.max_mz, config.fragment_tol)   # falcon.py:124-126
+    if config.overwrite:
+        for fn in os.listdir(spectra_dir):
+            os.remove(os.path.join(spectra_dir, fn))
+    charge_path = os.path.join(spectra_dir, "charges.json")
+    if os.path.isfile(charge_path) and not config.overwrite:                                   # falcon.py:143-149
+        with open(charge_path) as f:
+            charges = json.load(f)
+    else:
+        charges = _prepare_spectra(spectra_dir, min_mz, max_mz)
+        with open(charge_path, "w") as f:
+            json.dump(charges, f)
+
+    ann = cluster.AnnParams(eps=config.eps, low_dim=config.low_dim, n_probe=config.n_probe,
+                            n_neighbors=config.n_neighbors, n_neighbors_ann=config.n_neighbors_ann,
+                            mz_interval=config.mz_interval, min_mz=config.min_mz, max_mz=config.max_mz)
+    pipe = cluster.ClusterPipeline(device=config.device)
+    rows_all, current_label, representatives = [], 0, []
+    for charge in charges:                                                                     # falcon.py:153
+        part = np.load(os.path.join(spectra_dir, f"spectra_charge_{charge}.npz"), allow_pickle=True)
+        n = len(part["precursor_mz"])
+        if n == 0:
+            continue
+        ds = cluster.SpectrumDataset(part["precursor_mz"], part["retention_time"], part["mz"], part["intensity"],
+                                     part["indptr"])
+        labels, medoids = cluster.generate_clusters(
+            ds, config.linkage, config.distance_threshold, config.min_matched_peaks, config.precursor_tol[0],
+            config.precursor_tol[1], config.rt_tol, config.fragment_tol, config.batch_size, ann=ann, pipeline=pipe)
+        labels = labels + current_label                                                        # falcon.py:189-193
+        current_label = int(labels.max()) + 1
+        for i in range(n):
+            rows_all.append((str(part["filename"][i]), str(part["identifier"][i]), charge,
+                             float(part["precursor_mz"][i]), float(part["retention_time"][i]), int(labels[i])))
+        if config.export_representatives:                                                      # falcon.py:198-203
+            ip = part["indptr"]
+            for c, m in enumerate(medoids):
+                representatives.append({
+                    "identifier": str(part["identifier"][m]), "precursor_mz": float(part["precursor_mz"][m]),
+                    "precursor_charge": None if charge == "None" else int(charge),
+                    "retention_time": float(part["retention_time"][m]), "mz": part["mz"][ip[m]:ip[m + 1]],
+                    "intensity": part["intensity"][ip[m]:ip[m + 1]], "cluster": int(labels[m])})
+
+    rows_all.sort(key=lambda r: (_natural_key(r[0]), _natural_key(r[1])))                      # falcon.py:206-208
+    n_clusters = len({r[5] for r in rows_all})
+    logger.info("Export cluster assignments of %d spectra to %d unique clusters to output file %s",
+                len(rows_all), n_clusters, f"{config.output_filename}.csv")
+    csv_worker = threading.Thread(target=_write_cluster_info, args=(rows_all,), daemon=True)
+    csv_worker.start()
+    if config.export_representatives:
+        logger.info("Export %d cluster representative spectra to output file %s", len(representatives),
+                    f"{config.output_filename}.mgf")
+        mgf_worker = threading.Thread(target=ms_io.write_spectra,
+                                      args=(f"{config.output_filename}.mgf", representatives), daemon=True)
+        mgf_worker.start()
+        mgf_worker.join()
+    csv_worker.join()
+    if rm_work_dir:
+        shutil.rmtree(config.work_dir)
+    return 0
+
+
+def _prepare_spectra(spectra_dir: str, min_mz: float, max_mz: float) -> List[str]:
+    """falcon.py:247-328, in memory: read + preprocess every peak file, partition by precursor
+    charge, store one CSR `.npz` per charge."""
+    filenames = [fn for pattern in config.input_filenames for fn in glob.glob(pattern)]
+    logger.info("Read spectra from %d peak file(s)", len(filenames))
+    by_charge: Dict[str, List[dict]] = {}
+    low_quality = 0
+    for fn in filenames:
+        fn = os.path.abspath(fn)
+        for spec in ms_io.get_spectra(fn):
+            spec["filename"] = fn
+            out = spectrum.process_spectrum(
+                spec, config.min_peaks, config.min_mz_range, min_mz, max_mz, config.remove_precursor_tol,
+                config.min_intensity, config.max_peaks_used, None if config.scaling == "off" else config.scaling)
+            if out is None:
+                low_quality += 1
+            else:
+                by_charge.setdefault(str(out["precursor_charge"]), []).append(out)
+    n_total = 0
+    for charge, specs in by_charge.items():
+        indptr = np.zeros(len(specs) + 1, np.int64)
+        np.cumsum([len(s["mz"]) for s in specs], out=indptr[1:])
+        np.savez(os.path.join(spectra_dir, f"spectra_charge_{charge}.npz"),
+                 identifier=np.array([s["identifier"] for s in specs], dtype=object),
+                 filename=np.array([s["filename"] for s in specs], dtype=object),
+                 precursor_mz=np.array([s["precursor_mz"] for s in specs], np.float32),
+                 retention_time=np.array([s["retention_time"] for s in specs], np.float32),
+                 mz=np.concatenate([s["mz"] for s in specs]).astype(np.float32),
+                 intensity=np.concatenate([s["intensity"] for s in specs]).astype(np.float32), indptr=indptr)
+        n_total += len(specs)
+    logger.info("Read %d spectra from %d peak files", n_total, len(filenames))
+    logger.info("Skipped %d low-quality spectra", low_quality)
+    return sorted(by_charge, key=_natural_key)
+
+
+def _write_cluster_info(rows) -> None:
+    """falcon.py:483-524: `#` header block with every option, then the CSV table."""
+    with open(f"{config.output_filename}.csv", "a") as f:
+        f.write(f"# falcon version {__version__}\n")
+        for line in _option_lines():
+            f.write(f"# {line}\n")
+        f.write("#\n")
+        f.write("filename,spectrum_id,precursor_charge,precursor_mz,retention_time,cluster\n")
+        for fn, sid, charge, pmz, rt, lab in rows:
+            sid_q = f'"{sid}"' if ("," in sid or '"' in sid) else sid
+            f.write(f"{fn},{sid_q},{charge},{pmz},{rt},{lab}\n")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

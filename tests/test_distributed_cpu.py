@@ -1,0 +1,55 @@
+"""The multi-GPU exchange on CPU: world_size 2, `gloo` backend (same code path as RCCL)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from falcon_amd import distributed as fd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = [5, 3][rank]
+        k = 4
+        rng = np.random.default_rng(rank)
+        nb_idx = torch.from_numpy(rng.integers(-1, n, (n, k)).astype(np.int32))
+        nb_dist = torch.from_numpy(rng.random((n, k)).astype(np.float32))
+        counts = fd.allgather_counts(n, torch.device("cpu"))
+        off = sum(counts[:rank])
+        gi, gd, c2 = fd.allgatherv_neighbors(nb_idx, nb_dist, off)
+        labels = torch.arange(n, dtype=torch.int32) % 2            # 2 local labels per rank
+        gl, lc = fd.allgatherv_labels(labels, 2)
+        q.put((rank, counts, gi.numpy(), gd.numpy(), gl.numpy(), lc, nb_idx.numpy(), nb_dist.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgatherv_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, counts0, gi0, gd0, gl0, lc0, i0, d0), (r1, counts1, gi1, gd1, gl1, lc1, i1, d1) = res
+    assert counts0 == counts1 == [5, 3] and lc0 == lc1 == [2, 2]
+    # every rank holds the same global graph: rank order, ids shifted to global rows, -1 kept
+    exp_idx = np.concatenate([i0, np.where(i1 >= 0, i1 + 5, i1)])
+    exp_dist = np.concatenate([d0, d1])
+    for gi, gd in ((gi0, gd0), (gi1, gd1)):
+        assert np.array_equal(gi, exp_idx) and np.array_equal(gd, exp_dist)
+    exp_lab = np.concatenate([np.arange(5) % 2, np.arange(3) % 2 + 2])
+    assert np.array_equal(gl0, exp_lab) and np.array_equal(gl1, exp_lab)

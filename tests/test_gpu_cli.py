@@ -1,0 +1,58 @@
+"""`falcon.main()` end to end on the HIP path: MGF in, CSV (+ representatives MGF) out
+(reference falcon.py:33-244 contract; BASELINE config 1 driven through the GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import falcon_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def test_main_mgf_to_csv(tmp_path):
+    from falcon_amd import synth
+    from falcon_amd.falcon import main
+    from falcon_amd.ms_io import ms_io
+    d = synth.generate(3000, seed=21)
+    specs = []
+    for i in range(3000):
+        a, b = d["indptr"][i], d["indptr"][i + 1]
+        specs.append({"identifier": f"scan={i}", "precursor_mz": float(d["precursor_mz"][i]),
+                      "precursor_charge": int(d["precursor_charge"][i]), "retention_time": float(d["retention_time"][i]),
+                      "mz": d["mz"][a:b].astype(np.float64), "intensity": d["intensity"][a:b]})
+    mgf = str(tmp_path / "in.mgf")
+    ms_io.write_spectra(mgf, specs)
+    out = str(tmp_path / "res")
+    args = [mgf, out, "--eps", "0.3", "--export_representatives", "--remove_precursor_tol", "0.0",
+            "--min_intensity", "0.0", "--work_dir", str(tmp_path / "work")]
+    assert main(args) == 0
+    lines = open(out + ".csv").read().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    assert head[0].startswith("# falcon version") and "# eps = 0.300" in head and "# n_probe = 16" in head
+    body = lines[len(head):]
+    assert body[0] == "filename,spectrum_id,precursor_charge,precursor_mz,retention_time,cluster"
+    rows = [l.split(",") for l in body[1:]]
+    assert len(rows) == 3000
+    ids = [r[1] for r in rows]
+    assert ids[:3] == ["scan=0", "scan=1", "scan=2"] and ids[10] == "scan=10"      # natural sort
+    lab = np.array([int(r[5]) for r in rows])
+    charge = np.array([int(r[2]) for r in rows])
+    assert set(np.unique(charge)) == {2, 3}
+    # labels of different charges never overlap (falcon.py:189-193) and are dense
+    assert lab[charge == 2].max() < lab[charge == 3].min()
+    assert np.array_equal(np.unique(lab), np.arange(lab.max() + 1))
+    # same clustering as the oracle, per charge
+    from sklearn.metrics import adjusted_rand_score
+    import warnings
+    for c in (2, 3):
+        sel = synth.select_charge(d, c)
+        ref, _ = fo.generate_clusters(sel["mz"], sel["intensity"], sel["indptr"], sel["precursor_mz"], None, eps=0.3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert adjusted_rand_score(ref, lab[sel["rows"]]) >= 0.99
+    reps = list(ms_io.get_spectra(out + ".mgf"))
+    assert len(reps) == lab.max() + 1
+    # outputs exist -> a second run without --overwrite aborts with 1 (falcon.py:120-122)
+    assert main(args) == 1
+    assert main(args + ["--overwrite"]) == 0

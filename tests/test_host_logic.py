@@ -1,0 +1,169 @@
+"""Host logic that runs without a GPU: config surface, n_list rule, MGF I/O, preprocessing,
+synthetic generator, shard assignment, and the C1 plumbing case through the oracle."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import falcon_oracle as fo
+
+
+def test_config_defaults_match_reference_and_readme():
+    from falcon_amd.config import Config
+    c = Config()
+    with pytest.raises(RuntimeError):           # config.py:203-206
+        c.eps
+    c.parse(["in.mgf", "out"])
+    # config.py:52-183 defaults
+    assert c.input_filenames == ["in.mgf"] and c.output_filename == "out"
+    assert c.precursor_tol == [20.0, "ppm"] and c.rt_tol is None and c.fragment_tol == 0.05
+    assert c.linkage == "complete" and c.distance_threshold == 0.1 and c.min_matched_peaks == 0
+    assert c.batch_size == 2 ** 15 and c.min_peaks == 5 and c.min_mz_range == 250.0
+    assert c.min_mz == 101.0 and c.max_mz == 1500.0 and c.remove_precursor_tol == 1.5
+    assert c.min_intensity == 0.01 and c.max_peaks_used == 50 and c.scaling == "off"
+    assert c.work_dir is None and not c.overwrite and not c.export_representatives
+    # README options
+    assert c.eps == 0.1 and c.n_probe == 16 and c.n_neighbors == 64 and c.n_neighbors_ann == 128 and c.low_dim == 400
+    assert c["eps"] == c.eps
+
+
+def test_config_cli_ini_and_aliases(tmp_path):
+    from falcon_amd.config import Config
+    c = Config()
+    c.parse("a.mgf b.mgf out --eps 0.25 --precursor_tol 0.05 Da --rt_tol 30 --export_representatives")  # README.md:49
+    assert c.input_filenames == ["a.mgf", "b.mgf"] and c.eps == 0.25 and c.distance_threshold == 0.25
+    assert c.precursor_tol == [0.05, "Da"] and c.rt_tol == 30.0 and c.export_representatives
+    ini = tmp_path / "falcon.ini"
+    ini.write_text("eps = 0.2\nn_probe = 8\nprecursor_tol = 10 ppm\noverwrite = true\n")
+    c = Config()
+    c.parse(["-c", str(ini), "x.mgf", "out", "--n_probe", "4"])
+    assert c.eps == 0.2 and c.n_probe == 4 and c.precursor_tol == [10.0, "ppm"] and c.overwrite
+    c = Config()
+    with pytest.raises(ValueError):
+        c.parse(["x.mgf", "out", "--n_neighbors", "64", "--n_neighbors_ann", "32"])
+    with pytest.raises(SystemExit):
+        Config().parse(["x.mgf", "out", "--scaling", "bogus"])
+
+
+def test_n_list_rule_matches_oracle():
+    from falcon_amd.cluster.cluster import n_list_rule
+    sizes = np.array([0, 1, 5, 100, 101, 624, 700, 1248, 3000, 40000, 10 ** 7])
+    for n_probe in (1, 16, 32):
+        got = n_list_rule(sizes, n_probe)
+        for s, g in zip(sizes, got):
+            ref = fo.n_list_for(int(s)) if s > 0 else 1
+            assert g == (1 if ref <= n_probe else ref), (s, n_probe)
+
+
+def test_mgf_roundtrip_and_preprocessing(tmp_path):
+    from falcon_amd.ms_io import mgf_io, ms_io
+    from falcon_amd.cluster.spectrum import process_spectrum
+    specs = [{"identifier": "s1", "precursor_mz": 500.25, "precursor_charge": 2, "retention_time": 12.5,
+              "mz": np.array([150.0, 300.5, 499.9, 700.25, 900.0, 1200.0]),
+              "intensity": np.array([10, 200, 50, 80, 5, 1], np.float32)},
+             {"identifier": "s2", "precursor_mz": 800.0, "precursor_charge": None, "retention_time": 3.0,
+              "mz": np.array([120.0, 130.0]), "intensity": np.array([1, 2], np.float32)}]
+    fn = str(tmp_path / "t.mgf")
+    ms_io.write_spectra(fn, specs)
+    back = list(ms_io.get_spectra(fn))
+    assert [b["identifier"] for b in back] == ["s1", "s2"]
+    assert back[0]["precursor_charge"] == 2 and back[1]["precursor_charge"] is None
+    np.testing.assert_allclose(back[0]["mz"], specs[0]["mz"])
+    # malformed spectrum is skipped (mgf_io.py:27-30)
+    bad = "BEGIN IONS\nTITLE=x\nCHARGE=2+\n100 1\nEND IONS\n"
+    assert list(mgf_io.get_spectra(io.StringIO(bad))) == []
+    with pytest.raises(ValueError):
+        list(ms_io.get_spectra(str(tmp_path / "nope.mgf")))
+    # 6 peaks: 499.9 falls to the precursor window (charge 2 -> 500.25), 1200 to the 1 % filter
+    assert process_spectrum(dict(back[0], filename="f"), 5, 250.0, 101.0, 1500.0, 1.5, 0.01, 50, None) is None
+    out = process_spectrum(dict(back[0], filename="f"), 4, 250.0, 101.0, 1500.0, 1.5, 0.01, 50, None)
+    assert out is not None and abs(np.linalg.norm(out["intensity"]) - 1) < 1e-6
+    assert list(out["mz"]) == [150.0, 300.5, 700.25, 900.0]
+    assert np.all(np.diff(out["mz"]) > 0) and out["mz"].dtype == np.float32
+    assert process_spectrum(dict(back[1], filename="f"), 5, 250.0, 101.0, 1500.0, 1.5, 0.01, 50, None) is None
+    root = process_spectrum(dict(back[0], filename="f"), 3, 100.0, 101.0, 1500.0, None, None, None, "root")
+    assert abs(np.linalg.norm(root["intensity"]) - 1) < 1e-6
+
+
+def test_synth_is_deterministic_and_well_formed():
+    from falcon_amd import synth
+    a, b = synth.generate(3000), synth.generate(3000)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    cnt = np.diff(a["indptr"])
+    assert cnt.max() <= 50 and cnt.min() >= 1 and a["mz"].dtype == np.float32
+    assert a["mz"].min() >= 101 and a["mz"].max() <= 1500
+    for i in (0, 17, 2999):
+        m = a["mz"][a["indptr"][i]:a["indptr"][i + 1]]
+        assert np.all(np.diff(m) >= 0)
+        it = a["intensity"][a["indptr"][i]:a["indptr"][i + 1]]
+        assert abs(np.linalg.norm(it.astype(np.float64)) - 1) < 1e-5
+    c2 = synth.select_charge(a, 2)
+    assert set(np.unique(a["precursor_charge"])) == {2, 3} and len(c2["precursor_mz"]) == (a["precursor_charge"] == 2).sum()
+    # blocks of other ranks differ
+    assert not np.array_equal(synth.generate(1000, first_block=1)["precursor_mz"], synth.generate(1000)["precursor_mz"])
+
+
+def test_shard_units_lpt():
+    from falcon_amd.distributed import shard_units
+    rng = np.random.default_rng(0)
+    cost = rng.pareto(2.0, 500) + 0.1
+    owner = shard_units(cost, 8)
+    load = np.bincount(owner, weights=cost, minlength=8)
+    assert load.max() / load.mean() < 1.05
+    assert np.array_equal(owner, shard_units(cost, 8))
+
+
+def test_c1_plumbing_mgf_through_the_oracle(tmp_path):
+    """BASELINE config 1 (CPU plumbing): synthetic spectra -> MGF -> reader -> preprocessing ->
+    the CPU restatement of the hot path; clustering equals the direct-array run."""
+    from falcon_amd import synth
+    from falcon_amd.ms_io import ms_io
+    from falcon_amd.cluster.spectrum import process_spectrum
+    from sklearn.metrics import adjusted_rand_score
+    d = synth.generate(1500, seed=11)
+    specs = []
+    for i in range(1500):
+        a, b = d["indptr"][i], d["indptr"][i + 1]
+        specs.append({"identifier": f"spec_{i}", "precursor_mz": float(d["precursor_mz"][i]),
+                      "precursor_charge": int(d["precursor_charge"][i]), "retention_time": float(d["retention_time"][i]),
+                      "mz": d["mz"][a:b].astype(np.float64), "intensity": d["intensity"][a:b]})
+    fn = str(tmp_path / "c1.mgf")
+    ms_io.write_spectra(fn, specs)
+    got = [process_spectrum(dict(s, filename=fn), 5, 250.0, 100.95, 1500.0, None, None, 50, None)
+           for s in ms_io.get_spectra(fn)]
+    got = [g for g in got if g is not None and g["precursor_charge"] == 2]
+    sel = np.flatnonzero(d["precursor_charge"] == 2)
+    assert len(got) == len(sel)
+    indptr = np.zeros(len(got) + 1, np.int64)
+    np.cumsum([len(g["mz"]) for g in got], out=indptr[1:])
+    lab_mgf, _ = fo.generate_clusters(np.concatenate([g["mz"] for g in got]),
+                                      np.concatenate([g["intensity"] for g in got]), indptr,
+                                      np.array([g["precursor_mz"] for g in got], np.float32), None, eps=0.3)
+    c2 = synth.select_charge(d, 2)
+    lab_arr, med = fo.generate_clusters(c2["mz"], c2["intensity"], c2["indptr"], c2["precursor_mz"], None, eps=0.3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert adjusted_rand_score(lab_arr, lab_mgf) >= 0.99
+    assert np.array_equal(lab_arr[med], np.arange(len(med)))
+
+
+def test_oracle_ivf_exhaustive_equals_bruteforce_and_dbscan_variants_agree():
+    from falcon_amd import synth
+    from sklearn.metrics import adjusted_rand_score
+    d = synth.select_charge(synth.generate(4000, seed=2, mz_lo=600.0, mz_hi=603.0), 2)
+    nb, start, _ = fo.get_dim(101, 1500, 0.05)
+    X = fo.vectorize(d["mz"], d["intensity"], d["indptr"], start, 0.05, nb, 400)[:1200]
+    C, a, perm, off = fo.ivf_build(X, 16, 3)
+    s1, i1 = fo.ivf_search(X, C, a, perm, off, 16, 32)
+    s2, i2 = fo.exhaustive_topk(X, 32)
+    assert np.array_equal(i1, i2) and np.allclose(s1, s2, atol=1e-6)
+    kw = dict(eps=0.3, mz_interval=0.0, batch_size=1024, n_probe=4, kmeans_iters=3)
+    l_comp, _ = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], None, **kw)
+    l_skl, _ = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], None, dbscan="sklearn", **kw)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert adjusted_rand_score(l_skl, l_comp) >= 0.99      # north_star gate, order-independent DBSCAN
