@@ -298,7 +298,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         std::vector<DenseJob> jobs;
         int64_t tiles = 0;
         for (const BucketDev& b : bk) {
-            jobs.push_back({b.row0, b.list0, 0, tiles, b.n, b.n_list});
+            jobs.push_back({b.row0, b.list0, 0, tiles, b.n, b.n_list, 0});
             tiles += ceil_div(b.n, 32);
         }
         DenseJob* jobs_dev = nullptr;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64, 1) void ivf_fine_kernel(FineArgs a) {
     if (lane == 0) uoff[U] = R;
     __syncthreads();
 
-    const int64_t simrow = qvalid ? (a.q_sim_off[p0 + r] - a.sims_base) : 0;
+    const int64_t simrow = qvalid ? (a.q_sim_off[32 * t + r] - a.sims_base) : 0;   // tile-order slot
     float* __restrict__ orow = a.sims + simrow;
 
     // ---- stream the union's rows, 32 per step ----------------------------------------------
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64, 1) void ivf_fine_kernel(FineArgs a) {
     for (int c0 = 0; c0 < R; c0 += 32) {
         while (ucur + 1 < U && uoff[ucur + 1] <= c0) ++ucur;
         const float* nxt = (c0 + 32 < R) ? row_ptr(c0 + 32, ucur) : cur;
-        const f32x16 acc = cs.template dot<false>(q, cur, nxt, dh4);
+        const f32x16 acc = cs.template dot<false>(q, cur, nxt, dh4, [] {});
         cur = nxt;
         // epilogue: lane = query r; registers = candidates c0 + mfma32_row(i, h)
         const int cend = min(c0 + 32, R);

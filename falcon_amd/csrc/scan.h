@@ -24,7 +24,7 @@ struct SelectArgs {
     int n_probe;
     const int32_t* probes;       // [n, n_probe] bucket-local list ids (-1 = none)
     const int64_t* list_off;     // [total_lists + 1] positions in list order
-    const int64_t* q_sim_off;    // [n] where the query's sims start (float index)
+    const int64_t* q_sim_off;    // [32 * tiles] where the sims of tile-order slot 32*t+lane start
     const int32_t* perm;         // [n] list-order position -> sorted row
 };
 
@@ -44,8 +44,11 @@ struct FineArgs {
     int u_cap;                   // LDS union capacity (>= min(32 * n_probe, max n_list))
 };
 
+// xcd_list_tiles > 0 selects XCD-list mode (simtile.h): `jobs` = the launch's jobs sorted by
+// decreasing size with xtile0 filled in, xcd_list_tiles = tiles of the longest of the 8 lists.
 int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,
-                 int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base, int32_t* assign);
+                 int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base, int32_t* assign,
+                 int64_t xcd_list_tiles = 0);
 int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks);
 int launch_fine(fal_ctx* ctx, const FineArgs& a);
 

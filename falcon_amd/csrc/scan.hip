@@ -17,15 +17,22 @@ template <int DH4, int EPI>
 __global__ __launch_bounds__(64, 1) void dense_kernel(
     const float* __restrict__ Q, const float* __restrict__ Cm, int d, const DenseJob* __restrict__ jobs,
     int n_jobs, int64_t tile_begin, int64_t n_tiles, float* __restrict__ sims, int64_t sims_base,
-    int32_t* __restrict__ assign) {
-    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a
-    // contiguous run of tiles (neighbouring tiles scan the same bucket -> shared L2 lines).
-    const int64_t per_xcd = (n_tiles + 7) / 8;
-    const int64_t lt_all = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || lt_all >= n_tiles) return;
-    const int64_t t = tile_begin + lt_all;
-    const DenseJob job = jobs[find_job(jobs, n_jobs, t)];
-    const int lt = (int)(t - job.tile0);
+    int32_t* __restrict__ assign, int xcd_lists) {
+    DenseJob job;
+    int lt;
+    if (xcd_lists) {
+        int ji;
+        if (!find_job_xcd(jobs, n_jobs, blockIdx.x, &ji, &lt)) return;
+        job = jobs[ji];
+    } else {
+        // contiguous run of tiles per XCD (neighbouring tiles scan the same bucket -> shared L2 lines)
+        const int64_t per_xcd = (n_tiles + 7) / 8;
+        const int64_t lt_all = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= per_xcd || lt_all >= n_tiles) return;
+        const int64_t t = tile_begin + lt_all;
+        job = jobs[find_job(jobs, n_jobs, t)];
+        lt = (int)(t - job.tile0);
+    }
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int nq_t = min(32, job.nq - 32 * lt);
     const int dh = d >> 1, dh4 = dh >> 2;
@@ -39,37 +46,47 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
     int bestc = 0x7fffffff;
     const int nc = job.nc;
     float* out = nullptr;
-    if (EPI == EPI_STORE) out = sims + (job.obase - sims_base) + (int64_t)(32 * lt) * nc;
+    // the [32, ncp] block of this tile (ncp = nc rounded up to 32): every store below is in bounds,
+    // so the epilogue has no branches and the compiler can count its stores in vmcnt exactly
+    const int ncp = (nc + 31) & ~31;
+    if (EPI == EPI_STORE) out = sims + (job.obase - sims_base) + (int64_t)(32 * lt) * ncp + r;
 
     CandStream<DH4> cs;
     const float* cur = Cm + (job.c_row0 + min(r, nc - 1)) * d + (int64_t)h * dh;
     cs.prime(cur, dh4);
-    for (int c0 = 0; c0 < nc; c0 += 32) {
-        const float* nxt = Cm + (job.c_row0 + min(c0 + 32 + r, nc - 1)) * d + (int64_t)h * dh;
-        if (EPI == EPI_STORE) {
-            const f32x16 acc = cs.template dot<true>(q, cur, nxt, dh4);
-            const int c = c0 + r;
-            if (c < nc) {
+    f32x16 prev;                 // the previous chunk's result; its epilogue runs inside this chunk
+    // before the first chunk "previous" is a dummy: zeros land in chunk 0's slots and are overwritten
+    // by the real chunk-0 epilogue later in program order; -inf never wins the arg-max.  Keeping the
+    // epilogue unconditional keeps its stores out of branches (exact vmcnt bookkeeping).
+    int prev_c0 = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int ql = mfma32_row(i, h);
-                    if (ql < nq_t) out[(int64_t)ql * nc + c] = acc[i];
-                }
-            }
+    for (int i = 0; i < 16; ++i) prev[i] = (EPI == EPI_STORE) ? 0.f : -INFINITY;
+    auto epilogue = [&]() {
+        if (EPI == EPI_STORE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) out[mfma32_row(i, h) * ncp + prev_c0] = prev[i];
+            __builtin_amdgcn_sched_group_barrier(0x040, 16, 0);   // keep the 16 stores HERE in the pipeline
         } else {
-            const f32x16 acc = cs.template dot<false>(q, cur, nxt, dh4);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int c = c0 + mfma32_row(i, h);
-                const float s = acc[i];
+                const int c = prev_c0 + mfma32_row(i, h);
+                const float s = prev[i];
                 if (c < nc && s > best) {
                     best = s;
                     bestc = c;
                 }
             }
         }
+    };
+    for (int c0 = 0; c0 < nc; c0 += 32) {
+        const float* nxt = Cm + (job.c_row0 + min(c0 + 32 + r, nc - 1)) * d + (int64_t)h * dh;
+        const f32x16 acc = (EPI == EPI_STORE) ? cs.template dot<true>(q, cur, nxt, dh4, epilogue)
+                                              : cs.template dot<false>(q, cur, nxt, dh4, epilogue);
+        prev = acc;
+        prev_c0 = c0;
         cur = nxt;
     }
+    epilogue();
     if (EPI == EPI_ARGMAX) {
         const float ob = __shfl_xor(best, 32, 64);
         const int oc = __shfl_xor(bestc, 32, 64);
@@ -84,16 +101,18 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
 template <int EPI>
 static int launch_dense_t(fal_ctx* ctx, int stage, const float* Q, const float* Cm, int d, const DenseJob* jobs,
                           int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base,
-                          int32_t* assign) {
+                          int32_t* assign, int64_t xcd_list_tiles) {
     if (n_tiles <= 0) return FAL_OK;
     const int dh4 = d / 8;
-    const int64_t per_xcd = (n_tiles + 7) / 8;
+    const int xcd_lists = xcd_list_tiles > 0;
+    // XCD-list mode: n_tiles is unused, the grid is 8 x (longest list)
+    const int64_t per_xcd = xcd_lists ? xcd_list_tiles : (n_tiles + 7) / 8;
     FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     dim3 grid((unsigned)(per_xcd * 8)), block(64);
     StageScope ts(ctx, stage);
 #define FAL_LAUNCH_DENSE(DH4)                                                                              \
     hipLaunchKernelGGL((dense_kernel<DH4, EPI>), grid, block, 0, ctx->stream, Q, Cm, d, jobs, n_jobs,      \
-                       tile_begin, n_tiles, sims, sims_base, assign)
+                       tile_begin, n_tiles, sims, sims_base, assign, xcd_lists)
     if (dh4 <= 8) FAL_LAUNCH_DENSE(8);
     else if (dh4 <= 16) FAL_LAUNCH_DENSE(16);
     else if (dh4 <= 32) FAL_LAUNCH_DENSE(32);
@@ -109,10 +128,13 @@ static int launch_dense_t(fal_ctx* ctx, int stage, const float* Q, const float* 
 }
 
 int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,
-                 int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base, int32_t* assign) {
+                 int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base, int32_t* assign,
+                 int64_t xcd_list_tiles) {
     if (epi == EPI_STORE)
-        return launch_dense_t<EPI_STORE>(ctx, stage, Q, Cm, d, jobs, n_jobs, tile_begin, n_tiles, sims, sims_base, assign);
-    return launch_dense_t<EPI_ARGMAX>(ctx, stage, Q, Cm, d, jobs, n_jobs, tile_begin, n_tiles, sims, sims_base, assign);
+        return launch_dense_t<EPI_STORE>(ctx, stage, Q, Cm, d, jobs, n_jobs, tile_begin, n_tiles, sims, sims_base,
+                                         assign, xcd_list_tiles);
+    return launch_dense_t<EPI_ARGMAX>(ctx, stage, Q, Cm, d, jobs, n_jobs, tile_begin, n_tiles, sims, sims_base, assign,
+                                      xcd_list_tiles);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
         const int lt = (int)(t - job.tile0);
         if (32 * lt + ql >= job.nq) return;
         nc = job.nc;
-        row = a.sims + (job.obase - a.sims_base) + (int64_t)(32 * lt + ql) * nc;
+        row = a.sims + (job.obase - a.sims_base) + (int64_t)(32 * lt + ql) * ((nc + 31) & ~31);
         out_row = job.q_row0 + 32 * (int64_t)lt + ql;
         id0 = a.ids_are_rows ? job.c_row0 : 0;
     } else {
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
         }
         __syncthreads();
         nc = seg_off[np];
-        row = a.sims + (a.q_sim_off[p] - a.sims_base);
+        row = a.sims + (a.q_sim_off[32 * t + ql] - a.sims_base);   // tile-order slot
         out_row = a.perm[p];
     }
 

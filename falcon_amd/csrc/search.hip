@@ -3,8 +3,9 @@
 // Flat buckets (one list): dense tile scan of the bucket against itself + wavefront select.
 // IVF buckets: coarse quantiser (dense scan vs the bucket's centroids + select k = n_probe),
 // candidate-count prefix, fine scan over the union of probed lists, select.
-// The sims of a batch of tiles live in one scratch buffer sized to stay inside the 256 MiB
-// Infinity Cache, so the scan -> select hand-off does not travel through HBM.
+// The sims of a batch of buckets live in one scratch buffer (default 1 GiB, FALCON_SIMS_MB): big
+// enough that a launch holds many tiles per wave slot (short launches lose more to their tail than
+// the buffer's HBM round trip costs; measured 160 MiB: 4.5 ms, 1 GiB: 3.5 ms of scan at 1 M spectra).
 #include <algorithm>
 #include <stdlib.h>
 #include "common.h"
@@ -13,7 +14,8 @@
 
 namespace fal {
 
-// total candidates of each query = sum of the sizes of its probed lists (0 where probes are -1)
+// total candidates of each query = sum of the sizes of its probed lists (0 where probes are -1),
+// stored at the query's TILE-ORDER slot 32 * tile + lane (unused lanes of a last tile stay 0)
 __global__ void probe_totals_kernel(const int32_t* __restrict__ probes, int np, const DenseJob* __restrict__ jobs,
                                     int n_jobs, int64_t n_tiles, const int64_t* __restrict__ list_off,
                                     int64_t* __restrict__ totals) {
@@ -29,14 +31,14 @@ __global__ void probe_totals_kernel(const int32_t* __restrict__ probes, int np, 
         const int l = probes[p * np + j];
         if (l >= 0) tot += list_off[job.c_row0 + l + 1] - list_off[job.c_row0 + l];
     }
-    totals[p] = tot;
+    totals[g] = tot;      // slot g = 32 * tile + lane (tile order, padded)
 }
 
 static size_t sims_capacity_floats() {
     static size_t cap = 0;
     if (!cap) {
         const char* e = getenv("FALCON_SIMS_MB");
-        size_t mb = e ? (size_t)atoll(e) : 160;
+        size_t mb = e ? (size_t)atoll(e) : 1024;
         if (mb < 16) mb = 16;
         cap = mb * 1024 * 1024 / sizeof(float);
     }
@@ -62,23 +64,54 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     const size_t cap = sims_capacity_floats();
 
     // ---- job tables ------------------------------------------------------------------------
+    // Flat buckets are visited in order of decreasing size and dealt to the 8 XCD lists round-robin
+    // (simtile.h, XCD-list mode): the longest tiles start first, every XCD gets the same mix.
+    std::vector<int64_t> border;
+    for (int64_t b = 0; b < n_buckets; ++b)
+        if (ivf->n_list[b] == 1 && ivf->bucket_off[b + 1] > ivf->bucket_off[b]) border.push_back(b);
+    std::stable_sort(border.begin(), border.end(), [&](int64_t x, int64_t y) {
+        return ivf->bucket_off[x + 1] - ivf->bucket_off[x] > ivf->bucket_off[y + 1] - ivf->bucket_off[y];
+    });
     std::vector<DenseJob> flat, coarse;    // coarse doubles as the IVF tile table
-    int64_t flat_tiles = 0, ivf_tiles = 0, flat_o = 0, coarse_o = 0;
+    struct FlatBatch { size_t j0, j1; int64_t tiles, list_tiles, floats; };
+    std::vector<FlatBatch> flat_batches;
+    size_t need_flat = 0;
+    {
+        FlatBatch cur{0, 0, 0, 0, 0};
+        int64_t xt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto close = [&]() {
+            if (cur.j1 > cur.j0) {
+                cur.list_tiles = *std::max_element(xt, xt + 8);
+                flat_batches.push_back(cur);
+                need_flat = std::max(need_flat, (size_t)cur.floats);
+            }
+            cur = FlatBatch{cur.j1, cur.j1, 0, 0, 0};
+            std::fill(xt, xt + 8, 0);
+        };
+        for (int64_t b : border) {
+            const int64_t row0 = ivf->bucket_off[b], nb = ivf->bucket_off[b + 1] - row0;
+            const int64_t tiles = ceil_div(nb, 32), floats = tiles * 32 * ((nb + 31) & ~31ll);
+            if (cur.floats + floats > (int64_t)cap && cur.j1 > cur.j0) close();
+            const int x = (int)((cur.j1 - cur.j0) & 7);
+            // obase / tile0 / xtile0 are relative to the batch
+            flat.push_back({row0, row0, cur.floats, cur.tiles, (int32_t)nb, (int32_t)nb, xt[x]});
+            xt[x] += tiles;
+            cur.tiles += tiles;
+            cur.floats += floats;
+            cur.j1++;
+        }
+        close();
+    }
+    int64_t ivf_tiles = 0, coarse_o = 0;
     int max_n_list = 0;
     for (int64_t b = 0; b < n_buckets; ++b) {
         const int64_t row0 = ivf->bucket_off[b], nb = ivf->bucket_off[b + 1] - row0;
-        if (nb == 0) continue;
+        if (nb == 0 || ivf->n_list[b] == 1) continue;
         const int64_t tiles = ceil_div(nb, 32);
-        if (ivf->n_list[b] == 1) {
-            flat.push_back({row0, row0, flat_o, flat_tiles, (int32_t)nb, (int32_t)nb});
-            flat_tiles += tiles;
-            flat_o += tiles * 32 * nb;
-        } else {
-            coarse.push_back({row0, ivf->list_base[b], coarse_o, ivf_tiles, (int32_t)nb, ivf->n_list[b]});
-            ivf_tiles += tiles;
-            coarse_o += tiles * 32 * (int64_t)ivf->n_list[b];
-            max_n_list = std::max(max_n_list, ivf->n_list[b]);
-        }
+        coarse.push_back({row0, ivf->list_base[b], coarse_o, ivf_tiles, (int32_t)nb, ivf->n_list[b], 0});
+        ivf_tiles += tiles;
+        coarse_o += tiles * 32 * (((int64_t)ivf->n_list[b] + 31) & ~31ll);
+        max_n_list = std::max(max_n_list, ivf->n_list[b]);
     }
     // batches of whole tiles whose sims fit the buffer: [tile_begin, tile_end)
     auto make_batches = [&](const std::vector<DenseJob>& jobs, int64_t n_tiles, std::vector<int64_t>& cuts, size_t& need) {
@@ -86,7 +119,7 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         need = 0;
         int64_t used = 0;
         for (const DenseJob& j : jobs) {
-            const int64_t tiles = ceil_div(j.nq, 32), per_tile = 32 * (int64_t)j.nc;
+            const int64_t tiles = ceil_div(j.nq, 32), per_tile = 32 * (((int64_t)j.nc + 31) & ~31ll);
             for (int64_t t = 0; t < tiles;) {
                 int64_t room = ((int64_t)cap - used) / per_tile;
                 if (room <= 0 && used > 0) {
@@ -110,12 +143,11 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
             size_t mid = (lo + hi + 1) / 2;
             if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
         }
-        return jobs[lo].obase + (t - jobs[lo].tile0) * 32 * (int64_t)jobs[lo].nc;
+        return jobs[lo].obase + (t - jobs[lo].tile0) * 32 * (((int64_t)jobs[lo].nc + 31) & ~31ll);
     };
 
-    std::vector<int64_t> flat_cuts, coarse_cuts;
-    size_t need_flat = 0, need_coarse = 0;
-    if (!flat.empty()) make_batches(flat, flat_tiles, flat_cuts, need_flat);
+    std::vector<int64_t> coarse_cuts;
+    size_t need_coarse = 0;
     if (!coarse.empty()) make_batches(coarse, ivf_tiles, coarse_cuts, need_coarse);
 
     DenseJob *flat_dev = nullptr, *coarse_dev = nullptr;
@@ -131,20 +163,20 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * std::max(need_flat, need_coarse), (void**)&sims));
 
     // ---- A. flat buckets ---------------------------------------------------------------------
-    for (size_t bi = 0; bi + 1 < flat_cuts.size(); ++bi) {
-        const int64_t t0 = flat_cuts[bi], t1 = flat_cuts[bi + 1];
-        const int64_t base = obase_of_tile(flat, t0);
-        FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->Xl, ivf->Xl, d, flat_dev, (int)flat.size(), t0, t1 - t0, sims,
-                             base, nullptr));
+    for (const FlatBatch& fb : flat_batches) {
+        const DenseJob* jb = flat_dev + fb.j0;
+        const int nj = (int)(fb.j1 - fb.j0);
+        FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->Xl, ivf->Xl, d, jb, nj, 0, fb.tiles, sims, 0, nullptr,
+                             fb.list_tiles));
         SelectArgs sa{};
-        sa.sims = sims; sa.sims_base = base; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
-        sa.jobs = flat_dev; sa.n_jobs = (int)flat.size(); sa.tile_begin = t0; sa.ids_are_rows = 1;
-        FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, (t1 - t0) * 32));
+        sa.sims = sims; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
+        sa.jobs = jb; sa.n_jobs = nj; sa.tile_begin = 0; sa.ids_are_rows = 1;
+        FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, fb.tiles * 32));
     }
     ctx->counters[0] = 0;
     for (const DenseJob& j : flat) ctx->counters[0] += (int64_t)j.nq * j.nc;
     ctx->counters[1] = 0;
-    ctx->counters[2] = (int64_t)(flat_cuts.empty() ? 0 : flat_cuts.size() - 1);
+    ctx->counters[2] = (int64_t)flat_batches.size();
     ctx->counters[3] = (int64_t)(sizeof(float) * std::max(need_flat, need_coarse));
     if (coarse.empty()) {
         FAL_CHECK_HIP(hipStreamSynchronize(st));   // job vectors die with this frame
@@ -159,9 +191,10 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     int64_t *totals = nullptr, *q_sim_off = nullptr;
     FAL_TRY(ctx->reserve(SLOT_PROBES, sizeof(int32_t) * (size_t)ivf->n * np, (void**)&probes));
     FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * (size_t)ivf->n * np, (void**)&probe_sim));
-    FAL_TRY(ctx->reserve(SLOT_QOFF, sizeof(int64_t) * (size_t)(ivf->n + 1), (void**)&q_sim_off));
-    FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (size_t)(ivf->n + 1), (void**)&totals));
-    FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(ivf->n + 1), st));
+    const int64_t n_slots = ivf_tiles * 32;
+    FAL_TRY(ctx->reserve(SLOT_QOFF, sizeof(int64_t) * (size_t)(n_slots + 1), (void**)&q_sim_off));
+    FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (size_t)(n_slots + 1), (void**)&totals));
+    FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(n_slots + 1), st));
     for (size_t bi = 0; bi + 1 < coarse_cuts.size(); ++bi) {
         const int64_t t0 = coarse_cuts[bi], t1 = coarse_cuts[bi + 1];
         const int64_t base = obase_of_tile(coarse, t0);
@@ -174,52 +207,35 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     }
     {
         StageScope ts(ctx, ST_COARSE);
-        hipLaunchKernelGGL(probe_totals_kernel, dim3((unsigned)ceil_div(ivf_tiles * 32, 256)), dim3(256), 0, st, probes, np,
+        hipLaunchKernelGGL(probe_totals_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, st, probes, np,
                            coarse_dev, (int)coarse.size(), ivf_tiles, ivf->list_off, totals);
-        FAL_TRY(launch_exclusive_scan(ctx, totals, ivf->n, q_sim_off));
+        FAL_TRY(launch_exclusive_scan(ctx, totals, n_slots, q_sim_off));
     }
-    // candidate prefix back to the host to cut the fine scan into buffer-sized batches
-    std::vector<int64_t> qoff((size_t)ivf->n + 1);
-    FAL_CHECK_HIP(hipMemcpyAsync(qoff.data(), q_sim_off, sizeof(int64_t) * qoff.size(), hipMemcpyDeviceToHost, st));
+    // one prefix value per tile back to the host to cut the fine scan into buffer-sized batches
+    std::vector<int64_t> qoff((size_t)ivf_tiles + 1);
+    FAL_CHECK_HIP(hipMemcpy2DAsync(qoff.data(), sizeof(int64_t), q_sim_off, 32 * sizeof(int64_t), sizeof(int64_t),
+                                   (size_t)ivf_tiles + 1, hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipStreamSynchronize(st));
     std::vector<int64_t> fine_cuts(1, 0);
     size_t need_fine = 0;
     {
-        int64_t batch_first_p = -1, used = 0;
-        for (const DenseJob& j : coarse) {
-            const int64_t tiles = ceil_div(j.nq, 32);
-            for (int64_t t = 0; t < tiles; ++t) {
-                const int64_t pa = j.q_row0 + 32 * t, pb = std::min<int64_t>(pa + 32, j.q_row0 + j.nq);
-                const int64_t sz = qoff[pb] - qoff[pa];
-                if (batch_first_p < 0) batch_first_p = pa;
-                // a batch's sims span [qoff[first p], qoff[last p]) -- flat rows in between add nothing
-                const int64_t span = qoff[pb] - qoff[batch_first_p];
-                if (span > (int64_t)cap && used > 0) {
-                    fine_cuts.push_back(j.tile0 + t);
-                    batch_first_p = pa;
-                    used = 0;
-                }
-                used += sz;
-                need_fine = std::max(need_fine, (size_t)(qoff[pb] - qoff[batch_first_p]));
+        int64_t first = 0;
+        for (int64_t t = 0; t < ivf_tiles; ++t) {
+            if (qoff[t + 1] - qoff[first] > (int64_t)cap && t > first) {
+                fine_cuts.push_back(t);
+                first = t;
             }
+            need_fine = std::max(need_fine, (size_t)(qoff[t + 1] - qoff[first]));
         }
         if (fine_cuts.back() != ivf_tiles) fine_cuts.push_back(ivf_tiles);
     }
-    ctx->counters[0] += qoff[(size_t)ivf->n];
+    ctx->counters[0] += qoff[(size_t)ivf_tiles];
     ctx->counters[2] += (int64_t)fine_cuts.size() - 1;
     ctx->counters[3] = std::max<int64_t>(ctx->counters[3], (int64_t)(sizeof(float) * need_fine));
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * std::max<size_t>(need_fine, 16), (void**)&sims));
-    auto first_p_of_tile = [&](int64_t t) -> int64_t {
-        size_t lo = 0, hi = coarse.size() - 1;
-        while (lo < hi) {
-            size_t mid = (lo + hi + 1) / 2;
-            if (coarse[mid].tile0 <= t) lo = mid; else hi = mid - 1;
-        }
-        return coarse[lo].q_row0 + 32 * (t - coarse[lo].tile0);
-    };
     for (size_t bi = 0; bi + 1 < fine_cuts.size(); ++bi) {
         const int64_t t0 = fine_cuts[bi], t1 = fine_cuts[bi + 1];
-        const int64_t base = qoff[first_p_of_tile(t0)];
+        const int64_t base = qoff[(size_t)t0];
         FineArgs fa{};
         fa.Xl = ivf->Xl; fa.d = d; fa.jobs = coarse_dev; fa.n_jobs = (int)coarse.size();
         fa.tile_begin = t0; fa.n_tiles = t1 - t0; fa.n_probe = np; fa.probes = probes;

@@ -57,9 +57,14 @@ struct CandStream {
     // when there is none).
     // QUERY_IS_A = true : D[query][cand]  (lane: candidate = lane&31, 16 query rows in registers)
     // QUERY_IS_A = false: D[cand][query]  (lane: query = lane&31, 16 candidate rows in registers)
-    template <bool QUERY_IS_A>
+    // `mid()` runs once, kMidStep steps into the chunk: callers put the PREVIOUS chunk's epilogue
+    // there, so its stores / VALU work overlap this chunk's MFMAs and are long retired before any
+    // load issued after them is waited on (gfx950's vmcnt counts stores and loads together).
+    static constexpr int kMidStep = (DH4 > 24) ? 12 : DH4 / 2;
+
+    template <bool QUERY_IS_A, class Mid>
     __device__ __forceinline__ f32x16 dot(const float (&q)[DH4 * 4], const float* __restrict__ cur_half,
-                                          const float* __restrict__ next_half, int dh4) {
+                                          const float* __restrict__ next_half, int dh4, Mid&& mid) {
         const float4* pc = reinterpret_cast<const float4*>(cur_half);
         const float4* pn = reinterpret_cast<const float4*>(next_half);
         f32x16 acc;
@@ -87,6 +92,7 @@ struct CandStream {
             // in flight instead of letting the scheduler sink them next to their use)
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (j == kMidStep) mid();
         }
         return acc;
     }
@@ -104,7 +110,7 @@ __device__ __forceinline__ float sortable_f32(uint32_t u) {
 
 // One unit of dense work: the queries [q_row0, q_row0+nq) of array Q against the candidates
 // [c_row0, c_row0+nc) of array C.  Tiles of 32 queries; tile0 = index of the job's first tile
-// in the launch; obase = where the job's [nq, nc] block of sims starts (float index).
+// in the launch; obase = where the job's sims start (float index): one [32, ceil32(nc)] block per tile.
 struct DenseJob {
     int64_t q_row0;
     int64_t c_row0;
@@ -112,6 +118,7 @@ struct DenseJob {
     int64_t tile0;
     int32_t nq;
     int32_t nc;
+    int64_t xtile0;   // XCD-list mode: tiles of earlier jobs of the same XCD list (jobs j, j+8, j+16 ...)
 };
 
 // binary search: last job whose tile0 <= t
@@ -122,6 +129,30 @@ __device__ __forceinline__ int find_job(const DenseJob* __restrict__ jobs, int n
         if (jobs[mid].tile0 <= t) lo = mid; else hi = mid - 1;
     }
     return lo;
+}
+
+// XCD-list mode.  Workgroups are dealt round-robin over the 8 XCDs in blockIdx order, so a launch
+// is only as fast as its most loaded XCD.  Jobs (buckets) arrive sorted by decreasing size and job
+// j of the launch belongs to XCD list j % 8: every XCD gets the same mix of sizes (LPT-like) while
+// all tiles of a bucket stay on ONE XCD (its rows are fetched into one L2 only).  Block b serves
+// tile (b >> 3) of list (b & 7).  Returns false when that list is shorter.
+__device__ __forceinline__ bool find_job_xcd(const DenseJob* __restrict__ jobs, int n_jobs, unsigned bid,
+                                             int* job_index, int* local_tile) {
+    const int x = bid & 7;
+    const int64_t i = bid >> 3;
+    const int cnt = (n_jobs - x + 7) >> 3;          // jobs x, x+8, ... < n_jobs
+    if (cnt <= 0) return false;
+    int lo = 0, hi = cnt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[x + 8 * mid].xtile0 <= i) lo = mid; else hi = mid - 1;
+    }
+    const DenseJob& j = jobs[x + 8 * lo];
+    const int64_t lt = i - j.xtile0;
+    if (lt >= (j.nq + 31) / 32) return false;
+    *job_index = x + 8 * lo;
+    *local_tile = (int)lt;
+    return true;
 }
 
 }  // namespace fal
