@@ -141,13 +141,197 @@ int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* 
 // wavefront top-k select: one wave per query over that query's row of sims
 // ---------------------------------------------------------------------------------------------
 // Keys are (sortable sim, id); order = sim descending, then id ascending.  A round holds up to
-// 1024 keys in registers (16 per lane): the survivors of earlier rounds plus new candidates.
-// The k-th largest sim is found by a 32-step bitwise binary search whose counts are wave ballots
-// (v_cmp + s_bcnt1, no LDS); boundary ties are resolved by a second search over ids.  Survivors
-// are compacted into LDS by ballot-prefix ranks; the final <= k keys are rank-sorted.
-constexpr int kSelRegs = 16;
-
+// 64*R keys in registers (R per lane; R = 4, 8 or 16 chosen per query from its candidate count):
+// the survivors of earlier rounds plus new candidates.  The k-th largest sim is found by a bitwise
+// binary search whose counts are wave ballots (v_cmp + s_bcnt1, no LDS) and which stops as soon as
+// a threshold splits off exactly k keys; boundary ties are resolved by a second search over ids.
+// Survivors are compacted into LDS by ballot-prefix ranks; the final <= k keys are sorted by an
+// in-register bitonic network over the wave (shuffles, no LDS).
 __device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
+
+struct SelQuery {
+    const float* row;     // this query's sims
+    int64_t nc;           // number of candidates
+    int64_t id0;          // MODE_DENSE: id = id0 + position
+};
+
+template <int MODE, int R>
+__device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery& qy, int k, int lane,
+                                             uint32_t* sel_u, uint32_t* sel_id, const int64_t* seg_off,
+                                             const int64_t* seg_src) {
+    uint32_t u[R], id[R];
+    int carry = 0;
+    int64_t pos = 0;
+    bool first = true;
+    while (first || pos < qy.nc) {
+        first = false;
+        // ---- fill: slot s = i*64 + lane; the first `carry` slots come from LDS ---------------
+        const int64_t fresh = min<int64_t>(qy.nc - pos, 64 * R - carry);
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int s = i * 64 + lane;
+            u[i] = 0;
+            id[i] = 0xFFFFFFFFu;
+            if (s < carry) {
+                u[i] = sel_u[s];
+                id[i] = sel_id[s];
+            } else if (s - carry < fresh) {
+                const int64_t pp = pos + (s - carry);
+                u[i] = max(f32_sortable(qy.row[pp]), 1u);
+                if (MODE == MODE_DENSE) {
+                    id[i] = (uint32_t)(qy.id0 + pp);
+                } else {
+                    int lo = 0, hi = a.n_probe - 1;      // last segment with seg_off <= pp
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
+                    }
+                    id[i] = (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])];
+                }
+            }
+        }
+        const int m = carry + (int)fresh;
+        pos += fresh;
+        __syncthreads();   // all reads of sel_* done before they are rewritten
+
+        uint32_t T = 1, I = 0xFFFFFFFFu;
+        if (m > k) {
+            // largest T with count(u >= T) >= k; stop early when a threshold isolates exactly k keys
+            T = 0;
+            bool exact = false;
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t c = T | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) cnt += wave_count(u[i] >= c);
+                if (cnt >= k) T = c;
+                if (cnt == k) {
+                    exact = true;
+                    break;
+                }
+            }
+            if (!exact) {
+                int gt = 0, eq = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    gt += wave_count(u[i] > T);
+                    eq += wave_count(u[i] == T);
+                }
+                const int need = k - gt;
+                if (eq > need) {
+                    uint32_t lo = 0;      // largest value with count(u == T && id < lo) < need
+                    for (int bit = 31; bit >= 0; --bit) {
+                        const uint32_t c = lo | (1u << bit);
+                        int cnt = 0;
+#pragma unroll
+                        for (int i = 0; i < R; ++i) cnt += wave_count(u[i] == T && id[i] < c);
+                        if (cnt < need) lo = c;
+                    }
+                    I = lo;
+                }
+            }
+        }
+        // ---- compact survivors into LDS --------------------------------------------------
+        int base = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const bool keep = u[i] != 0 && ((u[i] > T) || (u[i] == T && id[i] <= I));
+            const uint64_t mask = __ballot(keep);
+            if (keep) {
+                const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
+                sel_u[w] = u[i];
+                sel_id[w] = id[i];
+            }
+            base += __popcll(mask);
+        }
+        carry = base;
+        __syncthreads();
+    }
+    return carry;
+}
+
+// lane ^ X exchange without LDS traffic where the hardware allows: DPP quad_perm for X = 1, 2;
+// ds_swizzle (bit-mask mode, no address VGPR, no memory) for X = 4, 8, 16; ds_bpermute for 32.
+template <int X>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if (X == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    if (X == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    if (X == 4 || X == 8 || X == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (X << 10));
+    return (uint32_t)__shfl_xor((int)v, X, 64);
+}
+
+// one compare-exchange level of the bitonic network at distance STRIDE inside blocks of SIZE.
+// Element index = lane * E + reg, so strides below E stay inside a lane's registers.
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_level(uint32_t (&hi)[E], uint32_t (&lo)[E], int lane) {
+    if constexpr (STRIDE < E) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            if ((r & STRIDE) == 0) {
+                const bool desc = ((lane * E + r) & SIZE) == 0;
+                const bool a_lt_b = hi[r] < hi[r | STRIDE] || (hi[r] == hi[r | STRIDE] && lo[r] < lo[r | STRIDE]);
+                if (a_lt_b == desc) {
+                    const uint32_t th = hi[r], tl = lo[r];
+                    hi[r] = hi[r | STRIDE];
+                    lo[r] = lo[r | STRIDE];
+                    hi[r | STRIDE] = th;
+                    lo[r | STRIDE] = tl;
+                }
+            }
+        }
+    } else {
+        constexpr int X = STRIDE / E;
+        const bool lower = (lane & X) == 0;          // this lane holds the lower index of the pair
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint32_t oh = lane_xor<X>(hi[r]), ol = lane_xor<X>(lo[r]);
+            const bool desc = ((lane * E + r) & SIZE) == 0;
+            const bool mine_lt = hi[r] < oh || (hi[r] == oh && lo[r] < ol);
+            const bool mine_gt = hi[r] > oh || (hi[r] == oh && lo[r] > ol);
+            // descending: the lower index keeps the larger key
+            if ((lower == desc) ? mine_lt : mine_gt) {
+                hi[r] = oh;
+                lo[r] = ol;
+            }
+        }
+    }
+}
+
+template <int E, int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_merge(uint32_t (&hi)[E], uint32_t (&lo)[E], int lane) {
+    bitonic_level<E, SIZE, STRIDE>(hi, lo, lane);
+    if constexpr (STRIDE > 1) bitonic_merge<E, SIZE, STRIDE / 2>(hi, lo, lane);
+}
+
+template <int E, int SIZE>
+__device__ __forceinline__ void bitonic_build(uint32_t (&hi)[E], uint32_t (&lo)[E], int lane) {
+    if constexpr (SIZE > 2) bitonic_build<E, SIZE / 2>(hi, lo, lane);
+    bitonic_merge<E, SIZE, SIZE / 2>(hi, lo, lane);
+}
+
+// descending sort of 64*E keys (hi = sortable sim, lo = ~id), E per lane at index lane*E + reg;
+// empty slots are (0, 0) and sink to the end
+template <int E>
+__device__ __forceinline__ void sort_and_store(const uint32_t* sel_u, const uint32_t* sel_id, int carry, int k, int lane,
+                                               float* __restrict__ osim, int32_t* __restrict__ oidx) {
+    uint32_t hi[E], lo[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int e = lane * E + r;
+        hi[r] = e < carry ? sel_u[e] : 0u;
+        lo[r] = e < carry ? ~sel_id[e] : 0u;
+    }
+    bitonic_build<E, 64 * E>(hi, lo, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int e = lane * E + r;
+        if (e < k) {
+            const bool valid = e < carry;
+            osim[e] = valid ? sortable_f32(hi[r]) : -INFINITY;
+            oidx[e] = valid ? (int32_t)~lo[r] : -1;
+        }
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
@@ -159,26 +343,19 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     const int k = a.k;
 
     // ---- locate this query ---------------------------------------------------------------
-    const float* row = nullptr;   // this query's sims
-    int64_t nc = 0;               // number of candidates
+    SelQuery qy{nullptr, 0, 0};
     int64_t out_row = 0;
-    int64_t id0 = 0;
+    const int64_t t = a.tile_begin + (blockIdx.x >> 5);
+    const int ql = blockIdx.x & 31;
+    const DenseJob job = a.jobs[find_job(a.jobs, a.n_jobs, t)];
+    const int lt = (int)(t - job.tile0);
+    if (32 * lt + ql >= job.nq) return;
     if (MODE == MODE_DENSE) {
-        const int64_t t = a.tile_begin + (blockIdx.x >> 5);
-        const int ql = blockIdx.x & 31;
-        const DenseJob job = a.jobs[find_job(a.jobs, a.n_jobs, t)];
-        const int lt = (int)(t - job.tile0);
-        if (32 * lt + ql >= job.nq) return;
-        nc = job.nc;
-        row = a.sims + (job.obase - a.sims_base) + (int64_t)(32 * lt + ql) * ((nc + 31) & ~31);
+        qy.nc = job.nc;
+        qy.row = a.sims + (job.obase - a.sims_base) + (int64_t)(32 * lt + ql) * ((job.nc + 31) & ~31);
         out_row = job.q_row0 + 32 * (int64_t)lt + ql;
-        id0 = a.ids_are_rows ? job.c_row0 : 0;
+        qy.id0 = a.ids_are_rows ? job.c_row0 : 0;
     } else {
-        const int64_t t = a.tile_begin + (blockIdx.x >> 5);
-        const int ql = blockIdx.x & 31;
-        const DenseJob job = a.jobs[find_job(a.jobs, a.n_jobs, t)];
-        const int lt = (int)(t - job.tile0);
-        if (32 * lt + ql >= job.nq) return;
         const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;   // query position in list order
         const int np = a.n_probe;
         const int32_t* pr = a.probes + p * np;
@@ -199,113 +376,21 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
             seg_off[np] = off;
         }
         __syncthreads();
-        nc = seg_off[np];
-        row = a.sims + (a.q_sim_off[32 * t + ql] - a.sims_base);   // tile-order slot
+        qy.nc = seg_off[np];
+        qy.row = a.sims + (a.q_sim_off[32 * t + ql] - a.sims_base);   // tile-order slot
         out_row = a.perm[p];
     }
 
-    uint32_t u[kSelRegs], id[kSelRegs];
-    int carry = 0;
-    int64_t pos = 0;
-    bool first = true;
-    while (first || pos < nc) {
-        first = false;
-        // ---- fill: slot s = i*64 + lane; the first `carry` slots come from LDS ---------------
-        const int64_t fresh = min<int64_t>(nc - pos, 64 * kSelRegs - carry);
-#pragma unroll
-        for (int i = 0; i < kSelRegs; ++i) {
-            const int s = i * 64 + lane;
-            u[i] = 0;
-            id[i] = 0xFFFFFFFFu;
-            if (s < carry) {
-                u[i] = sel_u[s];
-                id[i] = sel_id[s];
-            } else if (s - carry < fresh) {
-                const int64_t pp = pos + (s - carry);
-                u[i] = max(f32_sortable(row[pp]), 1u);
-                if (MODE == MODE_DENSE) {
-                    id[i] = (uint32_t)(id0 + pp);
-                } else {
-                    int lo = 0, hi = a.n_probe - 1;      // last segment with seg_off <= pp
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
-                    }
-                    id[i] = (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])];
-                }
-            }
-        }
-        const int m = carry + (int)fresh;
-        pos += fresh;
-        __syncthreads();   // all reads of sel_* done before they are rewritten
+    int carry;
+    if (qy.nc <= 256) carry = select_rounds<MODE, 4>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
+    else if (qy.nc <= 512) carry = select_rounds<MODE, 8>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
+    else carry = select_rounds<MODE, 16>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
 
-        uint32_t T = 1, I = 0xFFFFFFFFu;
-        if (m > k) {
-            // k-th largest sortable sim
-            T = 0;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t c = T | (1u << bit);
-                int cnt = 0;
-#pragma unroll
-                for (int i = 0; i < kSelRegs; ++i) cnt += wave_count(u[i] >= c);
-                if (cnt >= k) T = c;
-            }
-            int gt = 0, eq = 0;
-#pragma unroll
-            for (int i = 0; i < kSelRegs; ++i) {
-                gt += wave_count(u[i] > T);
-                eq += wave_count(u[i] == T);
-            }
-            const int need = k - gt;
-            if (eq > need) {
-                // smallest I with count(u == T && id <= I) >= need
-                uint32_t lo = 0;
-                for (int bit = 31; bit >= 0; --bit) {
-                    const uint32_t c = lo | (1u << bit);      // test: are there >= need ids < c ?
-                    int cnt = 0;
-#pragma unroll
-                    for (int i = 0; i < kSelRegs; ++i) cnt += wave_count(u[i] == T && id[i] < c);
-                    if (cnt < need) lo = c;
-                }
-                I = lo;   // largest value with count(id < I) < need  =>  count(id <= I) >= need
-            }
-        }
-        // ---- compact survivors into LDS --------------------------------------------------
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < kSelRegs; ++i) {
-            const bool keep = (u[i] > T) || (u[i] == T && u[i] != 0 && id[i] <= I);
-            const uint64_t mask = __ballot(keep);
-            if (keep) {
-                const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
-                sel_u[w] = u[i];
-                sel_id[w] = id[i];
-            }
-            base += __popcll(mask);
-        }
-        carry = base;
-        __syncthreads();
-    }
-
-    // ---- rank sort the survivors and write the row ---------------------------------------
     float* osim = a.out_sim + out_row * k;
     int32_t* oidx = a.out_idx + out_row * k;
-    for (int e = lane; e < k; e += 64) {
-        if (e >= carry) {
-            osim[e] = -INFINITY;
-            oidx[e] = -1;
-        }
-    }
-    for (int e = lane; e < carry; e += 64) {
-        const uint32_t mu = sel_u[e], mi = sel_id[e];
-        int rank = 0;
-        for (int j = 0; j < carry; ++j) {
-            const uint32_t ou = sel_u[j], oi = sel_id[j];
-            rank += (ou > mu) || (ou == mu && oi < mi);
-        }
-        osim[rank] = sortable_f32(mu);
-        oidx[rank] = (int32_t)mi;
-    }
+    if (k <= 64) sort_and_store<1>(sel_u, sel_id, carry, k, lane, osim, oidx);
+    else if (k <= 128) sort_and_store<2>(sel_u, sel_id, carry, k, lane, osim, oidx);
+    else sort_and_store<4>(sel_u, sel_id, carry, k, lane, osim, oidx);
 }
 
 int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks) {
