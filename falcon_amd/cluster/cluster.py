@@ -111,14 +111,18 @@ class ClusterPipeline:
         sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
         nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
                                              p.n_neighbors)
-        db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)
         if keep_intermediates:
+            # staged calls (one C-ABI call per SURVEY 8a row) so that every intermediate can be inspected
+            db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)
             self.last = dict(order=order, mz_sorted=mzs, rt_sorted=rts, splits=splits, X=X, n_list=n_list,
                              sim=sim, idx=idx, nb_idx=nb_idx, nb_dist=nb_dist, db=db.clone(), n_db=n_db, index=index)
-        lab, n_cl = c.refine_clusters(db, n_db, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol)
-        if keep_intermediates:
+            lab, n_cl = c.refine_clusters(db, n_db, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol)
             self.last.update(lab_sorted=lab, n_clusters=n_cl)
-        labels, medoids = c.finalize(lab, n_cl, order, nb_idx, nb_dist)
+            labels, medoids = c.finalize(lab, n_cl, order, nb_idx, nb_dist)
+        else:
+            # production: a9..a12 fused, counts stay on the device, one synchronisation
+            labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
+                                                    precursor_tol_mode, rt_tol, order)
         if not keep_intermediates:
             index.close()
         return labels, medoids

@@ -59,8 +59,16 @@ struct fal_ctx {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
         size_t used = 0;
     } timers[fal::kNumStages];
-    fal::Scratch scratch[16];
+    fal::Scratch scratch[24];
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // caching device allocator for per-call objects (index arrays): blocks are recycled, never
+    // returned to the driver before the context dies (hipMalloc / hipFree cost ~100 us each and
+    // hipFree synchronises the device)
+    struct PoolBlock { void* ptr; size_t cap; bool used; };
+    std::vector<PoolBlock> pool;
+    int pool_alloc(size_t bytes, void** out);
+    void pool_free(void* ptr);
 
     int reserve(int slot, size_t bytes, void** out);
     void stage_reset(int stage);

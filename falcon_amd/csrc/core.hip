@@ -31,6 +31,33 @@ int fal_ctx::reserve(int slot, size_t bytes, void** out) {
     return FAL_OK;
 }
 
+int fal_ctx::pool_alloc(size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    int best = -1;
+    for (size_t i = 0; i < pool.size(); ++i)
+        if (!pool[i].used && pool[i].cap >= bytes && (best < 0 || pool[i].cap < pool[best].cap)) best = (int)i;
+    if (best >= 0 && pool[best].cap <= 2 * bytes + (1 << 20)) {
+        pool[best].used = true;
+        *out = pool[best].ptr;
+        return FAL_OK;
+    }
+    void* p = nullptr;
+    const size_t cap = bytes + bytes / 16 + 256;
+    FAL_CHECK_HIP(hipMalloc(&p, cap));
+    pool.push_back({p, cap, true});
+    *out = p;
+    return FAL_OK;
+}
+
+void fal_ctx::pool_free(void* ptr) {
+    if (!ptr) return;
+    for (auto& b : pool)
+        if (b.ptr == ptr) {
+            b.used = false;      // stream-ordered reuse: every user enqueues on this context's stream
+            return;
+        }
+}
+
 void fal_ctx::stage_reset(int stage) { timers[stage].used = 0; }
 
 int fal_ctx::stage_begin(int stage, hipEvent_t* stop_out) {
@@ -108,6 +135,7 @@ int fal_ctx_destroy(fal_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->scratch)
         if (s.ptr) (void)hipFree(s.ptr);
+    for (auto& b : c->pool) (void)hipFree(b.ptr);
     for (auto& t : c->timers)
         for (auto& p : t.ev) {
             (void)hipEventDestroy(p.first);

@@ -161,16 +161,15 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
     return FAL_OK;
 }
 
-int fal_dbscan(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps, int32_t* labels,
-               int64_t* n_clusters) {
-    FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_dbscan: bad argument");
-    if (n_clusters) *n_clusters = 0;
-    if (n == 0) return FAL_OK;
-    FAL_REQUIRE(nb_idx && nb_dist && labels, FAL_EINVAL, "fal_dbscan: NULL array");
+}  // extern "C"
+
+// a9 with the cluster count left on the device at *d_count_out (no host synchronisation)
+int fal::dbscan_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps,
+                    int32_t* labels, int64_t** d_count_out) {
     int32_t* buf = nullptr;
     int64_t* rank = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int32_t) * (size_t)n * 4, (void**)&buf));
-    FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(n + 1), (void**)&rank));
+    FAL_TRY(ctx->reserve(SLOT_DB, sizeof(int32_t) * (size_t)n * 4, (void**)&buf));
+    FAL_TRY(ctx->reserve(SLOT_DB2, sizeof(int64_t) * (size_t)(n + 1), (void**)&rank));
     int32_t *core = buf, *parent = buf + n, *border = buf + 2 * n, *is_root = buf + 3 * n;
     const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
     const int egrid = (int)std::min<int64_t>(ceil_div(n * k, 256), (int64_t)ctx->num_cus * 32);
@@ -180,15 +179,25 @@ int fal_dbscan(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_
         hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent, border);
         hipLaunchKernelGGL(dbscan_edges_kernel, dim3(egrid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent, border);
         hipLaunchKernelGGL(dbscan_roots_kernel, dim3(grid), dim3(256), 0, ctx->stream, core, parent, n, is_root);
-        FAL_TRY(device_scan_i32(ctx, is_root, n, rank, SLOT_TAIL3));
+        FAL_TRY(device_scan_i32(ctx, is_root, n, rank, SLOT_DB3));
         hipLaunchKernelGGL(dbscan_label_kernel, dim3(grid), dim3(256), 0, ctx->stream, core, parent, border, rank, n, labels);
     }
     FAL_CHECK_HIP(hipGetLastError());
+    *d_count_out = rank + n;
+    return FAL_OK;
+}
+
+extern "C" int fal_dbscan(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps,
+                          int32_t* labels, int64_t* n_clusters) {
+    FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_dbscan: bad argument");
+    if (n_clusters) *n_clusters = 0;
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(nb_idx && nb_dist && labels, FAL_EINVAL, "fal_dbscan: NULL array");
+    int64_t* d_count = nullptr;
+    FAL_TRY(fal::dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels, &d_count));
     if (n_clusters) {
-        FAL_CHECK_HIP(hipMemcpyAsync(n_clusters, rank + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipMemcpyAsync(n_clusters, d_count, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     }
     return FAL_OK;
 }
-
-}  // extern "C"

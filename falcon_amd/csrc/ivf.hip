@@ -188,22 +188,14 @@ using namespace fal;
 // ------------------------------------------------------------------------------------------
 // build
 // ------------------------------------------------------------------------------------------
-static int dev_alloc(void** p, size_t bytes) {
-    *p = nullptr;
-    if (bytes == 0) bytes = 16;
-    FAL_CHECK_HIP(hipMalloc(p, bytes));
-    return FAL_OK;
-}
 
 extern "C" {
 
 int fal_ivf_destroy(fal_ivf* ivf) {
     if (!ivf) return FAL_OK;
-    if (ivf->ctx) (void)hipStreamSynchronize(ivf->ctx->stream);
-    void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts,
-                    ivf->bk_dev, ivf->q_list_base};
+    void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
     return FAL_OK;
 }
@@ -268,12 +260,11 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
 #define B_TRY(e) do { rc = (e); if (rc != FAL_OK) return fail(rc); } while (0)
 #define B_HIP(e) do { hipError_t _e = (e); if (_e != hipSuccess) { set_error("%s:%d %s: %s", __FILE__, __LINE__, #e, hipGetErrorString(_e)); return fail(_e == hipErrorOutOfMemory ? FAL_ENOMEM : FAL_EHIP); } } while (0)
 
-    B_TRY(dev_alloc((void**)&ivf->perm, sizeof(int32_t) * (size_t)n));
-    B_TRY(dev_alloc((void**)&ivf->assign, sizeof(int32_t) * (size_t)n));
-    B_TRY(dev_alloc((void**)&ivf->list_off, sizeof(int64_t) * (size_t)(total + 1)));
-    B_TRY(dev_alloc((void**)&ivf->counts, sizeof(int64_t) * (size_t)(total + 1)));
-    B_TRY(dev_alloc((void**)&ivf->centroids, sizeof(float) * (size_t)total * low_dim));
-    B_TRY(dev_alloc((void**)&ivf->q_list_base, sizeof(int64_t) * (size_t)n));
+    B_TRY(ctx->pool_alloc(sizeof(int32_t) * (size_t)n, (void**)&ivf->perm));
+    B_TRY(ctx->pool_alloc(sizeof(int32_t) * (size_t)n, (void**)&ivf->assign));
+    B_TRY(ctx->pool_alloc(sizeof(int64_t) * (size_t)(total + 1), (void**)&ivf->list_off));
+    B_TRY(ctx->pool_alloc(sizeof(int64_t) * (size_t)(total + 1), (void**)&ivf->counts));
+    B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)total * low_dim, (void**)&ivf->centroids));
     ctx->stage_reset(ST_BUILD);
 
     // counts: flat buckets hold all their rows in their single list
@@ -281,8 +272,8 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         std::vector<int64_t> cnt_host(total + 1, 0), qlb;
         for (int64_t b = 0; b < n_buckets; ++b)
             if (n_list[b] == 1) cnt_host[ivf->list_base[b]] = bucket_off[b + 1] - bucket_off[b];
+        // pageable source: hipMemcpyAsync returns once the data sits in the runtime's staging buffer
         B_HIP(hipMemcpyAsync(ivf->counts, cnt_host.data(), sizeof(int64_t) * (total + 1), hipMemcpyHostToDevice, st));
-        B_HIP(hipStreamSynchronize(st));   // cnt_host goes out of scope
     }
     B_HIP(hipMemsetAsync(ivf->assign, 0, sizeof(int32_t) * (size_t)n, st));
     B_HIP(hipMemsetAsync(ivf->centroids, 0, sizeof(float) * (size_t)total * low_dim, st));
@@ -292,7 +283,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         B_HIP(hipGetLastError());
     }
     if (!bk.empty()) {
-        B_TRY(dev_alloc((void**)&ivf->bk_dev, sizeof(BucketDev) * bk.size()));
+        B_TRY(ctx->pool_alloc(sizeof(BucketDev) * bk.size(), (void**)&ivf->bk_dev));
         B_HIP(hipMemcpyAsync(ivf->bk_dev, bk.data(), sizeof(BucketDev) * bk.size(), hipMemcpyHostToDevice, st));
         // dense jobs: rows of the bucket x centroids of the bucket
         std::vector<DenseJob> jobs;
@@ -304,7 +295,6 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         DenseJob* jobs_dev = nullptr;
         B_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * jobs.size(), (void**)&jobs_dev));
         B_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(DenseJob) * jobs.size(), hipMemcpyHostToDevice, st));
-        B_HIP(hipStreamSynchronize(st));   // host vectors are about to go away / be reused
         const BucketDev* bkd = (const BucketDev*)ivf->bk_dev;
         const int nbk = (int)bk.size();
         {
@@ -331,7 +321,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         hipLaunchKernelGGL(list_walk_kernel<2>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
                            nbk, nullptr, nullptr, ivf->list_off, ivf->perm);
         B_HIP(hipGetLastError());
-        B_TRY(dev_alloc((void**)&ivf->Xl_owned, sizeof(float) * (size_t)n * low_dim));
+        B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * low_dim, (void**)&ivf->Xl_owned));
         hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), ctx->num_cus * 16)),
                            dim3(256), 0, st, X, ivf->perm, n, low_dim, ivf->Xl_owned);
         B_HIP(hipGetLastError());

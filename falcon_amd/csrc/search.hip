@@ -178,10 +178,7 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     ctx->counters[1] = 0;
     ctx->counters[2] = (int64_t)flat_batches.size();
     ctx->counters[3] = (int64_t)(sizeof(float) * std::max(need_flat, need_coarse));
-    if (coarse.empty()) {
-        FAL_CHECK_HIP(hipStreamSynchronize(st));   // job vectors die with this frame
-        return FAL_OK;
-    }
+    if (coarse.empty()) return FAL_OK;   // (job tables were copied from pageable memory: already staged)
     for (const DenseJob& j : coarse) ctx->counters[1] += (int64_t)j.nq * j.nc;
 
     // ---- B. IVF buckets: coarse quantiser ------------------------------------------------------

@@ -180,122 +180,136 @@ __device__ void flat_cut_1d(const RefineScratch& S, int64_t o, int m, double t, 
     __syncthreads();
 }
 
-// one wave per DBSCAN cluster c: rows[seg[c] .. seg[c+1]) are its members (ascending rows)
-__global__ __launch_bounds__(64) void refine_kernel(const int32_t* __restrict__ rows, const int64_t* __restrict__ seg,
+// ascending in-place sort of the m member rows of one cluster (rank by counting through `tmp`)
+__device__ __forceinline__ void sort_rows(int32_t* __restrict__ rows, int32_t* __restrict__ tmp, int m, int lane) {
+    for (int e = lane; e < m; e += 64) tmp[e] = rows[e];
+    __syncthreads();
+    for (int e = lane; e < m; e += 64) {
+        const int32_t v = tmp[e];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += tmp[j] < v;
+        rows[rank] = v;
+    }
+    __syncthreads();
+}
+
+// one wave per DBSCAN cluster c (grid-stride; the cluster count lives on the device):
+// rows[seg[c] .. seg[c+1]) are its members, scattered in arbitrary order by member_scatter_kernel.
+__global__ __launch_bounds__(64) void refine_kernel(int32_t* __restrict__ rows, const int64_t* __restrict__ seg,
+                                                    const int64_t* __restrict__ d_count,
                                                     const float* __restrict__ mz, const float* __restrict__ rt,
                                                     double tol, int is_da, double rt_tol, RefineScratch S,
                                                     int32_t* __restrict__ sub, int32_t* __restrict__ n_sub) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int64_t o = seg[c];
-    const int m = (int)(seg[c + 1] - o);
+    const int lane = threadIdx.x;
+    const int64_t C = *d_count;
     const bool use_rt = rt != nullptr && rt_tol >= 0.0;
-    int32_t* out = sub + o;
-    if (m < 2) {                                   // cluster.py:399-402 (min_samples = 2)
-        for (int e = lane; e < m; e += 64) out[e] = -1;
-        if (lane == 0) n_sub[c] = 0;
-        return;
-    }
-    int32_t* A = S.t_a + o;
-    for (int e = lane; e < m; e += 64) S.val[o + e] = mz[rows[o + e]];
-    __syncthreads();
-    flat_cut_1d(S, o, m, tol, !is_da, use_rt, A, lane);
-    if (use_rt) {
-        int32_t* B = S.t_b + o;
-        for (int e = lane; e < m; e += 64) S.val[o + e] = rt[rows[o + e]];
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const int64_t o = seg[c];
+        const int m = (int)(seg[c + 1] - o);
+        int32_t* out = sub + o;
         __syncthreads();
-        flat_cut_1d(S, o, m, rt_tol, false, true, B, lane);
-        // cluster.py:423-429: np.unique(a * 2 + b * 3, return_inverse=True)[1]
-        int32_t* V = S.stack + o;
-        int32_t* first = S.visit + o;
-        for (int e = lane; e < m; e += 64) V[e] = A[e] * 2 + B[e] * 3;
-        __syncthreads();
-        for (int e = lane; e < m; e += 64) {
-            bool f = true;
-            for (int j = 0; j < e && f; ++j) f = V[j] != V[e];
-            first[e] = f;
-        }
-        __syncthreads();
-        for (int e = lane; e < m; e += 64) {
-            int r = 0;
-            for (int j = 0; j < m; ++j) r += first[j] && V[j] < V[e];
-            A[e] = r;
-        }
-        __syncthreads();
-    }
-    // number of flat clusters = max + 1
-    int mx = 0;
-    for (int e = lane; e < m; e += 64) mx = max(mx, A[e]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
-    const int n_flat = mx + 1;
-    if (n_flat == 1) {                              // cluster.py:433-435
-        for (int e = lane; e < m; e += 64) out[e] = 0;
-        if (lane == 0) n_sub[c] = 1;
-        return;
-    }
-    if (n_flat == m) {                              // cluster.py:436-439
-        for (int e = lane; e < m; e += 64) out[e] = -1;
-        if (lane == 0) n_sub[c] = 0;
-        return;
-    }
-    // cluster.py:441-454: groups with < 2 members -> -1, the others numbered by first occurrence
-    int32_t* fo = S.ord + o;      // first occurrence (member index) of the member's group, or -1 if group too small
-    for (int e = lane; e < m; e += 64) {
-        int cnt = 0, f = -1;
-        for (int j = 0; j < m; ++j) {
-            if (A[j] == A[e]) {
-                if (f < 0) f = j;
-                ++cnt;
-            }
-        }
-        fo[e] = cnt >= 2 ? f : -1;
-    }
-    __syncthreads();
-    int total = 0;
-    for (int e = lane; e < m; e += 64) {
-        int id = -1;
-        if (fo[e] >= 0) {
-            id = 0;
-            for (int j = 0; j < fo[e]; ++j) id += fo[j] == j;     // kept groups that start earlier
-        }
-        out[e] = id;
-        total += fo[e] == e;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
-    if (lane == 0) n_sub[c] = total;
-}
-
-__global__ void label_keys_kernel(const int32_t* __restrict__ labels, int64_t n, int32_t n_clusters,
-                                  uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t l = labels[i];
-        keys[i] = l < 0 ? (uint32_t)n_clusters : (uint32_t)l;
-        vals[i] = (int32_t)i;
-    }
-}
-
-// seg[c] = first sorted position with key c (keys 0..n_clusters; every cluster id occurs)
-__global__ void seg_start_kernel(const uint32_t* __restrict__ keys, int64_t n, int32_t n_clusters,
-                                 int64_t* __restrict__ seg) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i == n) {
-            // positions after the last cluster: noise block start (or n)
-            if (n == 0 || keys[n - 1] != (uint32_t)n_clusters) seg[n_clusters] = n;
+        if (m < 2) {                                   // cluster.py:399-402 (min_samples = 2)
+            for (int e = lane; e < m; e += 64) out[e] = -1;
+            if (lane == 0) n_sub[c] = 0;
             continue;
         }
-        if (i == 0 || keys[i] != keys[i - 1]) seg[keys[i]] = i;
+        sort_rows(rows + o, S.stack + o, m, lane);     // members in ascending (precursor-sorted) row order
+        int32_t* A = S.t_a + o;
+        for (int e = lane; e < m; e += 64) S.val[o + e] = mz[rows[o + e]];
+        __syncthreads();
+        flat_cut_1d(S, o, m, tol, !is_da, use_rt, A, lane);
+        if (use_rt) {
+            int32_t* B = S.t_b + o;
+            for (int e = lane; e < m; e += 64) S.val[o + e] = rt[rows[o + e]];
+            __syncthreads();
+            flat_cut_1d(S, o, m, rt_tol, false, true, B, lane);
+            // cluster.py:423-429: np.unique(a * 2 + b * 3, return_inverse=True)[1]
+            int32_t* V = S.stack + o;
+            int32_t* first = S.visit + o;
+            for (int e = lane; e < m; e += 64) V[e] = A[e] * 2 + B[e] * 3;
+            __syncthreads();
+            for (int e = lane; e < m; e += 64) {
+                bool f = true;
+                for (int j = 0; j < e && f; ++j) f = V[j] != V[e];
+                first[e] = f;
+            }
+            __syncthreads();
+            for (int e = lane; e < m; e += 64) {
+                int r = 0;
+                for (int j = 0; j < m; ++j) r += first[j] && V[j] < V[e];
+                A[e] = r;
+            }
+            __syncthreads();
+        }
+        // number of flat clusters = max + 1
+        int mx = 0;
+        for (int e = lane; e < m; e += 64) mx = max(mx, A[e]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off, 64));
+        const int n_flat = mx + 1;
+        if (n_flat == 1) {                              // cluster.py:433-435
+            for (int e = lane; e < m; e += 64) out[e] = 0;
+            if (lane == 0) n_sub[c] = 1;
+            continue;
+        }
+        if (n_flat == m) {                              // cluster.py:436-439
+            for (int e = lane; e < m; e += 64) out[e] = -1;
+            if (lane == 0) n_sub[c] = 0;
+            continue;
+        }
+        // cluster.py:441-454: groups with < 2 members -> -1, the others numbered by first occurrence
+        int32_t* fo = S.ord + o;      // first occurrence (member index) of the member's group, -1 if the group is too small
+        for (int e = lane; e < m; e += 64) {
+            int cnt = 0, f = -1;
+            for (int j = 0; j < m; ++j) {
+                if (A[j] == A[e]) {
+                    if (f < 0) f = j;
+                    ++cnt;
+                }
+            }
+            fo[e] = cnt >= 2 ? f : -1;
+        }
+        __syncthreads();
+        int total = 0;
+        for (int e = lane; e < m; e += 64) {
+            int id = -1;
+            if (fo[e] >= 0) {
+                id = 0;
+                for (int j = 0; j < fo[e]; ++j) id += fo[j] == j;     // kept groups that start earlier
+            }
+            out[e] = id;
+            total += fo[e] == e;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) total += __shfl_xor(total, off, 64);
+        if (lane == 0) n_sub[c] = total;
     }
 }
 
-__global__ void relabel_kernel(const int32_t* __restrict__ rows, const uint32_t* __restrict__ keys, int64_t n,
-                               int32_t n_clusters, const int32_t* __restrict__ sub, const int64_t* __restrict__ base,
-                               int32_t* __restrict__ labels) {
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t c = keys[p];
-        int32_t lab = -1;
-        if (c < (uint32_t)n_clusters && sub[p] >= 0) lab = (int32_t)(base[c] + sub[p]);
-        labels[rows[p]] = lab;
+// members of every DBSCAN cluster, grouped: histogram -> exclusive scan -> scatter
+__global__ void label_hist_kernel(const int32_t* __restrict__ labels, int64_t n, int32_t* __restrict__ counts) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (labels[i] >= 0) atomicAdd(&counts[labels[i]], 1);
+}
+
+__global__ void member_scatter_kernel(const int32_t* __restrict__ labels, int64_t n, const int64_t* __restrict__ seg,
+                                      int32_t* __restrict__ cursor, int32_t* __restrict__ rows) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t l = labels[i];
+        if (l >= 0) rows[seg[l] + atomicAdd(&cursor[l], 1)] = (int32_t)i;
+    }
+}
+
+// one wave per cluster: final label = (clusters kept by earlier DBSCAN clusters) + sub id
+__global__ __launch_bounds__(64) void relabel_kernel(const int32_t* __restrict__ rows, const int64_t* __restrict__ seg,
+                                                     const int64_t* __restrict__ d_count,
+                                                     const int32_t* __restrict__ sub, const int64_t* __restrict__ base,
+                                                     int32_t* __restrict__ labels) {
+    const int64_t C = *d_count;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const int64_t o = seg[c];
+        const int m = (int)(seg[c + 1] - o);
+        for (int e = threadIdx.x; e < m; e += 64) labels[rows[o + e]] = sub[o + e] >= 0 ? (int32_t)(base[c] + sub[o + e]) : -1;
     }
 }
 
@@ -335,10 +349,11 @@ __global__ void medoid_score_kernel(const int32_t* __restrict__ labels, int64_t 
     }
 }
 
-__global__ void finalize_kernel(const int32_t* __restrict__ labels, int64_t n, int64_t n_clusters,
+__global__ void finalize_kernel(const int32_t* __restrict__ labels, int64_t n, const int64_t* __restrict__ d_count,
                                 const int64_t* __restrict__ row_order, const int64_t* __restrict__ noise_rank,
                                 const unsigned long long* __restrict__ best, int32_t* __restrict__ labels_out,
                                 int32_t* __restrict__ medoids_out) {
+    const int64_t n_clusters = *d_count;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t ds = row_order[i];
         const int32_t l = labels[i];
@@ -357,6 +372,77 @@ __global__ void finalize_kernel(const int32_t* __restrict__ labels, int64_t n, i
 
 using namespace fal;
 
+// a10 on device-resident counts: *d_count_in DBSCAN clusters in, *d_count_out refined clusters out
+int fal::refine_dev(fal_ctx* ctx, int32_t* labels, int64_t n, const float* mz, const float* rt, double tol, int is_da,
+                    double rt_tol, const int64_t* d_count_in, int64_t** d_count_out) {
+    hipStream_t st = ctx->stream;
+    const int64_t cmax = n / 2 + 1;           // a DBSCAN cluster has at least two members
+    int32_t *counts = nullptr, *rows = nullptr;
+    int64_t *seg = nullptr, *base = nullptr;
+    unsigned char* slab = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int32_t) * (size_t)(3 * cmax + 2 * n) + 64, (void**)&counts));
+    int32_t* cursor = counts + cmax;
+    int32_t* n_sub = cursor + cmax;
+    rows = n_sub + cmax;
+    int32_t* sub = rows + n;
+    FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(2 * (cmax + 2)), (void**)&seg));
+    base = seg + (cmax + 2);
+    const size_t per = 4 * 11 + 8;   // 11 4-byte arrays + 1 double array
+    FAL_TRY(ctx->reserve(SLOT_TAIL4, per * (size_t)n + 256, (void**)&slab));
+    RefineScratch S;
+    S.zmd = reinterpret_cast<double*>(slab);
+    float* f = reinterpret_cast<float*>(slab + 8 * (size_t)n);
+    S.val = f;            S.smin = f + n;       S.smax = f + 2 * n;
+    int32_t* q = reinterpret_cast<int32_t*>(f + 3 * n);
+    S.ord = q;            S.sid = q + n;        S.zl = q + 2 * n;     S.zr = q + 3 * n;
+    S.t_a = q + 4 * n;    S.t_b = q + 5 * n;    S.stack = q + 6 * n;  S.visit = q + 7 * n;
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
+    const int cgrid = (int)std::min<int64_t>(cmax, (int64_t)ctx->num_cus * 32);
+    FAL_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)(3 * cmax), st));   // counts, cursor, n_sub
+    {
+        StageScope ts(ctx, ST_TAIL);
+        hipLaunchKernelGGL(label_hist_kernel, dim3(grid), dim3(256), 0, st, labels, n, counts);
+        FAL_TRY(device_scan_i32(ctx, counts, cmax, seg, SLOT_TAIL3));
+        hipLaunchKernelGGL(member_scatter_kernel, dim3(grid), dim3(256), 0, st, labels, n, seg, cursor, rows);
+        hipLaunchKernelGGL(refine_kernel, dim3(cgrid), dim3(64), 0, st, rows, seg, d_count_in, mz,
+                           rt_tol >= 0.0 ? rt : nullptr, tol, is_da, rt_tol, S, sub, n_sub);
+        FAL_TRY(device_scan_i32(ctx, n_sub, cmax, base, SLOT_TAIL3));
+        hipLaunchKernelGGL(relabel_kernel, dim3(cgrid), dim3(64), 0, st, rows, seg, d_count_in, sub, base, labels);
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    *d_count_out = base + cmax;     // total of n_sub
+    return FAL_OK;
+}
+
+// a11 + a12 on a device-resident cluster count; the number of noise rows is left at *d_noise_out
+int fal::finalize_dev(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, const int64_t* d_count,
+                      const int64_t* row_order, const int32_t* nb_idx, const float* nb_dist, int k,
+                      int32_t* labels_out, int32_t* medoids_out, int64_t** d_noise_out) {
+    hipStream_t st = ctx->stream;
+    const int64_t cmax = n / 2 + 1;
+    int32_t *size = nullptr, *noise = nullptr;
+    unsigned long long* best = nullptr;
+    int64_t* rank = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_FIN, sizeof(int32_t) * (size_t)(n + cmax + 2), (void**)&size));
+    noise = size + cmax + 1;
+    FAL_TRY(ctx->reserve(SLOT_FIN2, sizeof(unsigned long long) * (size_t)(cmax + 1), (void**)&best));
+    FAL_TRY(ctx->reserve(SLOT_FIN3, sizeof(int64_t) * (size_t)(n + 1), (void**)&rank));
+    FAL_CHECK_HIP(hipMemsetAsync(size, 0, sizeof(int32_t) * (size_t)(cmax + 1), st));
+    FAL_CHECK_HIP(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * (size_t)(cmax + 1), st));
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
+    {
+        StageScope ts(ctx, ST_TAIL);
+        hipLaunchKernelGGL(cluster_size_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, size, row_order, noise);
+        hipLaunchKernelGGL(medoid_score_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, size, best);
+        FAL_TRY(device_scan_i32(ctx, noise, n, rank, SLOT_TAIL3));
+        hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, d_count, row_order, rank,
+                           best, labels_out, medoids_out);
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    *d_noise_out = rank + n;
+    return FAL_OK;
+}
+
 extern "C" {
 
 int fal_refine_clusters(fal_ctx* ctx, int32_t* labels, int64_t n, const float* precursor_mz_sorted,
@@ -369,46 +455,13 @@ int fal_refine_clusters(fal_ctx* ctx, int32_t* labels, int64_t n, const float* p
         return FAL_OK;
     }
     FAL_REQUIRE(labels && precursor_mz_sorted, FAL_EINVAL, "fal_refine_clusters: NULL array");
-    hipStream_t st = ctx->stream;
-    // sort rows by (label, row): stable radix sort on the label
-    uint32_t *keys = nullptr, *keys_s = nullptr;
-    int32_t *vals = nullptr, *rows = nullptr, *sub = nullptr, *n_sub = nullptr;
-    int64_t *seg = nullptr, *base = nullptr;
-    unsigned char* slab = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int32_t) * (size_t)n * 5 + 64, (void**)&keys));
-    keys_s = keys + n;
-    vals = reinterpret_cast<int32_t*>(keys + 2 * n);
-    rows = vals + n;
-    sub = rows + n;
-    FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(2 * (C + 2)) + sizeof(int32_t) * (size_t)(C + 2), (void**)&seg));
-    base = seg + (C + 2);
-    n_sub = reinterpret_cast<int32_t*>(base + (C + 2));
-    const size_t per = 4 * 11 + 8;   // 11 4-byte arrays + 1 double array
-    FAL_TRY(ctx->reserve(SLOT_TAIL4, per * (size_t)n + 256, (void**)&slab));
-    RefineScratch S;
-    S.zmd = reinterpret_cast<double*>(slab);
-    float* f = reinterpret_cast<float*>(slab + 8 * (size_t)n);
-    S.val = f;            S.smin = f + n;       S.smax = f + 2 * n;
-    int32_t* q = reinterpret_cast<int32_t*>(f + 3 * n);
-    S.ord = q;            S.sid = q + n;        S.zl = q + 2 * n;     S.zr = q + 3 * n;
-    S.t_a = q + 4 * n;    S.t_b = q + 5 * n;    S.stack = q + 6 * n;  S.visit = q + 7 * n;
-    const int grid = (int)std::min<int64_t>(ceil_div(n + 1, 256), (int64_t)ctx->num_cus * 16);
+    int64_t *d_in = nullptr, *d_out = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * 4, (void**)&d_in));
+    FAL_CHECK_HIP(hipMemcpyAsync(d_in, &C, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     ctx->stage_reset(ST_TAIL);
-    {
-        StageScope ts(ctx, ST_TAIL);
-        hipLaunchKernelGGL(label_keys_kernel, dim3(grid), dim3(256), 0, st, labels, n, (int32_t)C, keys, vals);
-        int bits = 1;
-        while ((1ll << bits) <= C) ++bits;
-        FAL_TRY(sort_pairs_u32_i32(ctx, keys, keys_s, vals, rows, n, bits, SLOT_TAIL3));
-        hipLaunchKernelGGL(seg_start_kernel, dim3(grid), dim3(256), 0, st, keys_s, n, (int32_t)C, seg);
-        hipLaunchKernelGGL(refine_kernel, dim3((unsigned)C), dim3(64), 0, st, rows, seg, precursor_mz_sorted,
-                           rt_tol >= 0.0 ? rt_sorted : nullptr, tol, tol_is_da, rt_tol, S, sub, n_sub);
-        FAL_TRY(device_scan_i32(ctx, n_sub, C, base, SLOT_TAIL3));
-        hipLaunchKernelGGL(relabel_kernel, dim3(grid), dim3(256), 0, st, rows, keys_s, n, (int32_t)C, sub, base, labels);
-    }
-    FAL_CHECK_HIP(hipGetLastError());
-    FAL_CHECK_HIP(hipMemcpyAsync(n_clusters, base + C, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    FAL_CHECK_HIP(hipStreamSynchronize(st));
+    FAL_TRY(refine_dev(ctx, labels, n, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol, d_in, &d_out));
+    FAL_CHECK_HIP(hipMemcpyAsync(n_clusters, d_out, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return FAL_OK;
 }
 
@@ -420,32 +473,43 @@ int fal_finalize(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, int64_t 
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(labels_sorted && row_order && nb_idx && nb_dist && labels_out && medoids_out, FAL_EINVAL,
                 "fal_finalize: NULL array");
-    hipStream_t st = ctx->stream;
-    int32_t *size = nullptr, *noise = nullptr;
-    unsigned long long* best = nullptr;
-    int64_t* rank = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int32_t) * (size_t)(n + n_clusters + 2), (void**)&size));
-    noise = size + n_clusters + 1;
-    FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(unsigned long long) * (size_t)(n_clusters + 1), (void**)&best));
-    FAL_TRY(ctx->reserve(SLOT_TAIL4, sizeof(int64_t) * (size_t)(n + 1), (void**)&rank));
-    FAL_CHECK_HIP(hipMemsetAsync(size, 0, sizeof(int32_t) * (size_t)(n_clusters + 1), st));
-    FAL_CHECK_HIP(hipMemsetAsync(best, 0xFF, sizeof(unsigned long long) * (size_t)(n_clusters + 1), st));
-    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
-    {
-        StageScope ts(ctx, ST_TAIL);
-        hipLaunchKernelGGL(cluster_size_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, size, row_order, noise);
-        hipLaunchKernelGGL(medoid_score_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, size, best);
-        FAL_TRY(device_scan_i32(ctx, noise, n, rank, SLOT_TAIL3));
-        hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, n_clusters, row_order, rank,
-                           best, labels_out, medoids_out);
-    }
-    FAL_CHECK_HIP(hipGetLastError());
+    int64_t *d_c = nullptr, *d_noise = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * 4, (void**)&d_c));
+    FAL_CHECK_HIP(hipMemcpyAsync(d_c, &n_clusters, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    FAL_TRY(finalize_dev(ctx, labels_sorted, n, d_c, row_order, nb_idx, nb_dist, k, labels_out, medoids_out, &d_noise));
     if (n_labels) {
         int64_t n_noise = 0;
-        FAL_CHECK_HIP(hipMemcpyAsync(&n_noise, rank + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        FAL_CHECK_HIP(hipStreamSynchronize(st));
+        FAL_CHECK_HIP(hipMemcpyAsync(&n_noise, d_noise, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         *n_labels = n_clusters + n_noise;
     }
+    return FAL_OK;
+}
+
+// a9 + a10 + a11 + a12 in one call with every intermediate count on the device: one host
+// synchronisation (for the two output counts) instead of three.
+int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps,
+                      const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
+                      double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
+                      int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+    FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX && n_clusters && n_labels, FAL_EINVAL,
+                "fal_cluster_graph: bad argument");
+    *n_clusters = *n_labels = 0;
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(nb_idx && nb_dist && precursor_mz_sorted && row_order && labels_sorted_scratch && labels_out && medoids_out,
+                FAL_EINVAL, "fal_cluster_graph: NULL array");
+    int64_t *d_db = nullptr, *d_cl = nullptr, *d_noise = nullptr;
+    ctx->stage_reset(ST_TAIL);
+    FAL_TRY(dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels_sorted_scratch, &d_db));
+    FAL_TRY(refine_dev(ctx, labels_sorted_scratch, n, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol, d_db, &d_cl));
+    FAL_TRY(finalize_dev(ctx, labels_sorted_scratch, n, d_cl, row_order, nb_idx, nb_dist, k, labels_out, medoids_out,
+                         &d_noise));
+    int64_t h[2] = {0, 0};
+    FAL_CHECK_HIP(hipMemcpyAsync(&h[0], d_cl, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FAL_CHECK_HIP(hipMemcpyAsync(&h[1], d_noise, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *n_clusters = h[0];
+    *n_labels = h[0] + h[1];
     return FAL_OK;
 }
 

@@ -8,4 +8,12 @@ int device_scan_i32(fal_ctx* ctx, const int32_t* in, int64_t n, int64_t* out, in
 // stable LSD radix sort of (uint32 key, int32 value) pairs on bits [0, end_bit)
 int sort_pairs_u32_i32(fal_ctx* ctx, const uint32_t* kin, uint32_t* kout, const int32_t* vin, int32_t* vout,
                        int64_t n, int end_bit, int scratch_slot);
+// a9 / a10 / a11+a12 with every count left on the device (graph.hip, tail.hip)
+int dbscan_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps, int32_t* labels,
+               int64_t** d_count_out);
+int refine_dev(fal_ctx* ctx, int32_t* labels, int64_t n, const float* mz, const float* rt, double tol, int is_da,
+               double rt_tol, const int64_t* d_count_in, int64_t** d_count_out);
+int finalize_dev(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, const int64_t* d_count,
+                 const int64_t* row_order, const int32_t* nb_idx, const float* nb_dist, int k, int32_t* labels_out,
+                 int32_t* medoids_out, int64_t** d_noise_out);
 }  // namespace fal

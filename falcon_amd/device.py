@@ -195,6 +195,22 @@ class Context:
         return labels, medoids[:int(nl.value)]
 
 
+    def cluster_graph(self, nb_idx, nb_dist, eps: float, mz_sorted, rt_sorted, tol: float, mode: str, rt_tol, order):
+        """a9..a12 fused: -> labels i32[n] (dataset rows), medoids i32[n_labels], labels_sorted, n_clusters"""
+        torch = _torch()
+        n, k = nb_idx.shape
+        lab_sorted = self.empty((n,), torch.int32)
+        labels = self.empty((n,), torch.int32)
+        medoids = self.empty((n,), torch.int32)
+        nc, nl = C.c_int64(), C.c_int64()
+        check(self.lib.fal_cluster_graph(self._h, self._p(nb_idx), self._p(nb_dist), n, k, float(eps),
+                                         self._p(mz_sorted), self._p(rt_sorted), float(tol), int(mode == "Da"),
+                                         -1.0 if rt_tol is None else float(rt_tol), self._p(order),
+                                         self._p(lab_sorted), self._p(labels), self._p(medoids), C.byref(nc),
+                                         C.byref(nl)), "fal_cluster_graph")
+        return labels, medoids[:int(nl.value)], lab_sorted, int(nc.value)
+
+
 class IvfIndex:
     """Opaque `fal_ivf` handle (keeps the vectors alive: the index borrows them)."""
 

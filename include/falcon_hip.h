@@ -162,6 +162,15 @@ int fal_finalize(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, int64_t 
                  const int64_t* row_order, const int32_t* nb_idx, const float* nb_dist, int k,
                  int32_t* labels_out, int32_t* medoids_out, int64_t* n_labels /*[host]*/);
 
+/* ---- a9 + a10 + a11 + a12 in one call (same kernels; all intermediate counts stay on the
+ *          device, a single host synchronisation at the end).  labels_sorted_scratch i32[n]
+ *          receives the refined labels in sorted-row space (-1 = noise). ------------- [dev] */
+int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k,
+                      float eps, const float* precursor_mz_sorted, const float* rt_sorted,
+                      double tol, int tol_is_da, double rt_tol, const int64_t* row_order,
+                      int32_t* labels_sorted_scratch, int32_t* labels_out, int32_t* medoids_out,
+                      int64_t* n_clusters /*[host]*/, int64_t* n_labels /*[host]*/);
+
 /* ---- sort by precursor m/z (reference cluster.py:73-85 `.sort_values`): stable.
  *          order_out i64[n] (dataset row of sorted position), mz_sorted_out f32[n]. [dev] */
 int fal_sort_by_precursor(fal_ctx* ctx, const float* precursor_mz, int64_t n,
