@@ -86,13 +86,15 @@ def main():
     ap.add_argument("--mz_interval", type=float, default=1.0)
     ap.add_argument("--exchange", choices=["neighbors", "labels", "none"], default="neighbors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the charge partitions on two host threads / two streams (PartitionRunner)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from falcon_amd import synth
     from falcon_amd import distributed as fdist
-    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, PartitionRunner, SpectrumDataset
     from falcon_amd.device import Context
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,6 +110,7 @@ def main():
 
     ctx = Context(local_rank)
     pipe = ClusterPipeline(ctx)
+    runner = PartitionRunner(local_rank, 2) if args.overlap else None
     p = AnnParams(eps=args.eps, low_dim=args.low_dim, n_probe=args.n_probe, n_neighbors=args.n_neighbors,
                   n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval)
 
@@ -130,32 +133,41 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    run_args = (20.0, "ppm", None, 0.05, args.batch_size, p)
+    keep_nb = args.exchange == "neighbors" and world > 1
+
     def step(collect=None):
+        """one pass of the hot path over this rank's shard; `collect` != None: serial, per-stage timing"""
+        if runner is not None and collect is None:
+            outs = runner.run(parts, *run_args, keep_intermediates=keep_nb)       # partitions overlap
+            lasts = [pp.last for pp in runner.last_pipes] if keep_nb else []
+        else:
+            outs, lasts = [], []
+            for ds in parts:
+                outs.append(pipe.run(ds, *run_args, keep_intermediates=keep_nb))
+                if keep_nb:
+                    lasts.append(dict(pipe.last))
+                if collect is not None:
+                    collect.append({k: ctx.stage_ms(k) for k in ("vectorize", "build", "coarse", "scan", "select",
+                                                                  "filter", "dbscan", "tail")}
+                                   | {"pairs": ctx.counter(0), "coarse_pairs": ctx.counter(1),
+                                      "scan_launches": ctx.counter(2), "sims_bytes": ctx.counter(3), "n": len(ds)})
         labels_all, current = [], 0
-        nb_all = []
-        for ds in parts:
-            labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, args.batch_size, p,
-                                       keep_intermediates=(args.exchange == "neighbors" and world > 1))
+        for labels, medoids in outs:
             labels_all.append(labels + current)                  # falcon.py:189-193
             current += int(medoids.numel())
-            if args.exchange == "neighbors" and world > 1:
-                nb_all.append((pipe.last["nb_idx"], pipe.last["nb_dist"], pipe.last["order"]))
-                pipe.last["index"].close()
-            if collect is not None:
-                collect.append({k: ctx.stage_ms(k) for k in ("vectorize", "build", "coarse", "scan", "select",
-                                                              "filter", "dbscan", "tail")}
-                               | {"pairs": ctx.counter(0), "coarse_pairs": ctx.counter(1),
-                                  "scan_launches": ctx.counter(2), "sims_bytes": ctx.counter(3), "n": len(ds)})
         labels = torch.cat(labels_all)
         if world > 1 and args.exchange != "none":
             if args.exchange == "neighbors":
                 # one all-gatherv of the sparse neighbour lists (ids -> global sorted rows of the job)
                 off = row_offset
                 gi, gd = [], []
-                for nb_idx, nb_dist, _ in nb_all:
+                for last in lasts:
+                    nb_idx, nb_dist = last["nb_idx"], last["nb_dist"]
                     gi.append(torch.where(nb_idx >= 0, nb_idx + off, nb_idx))
                     gd.append(nb_dist)
                     off += nb_idx.shape[0]
+                    last["index"].close()
                 g_idx, counts = fdist.allgatherv_rows(torch.cat(gi))
                 g_dist, _ = fdist.allgatherv_rows(torch.cat(gd), counts)
                 del g_idx, g_dist
@@ -210,6 +222,7 @@ def main():
                                    f"n_probe={args.n_probe}, eps={args.eps}, precursor_tol=20ppm, "
                                    f"mz_interval={args.mz_interval}, batch_size={args.batch_size}",
                        "exchange": args.exchange if world > 1 else "none",
+                       "partitions": "2 host threads / 2 streams" if args.overlap else "serial",
                        "parallelism": f"bucket-sharded x{world}"},
             "roofline": {"kernel": "dense_kernel<.,STORE> / ivf_fine_kernel (cosine scan, fp32 MFMA 32x32x2)",
                          "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,

@@ -128,6 +128,54 @@ class ClusterPipeline:
         return labels, medoids
 
 
+class PartitionRunner:
+    """Runs independent partitions (precursor charges, falcon.py:151-160) concurrently: one host
+    thread + one HIP stream + one `fal_ctx` per partition slot, the way the reference clusters its
+    blocks on a thread pool (cluster.py:115-136).  The GPU interleaves the streams, so the host
+    planning / synchronisation gaps of one partition hide under the kernels of the other."""
+
+    def __init__(self, device: int = 0, n_slots: int = 2):
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        self.device, self.n_slots = device, n_slots
+        self._tls = threading.local()
+        self._pool = ThreadPoolExecutor(max_workers=n_slots, thread_name_prefix="falcon-part")
+        self.pipelines = []
+        self._lock = threading.Lock()
+
+    def _pipeline(self):
+        import torch
+        if not hasattr(self._tls, "pipe"):
+            torch.cuda.set_device(self.device)
+            self._tls.stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._tls.stream):
+                self._tls.pipe = ClusterPipeline(device=self.device)      # binds the ctx to this stream
+            with self._lock:
+                self.pipelines.append(self._tls.pipe)
+        return self._tls.pipe, self._tls.stream
+
+    def _run_one(self, ds, args, kwargs):
+        import torch
+        pipe, stream = self._pipeline()
+        with torch.cuda.stream(stream):
+            out = pipe.run(ds, *args, **kwargs)
+            stream.synchronize()
+        return out, pipe
+
+    def run(self, datasets, *args, **kwargs):
+        """-> [(labels, medoids), ...] in the order of `datasets` (largest partition is started first)."""
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()      # inputs produced on the caller's stream
+        order = sorted(range(len(datasets)), key=lambda i: -len(datasets[i]))
+        futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs) for i in order}
+        res = [futs[i].result() for i in range(len(datasets))]
+        self.last_pipes = [r[1] for r in res]
+        return [r[0] for r in res]
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+
+
 _default_pipeline: Optional[ClusterPipeline] = None
 
 

@@ -63,16 +63,25 @@ __device__ __forceinline__ bool edge_ok(int32_t j, float dist, int64_t i, float 
     return j >= 0 && (int64_t)j != i && dist <= eps;
 }
 
-// core(i) <=> row i stores a neighbour within eps (the point itself is the other sample)
-__global__ void dbscan_core_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist, int64_t n,
-                                   int k, float eps, int32_t* __restrict__ core, int32_t* __restrict__ parent,
-                                   int32_t* __restrict__ border_src) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+// core(i) <=> row i stores a neighbour within eps (the point itself is the other sample).
+// One wave per row: 64 consecutive slots per load (coalesced), any() by ballot.
+__global__ __launch_bounds__(256) void dbscan_core_kernel(const int32_t* __restrict__ nb_idx,
+                                                          const float* __restrict__ nb_dist, int64_t n, int k,
+                                                          float eps, int32_t* __restrict__ core,
+                                                          int32_t* __restrict__ parent, int32_t* __restrict__ border_src) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
         bool c = false;
-        for (int s = 0; s < k && !c; ++s) c = edge_ok(nb_idx[i * k + s], nb_dist[i * k + s], i, eps);
-        core[i] = c;
-        parent[i] = (int32_t)i;
-        border_src[i] = 0x7fffffff;
+        for (int s0 = 0; s0 < k && !c; s0 += 64) {
+            const int s = s0 + lane;
+            const bool ok = s < k && edge_ok(nb_idx[i * k + s], nb_dist[i * k + s], i, eps);
+            c = __ballot(ok) != 0;
+        }
+        if (lane == 0) {
+            core[i] = c;
+            parent[i] = (int32_t)i;
+            border_src[i] = 0x7fffffff;
+        }
     }
 }
 
@@ -176,7 +185,7 @@ int fal::dbscan_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, i
     ctx->stage_reset(ST_DBSCAN);
     {
         StageScope ts(ctx, ST_DBSCAN);
-        hipLaunchKernelGGL(dbscan_core_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent, border);
+        hipLaunchKernelGGL(dbscan_core_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64)), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent, border);
         hipLaunchKernelGGL(dbscan_edges_kernel, dim3(egrid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent, border);
         hipLaunchKernelGGL(dbscan_roots_kernel, dim3(grid), dim3(256), 0, ctx->stream, core, parent, n, is_root);
         FAL_TRY(device_scan_i32(ctx, is_root, n, rank, SLOT_DB3));

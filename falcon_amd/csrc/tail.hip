@@ -328,24 +328,41 @@ __global__ void cluster_size_kernel(const int32_t* __restrict__ labels, int64_t 
 // score_i = sum (float32, stored order) of dist to stored same-cluster neighbours + 1.0 per
 // member the row does not store (cluster.py:536-550 on the sparse graph); argmin per cluster
 // with ties to the lowest row, via a 64-bit atomic min of (score bits, row).
-__global__ void medoid_score_kernel(const int32_t* __restrict__ labels, int64_t n, const int32_t* __restrict__ nb_idx,
-                                    const float* __restrict__ nb_dist, int k, const int32_t* __restrict__ size,
-                                    unsigned long long* __restrict__ best) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void medoid_score_kernel(const int32_t* __restrict__ labels, int64_t n,
+                                                           const int32_t* __restrict__ nb_idx,
+                                                           const float* __restrict__ nb_dist, int k,
+                                                           const int32_t* __restrict__ size,
+                                                           unsigned long long* __restrict__ best) {
+    // one wave per row: coalesced row read, same-cluster slots found by ballot, then their
+    // distances added ONE BY ONE in slot order (float32) so the sum equals the oracle's
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = blockIdx.x * 4ll + (threadIdx.x >> 6); i < n; i += (int64_t)gridDim.x * 4) {
         const int32_t l = labels[i];
         if (l < 0) continue;
         float s = 0.f;
         int same = 0;
-        for (int c = 0; c < k; ++c) {
-            const int32_t j = nb_idx[i * k + c];
-            if (j >= 0 && (int64_t)j != i && labels[j] == l) {
-                s += nb_dist[i * k + c];
-                ++same;
+        for (int c0 = 0; c0 < k; c0 += 64) {
+            const int c = c0 + lane;
+            int32_t j = -1;
+            float dv = 0.f;
+            if (c < k) {
+                j = nb_idx[i * k + c];
+                dv = nb_dist[i * k + c];
+            }
+            const bool in = j >= 0 && (int64_t)j != i && labels[j] == l;
+            uint64_t mask = __ballot(in);
+            same += __popcll(mask);
+            while (mask) {
+                const int b = __ffsll((unsigned long long)mask) - 1;
+                mask &= mask - 1;
+                s += __shfl(dv, b, 64);
             }
         }
-        s += (float)(size[l] - 1 - same);
-        const unsigned long long key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(uint32_t)i;
-        atomicMin(&best[l], key);
+        if (lane == 0) {
+            s += (float)(size[l] - 1 - same);
+            const unsigned long long key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(uint32_t)i;
+            atomicMin(&best[l], key);
+        }
     }
 }
 
@@ -433,7 +450,7 @@ int fal::finalize_dev(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, con
     {
         StageScope ts(ctx, ST_TAIL);
         hipLaunchKernelGGL(cluster_size_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, size, row_order, noise);
-        hipLaunchKernelGGL(medoid_score_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, size, best);
+        hipLaunchKernelGGL(medoid_score_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64)), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, size, best);
         FAL_TRY(device_scan_i32(ctx, noise, n, rank, SLOT_TAIL3));
         hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, d_count, row_order, rank,
                            best, labels_out, medoids_out);
