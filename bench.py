@@ -71,6 +71,22 @@ def cpu_baseline(data, params, seconds_target=20.0):
                       f"{dt:.1f} s"}
 
 
+def pmc_traffic(args):
+    """HBM bytes per scan launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2
+    + WRITE_SIZE, collected in separate passes as MI355X_MICROARCH.md prescribes).  Counters cannot be
+    read from inside the run, so the figure is only reported for the workload it was measured on."""
+    fn = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic_per_step.json")
+    default = (args.spectra == 1_000_000 and args.low_dim == 400 and args.n_neighbors_ann == 128
+               and args.mz_interval == 1.0 and args.batch_size == 2 ** 15)
+    if not default or not os.path.isfile(fn):
+        return None
+    try:
+        with open(fn) as f:
+            return float(json.load(f)["scan"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,7 +242,9 @@ def main():
                        "parallelism": f"bucket-sharded x{world}"},
             "roofline": {"kernel": "dense_kernel<.,STORE> / ivf_fine_kernel (cosine scan, fp32 MFMA 32x32x2)",
                          "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(args),
+                         "traffic_unit": "HBM bytes per launch (PMC, profiles/r1_pmc_hbm_traffic_per_step.json)",
+                         "flops_per_launch": flops / max(scan_launches, 1),
                          "launches": scan_launches, "avg_launch_ms": scan_ms / max(scan_launches, 1),
                          "pairs_per_step": pairs},
             "roofline_hbm": {"kernel": "cosine scan", "bound": "hbm",
