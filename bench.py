@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0            # ... "HBM3E peak BW 8.0 TB/s spec"
+PEAK_MFMA_F16_TFLOPS = 2500.0    # ... "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def cpu_baseline(data, params, seconds_target=20.0):
@@ -45,7 +46,7 @@ def cpu_baseline(data, params, seconds_target=20.0):
     c2 = synth.select_charge(data, 2)
     pm = c2["precursor_mz"]
     lo = 600.0
-    width = 16.0
+    width = 200.0          # ~175k spectra: 10-30 s of single-thread numpy
     sel = np.flatnonzero((pm >= lo) & (pm < lo + width))
     if len(sel) < 256:
         sel = np.arange(min(len(pm), 20000))
@@ -101,6 +102,9 @@ def main():
     ap.add_argument("--batch_size", type=int, default=2 ** 15)
     ap.add_argument("--mz_interval", type=float, default=1.0)
     ap.add_argument("--exchange", choices=["neighbors", "labels", "none"], default="neighbors")
+    ap.add_argument("--scan", choices=["f32", "f16x3"], default="f32",
+                    help="flat-scan arithmetic: exact fp32 MFMA (default) or hi/lo float16 split on the f16 MFMA")
+    ap.add_argument("--dtype", choices=["f32", "f16"], default="f32", help="vector dtype (f16 = BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="run the charge partitions on two host threads / two streams (PartitionRunner)")
@@ -128,7 +132,7 @@ def main():
     pipe = ClusterPipeline(ctx)
     runner = PartitionRunner(local_rank, 2) if args.overlap else None
     p = AnnParams(eps=args.eps, low_dim=args.low_dim, n_probe=args.n_probe, n_neighbors=args.n_neighbors,
-                  n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval)
+                  n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval, scan=args.scan, dtype=args.dtype)
 
     # ---- this rank's shard: its own generator blocks, resident in HBM ------------------------
     blocks_per_rank = (args.spectra + synth.BLOCK - 1) // synth.BLOCK
@@ -220,6 +224,22 @@ def main():
         algo_bytes = n_rows * (2 * d * 4 + 8 * args.n_neighbors_ann)          # SURVEY 8(d) compulsory bytes
         stage_ms = {k: round(sum(s[k][0] for s in stages), 3) for k in
                     ("vectorize", "build", "coarse", "scan", "select", "filter", "dbscan", "tail")}
+        f16_path = args.scan == "f16x3" or args.dtype == "f16"
+        elem = 2 if args.dtype == "f16" else 4
+        algo_bytes = n_rows * (2 * d * elem + 8 * args.n_neighbors_ann)
+        hbm_gbs = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        if f16_path:
+            # issued matrix work: 3 f16 MFMAs per k-step for the split, 1 for plain float16 rows
+            issued_tf = achieved_tf * (3 if args.scan == "f16x3" and args.dtype == "f32" else 1)
+            mfma_frac, hbm_frac = issued_tf / PEAK_MFMA_F16_TFLOPS, hbm_gbs / PEAK_HBM_GBS
+            if hbm_frac >= mfma_frac:
+                roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac}
+            else:
+                roof = {"bound": "mfma", "achieved": issued_tf, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": mfma_frac}
+            roof.update({"kernel": "scan16_kernel (f16 MFMA 32x32x16, LDS-staged) + dense_kernel for buckets < 64",
+                         "traffic": None, "mfma_f16_frac": mfma_frac, "hbm_frac": hbm_frac,
+                         "algorithmic_tflops": achieved_tf})
         out = {
             "metric": "spectra clustered/sec @1/2/4/8 GPU; cosine-kernel HBM GB/s vs roofline",
             "value": n_local * world * args.steps / dt,
@@ -231,7 +251,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f16" if args.dtype == "f16" else "f16x3 (f32 vectors as hi/lo float16, f32 accumulate)"
+                      if args.scan == "f16x3" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"{args.spectra} synthetic spectra per GPU (charges 2+3), low_dim={d}, "
                                    f"n_neighbors={args.n_neighbors}, n_neighbors_ann={args.n_neighbors_ann}, "
@@ -254,6 +275,10 @@ def main():
                              "algorithmic_bytes": algo_bytes},
             "stage_ms": stage_ms,
         }
+        if f16_path:
+            roof.update({"launches": scan_launches, "avg_launch_ms": scan_ms / max(scan_launches, 1),
+                         "pairs_per_step": pairs})
+            out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, p)
         print(json.dumps(out))

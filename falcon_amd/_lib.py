@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfalcon_hip.so")
 
-FAL_DTYPE_F32, FAL_DTYPE_F16 = 0, 1
+FAL_DTYPE_F32, FAL_DTYPE_F16, FAL_DTYPE_SPLIT16 = 0, 1, 2
 STAGES = {"vectorize": 0, "build": 1, "coarse": 2, "scan": 3, "select": 4, "filter": 5, "dbscan": 6, "tail": 7}
 
 
@@ -43,6 +43,7 @@ _SIGNATURES = {
     "fal_precursor_splits": ([c_void_p, c_void_p, c_int64, c_double, c_int, c_int64, c_double, c_int,
                               c_void_p, c_int64, P(c_int64)], c_int),
     "fal_ivf_build": ([c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, P(c_void_p)], c_int),
+    "fal_ivf_attach_f16": ([c_void_p, c_void_p, c_int], c_int),
     "fal_ivf_destroy": ([c_void_p], c_int),
     "fal_ivf_total_lists": ([c_void_p, P(c_int64)], c_int),
     "fal_ivf_export": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),

@@ -37,7 +37,9 @@ class AnnParams:
     hash_seed: int = 0
     min_mz: float = 101.0
     max_mz: float = 1500.0
-    dtype: str = "f32"
+    dtype: str = "f32"            # "f32", or "f16": float16 vectors + f16 MFMA scan (BASELINE config 5)
+    scan: str = "f32"             # flat-bucket scan arithmetic for float32 vectors: "f32" (exact fp32 MFMA) or
+                                  # "f16x3" (hi/lo float16 split, 3 f16 MFMAs per step, ~3e-7 absolute error)
 
 
 def n_list_rule(sizes: np.ndarray, n_probe: int) -> np.ndarray:
@@ -104,17 +106,30 @@ class ClusterPipeline:
         order, mzs = c.sort_by_precursor(pmz)                                      # cluster.py:73-85
         rts = c.gather_f32(ds.retention_time, order) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
-        X = c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
-                        p.hash_seed, True, "f32")
         n_list = n_list_rule(np.diff(splits), p.n_probe)
-        index = c.ivf_build(X, splits, n_list, p.kmeans_iters)
+        all_flat = bool((n_list == 1).all())
+        vec = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
+                                     p.hash_seed, True, dt)
+        X = X16 = None
+        if p.dtype == "f16":
+            if not all_flat:
+                raise _device.FalconHipError("dtype='f16' supports flat buckets only in this build "
+                                             "(a bucket needs an IVF index: lower batch_size / mz_interval)")
+            X16 = vec("f16")
+        elif p.scan == "f16x3":
+            X16 = vec("split16")
+            if not all_flat:
+                X = vec("f32")              # k-means, coarse quantiser and IVF fine scan stay exact fp32
+        else:
+            X = vec("f32")
+        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16)
         sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
         nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
                                              p.n_neighbors)
         if keep_intermediates:
             # staged calls (one C-ABI call per SURVEY 8a row) so that every intermediate can be inspected
             db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)
-            self.last = dict(order=order, mz_sorted=mzs, rt_sorted=rts, splits=splits, X=X, n_list=n_list,
+            self.last = dict(order=order, mz_sorted=mzs, rt_sorted=rts, splits=splits, X=X, X16=X16, n_list=n_list,
                              sim=sim, idx=idx, nb_idx=nb_idx, nb_dist=nb_dist, db=db.clone(), n_db=n_db, index=index)
             lab, n_cl = c.refine_clusters(db, n_db, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol)
             self.last.update(lab_sorted=lab, n_clusters=n_cl)

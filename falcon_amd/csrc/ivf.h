@@ -20,6 +20,8 @@ struct fal_ivf {
     const float* X = nullptr;        // caller's vectors, precursor-sorted rows (borrowed)
     const float* Xl = nullptr;       // the same rows in (bucket, list, row) order (== X when all flat)
     float* Xl_owned = nullptr;
+    const void* X16 = nullptr;       // optional f16 rows (sorted order) for the flat scan: [n, planes, d]
+    int x16_planes = 0;
     std::vector<int64_t> bucket_off; // host, n_buckets + 1
     std::vector<int32_t> n_list;     // host, per bucket
     std::vector<int64_t> list_base;  // host, global id of each bucket's list 0

@@ -200,6 +200,20 @@ int fal_ivf_destroy(fal_ivf* ivf) {
     return FAL_OK;
 }
 
+int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes) {
+    FAL_REQUIRE(ivf && X16 && (planes == 1 || planes == 2), FAL_EINVAL, "fal_ivf_attach_f16: bad argument");
+    {
+        const int d = ivf->d;
+        const bool ok = planes == 2 ? (d == 64 || d == 128 || d == 256 || d == 400)
+                                    : (d == 64 || d == 128 || d == 256 || d == 400 || d == 512 || d == 800);
+        FAL_REQUIRE(ok, FAL_EUNSUPPORTED, "fal_ivf_attach_f16: low_dim %d with %d plane(s) is not instantiated "
+                    "(planes 1: 64/128/256/400/512/800, planes 2: 64/128/256/400)", d, planes);
+    }
+    ivf->X16 = X16;
+    ivf->x16_planes = planes;
+    return FAL_OK;
+}
+
 int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists) {
     FAL_REQUIRE(ivf && total_lists, FAL_EINVAL, "fal_ivf_total_lists: NULL");
     *total_lists = ivf->total_lists;
@@ -215,7 +229,11 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
                 "fal_ivf_build: low_dim must be a multiple of 8 in [8, %d]", FAL_MAX_LOW_DIM);
     FAL_REQUIRE(n_buckets >= 0 && (n_buckets == 0 || (bucket_off && n_list)), FAL_EINVAL, "fal_ivf_build: NULL bucket arrays");
     FAL_REQUIRE(kmeans_iters >= 0, FAL_EINVAL, "fal_ivf_build: kmeans_iters < 0");
-    FAL_REQUIRE(n == 0 || X, FAL_EINVAL, "fal_ivf_build: NULL X");
+    {
+        bool any_ivf = false;
+        for (int64_t b = 0; b < n_buckets; ++b) any_ivf |= n_list[b] > 1;
+        FAL_REQUIRE(n == 0 || X || !any_ivf, FAL_EINVAL, "fal_ivf_build: X may only be NULL when every bucket is flat");
+    }
     if (n_buckets > 0) {
         FAL_REQUIRE(bucket_off[0] == 0 && bucket_off[n_buckets] == n, FAL_EINVAL,
                     "fal_ivf_build: bucket_off must start at 0 and end at n");

@@ -51,5 +51,10 @@ int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* 
                  int64_t xcd_list_tiles = 0);
 int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks);
 int launch_fine(fal_ctx* ctx, const FineArgs& a);
+// f16-MFMA flat scan (scan16.hip): jobs sorted by decreasing size, xtile0 = 128-query tiles of earlier
+// jobs of the same XCD list; list_tiles = longest list.  planes = 1 (f16 rows) or 2 (hi/lo split).
+// sink: >= 64 floats of scratch that idle waves store to.
+int launch_scan16(fal_ctx* ctx, int planes, const void* Xs, int d, const DenseJob* jobs, int n_jobs, int64_t list_tiles,
+                  float* sims, int64_t sims_base, float* sink);
 
 }  // namespace fal

@@ -73,29 +73,45 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         return ivf->bucket_off[x + 1] - ivf->bucket_off[x] > ivf->bucket_off[y + 1] - ivf->bucket_off[y];
     });
     std::vector<DenseJob> flat, coarse;    // coarse doubles as the IVF tile table
-    struct FlatBatch { size_t j0, j1; int64_t tiles, list_tiles, floats; };
+    // a batch = jobs [j0, j1): [j0, jm) go to the f16-MFMA kernel (128-query tiles), [jm, j1) to the fp32 one
+    struct FlatBatch { size_t j0, jm, j1; int64_t tiles, list_tiles16, list_tiles32, floats; };
     std::vector<FlatBatch> flat_batches;
     size_t need_flat = 0;
+    const bool have16 = ivf->X16 != nullptr;
+    const int64_t thr16 = ivf->X ? 64 : 0;           // without float32 rows everything takes the f16 kernel
+    FAL_REQUIRE(have16 || ivf->X || border.empty(), FAL_EINVAL, "fal_ivf_search_topk: the index has no vectors to scan");
     {
-        FlatBatch cur{0, 0, 0, 0, 0};
-        int64_t xt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        FlatBatch cur{0, 0, 0, 0, 0, 0, 0};
+        int64_t xt16[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         auto close = [&]() {
             if (cur.j1 > cur.j0) {
-                cur.list_tiles = *std::max_element(xt, xt + 8);
+                cur.list_tiles16 = *std::max_element(xt16, xt16 + 8);
+                cur.list_tiles32 = *std::max_element(xt32, xt32 + 8);
                 flat_batches.push_back(cur);
                 need_flat = std::max(need_flat, (size_t)cur.floats);
             }
-            cur = FlatBatch{cur.j1, cur.j1, 0, 0, 0};
-            std::fill(xt, xt + 8, 0);
+            cur = FlatBatch{cur.j1, cur.j1, cur.j1, 0, 0, 0, 0};
+            std::fill(xt16, xt16 + 8, 0);
+            std::fill(xt32, xt32 + 8, 0);
         };
         for (int64_t b : border) {
             const int64_t row0 = ivf->bucket_off[b], nb = ivf->bucket_off[b + 1] - row0;
             const int64_t tiles = ceil_div(nb, 32), floats = tiles * 32 * ((nb + 31) & ~31ll);
             if (cur.floats + floats > (int64_t)cap && cur.j1 > cur.j0) close();
-            const int x = (int)((cur.j1 - cur.j0) & 7);
+            const bool use16 = have16 && nb >= thr16;      // sizes are non-increasing: the f16 part is a prefix
+            int64_t xtile0;
+            if (use16) {
+                const int x = (int)((cur.j1 - cur.j0) & 7);
+                xtile0 = xt16[x];
+                xt16[x] += ceil_div(nb, 128);
+                cur.jm = cur.j1 + 1;
+            } else {
+                const int x = (int)((cur.j1 - cur.jm) & 7);
+                xtile0 = xt32[x];
+                xt32[x] += tiles;
+            }
             // obase / tile0 / xtile0 are relative to the batch
-            flat.push_back({row0, row0, cur.floats, cur.tiles, (int32_t)nb, (int32_t)nb, xt[x]});
-            xt[x] += tiles;
+            flat.push_back({row0, row0, cur.floats, cur.tiles, (int32_t)nb, (int32_t)nb, xtile0});
             cur.tiles += tiles;
             cur.floats += floats;
             cur.j1++;
@@ -160,14 +176,19 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         FAL_CHECK_HIP(hipMemcpyAsync(coarse_dev, coarse.data(), sizeof(DenseJob) * coarse.size(), hipMemcpyHostToDevice, st));
     }
     float* sims = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * std::max(need_flat, need_coarse), (void**)&sims));
+    const size_t sims_floats = std::max(need_flat, need_coarse);
+    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (sims_floats + 64), (void**)&sims));   // + sink for scan16
 
     // ---- A. flat buckets ---------------------------------------------------------------------
     for (const FlatBatch& fb : flat_batches) {
         const DenseJob* jb = flat_dev + fb.j0;
         const int nj = (int)(fb.j1 - fb.j0);
-        FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->Xl, ivf->Xl, d, jb, nj, 0, fb.tiles, sims, 0, nullptr,
-                             fb.list_tiles));
+        if (fb.jm > fb.j0)
+            FAL_TRY(launch_scan16(ctx, ivf->x16_planes, ivf->X16, d, jb, (int)(fb.jm - fb.j0), fb.list_tiles16, sims, 0,
+                                  sims + sims_floats));
+        if (fb.j1 > fb.jm)
+            FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->Xl, ivf->Xl, d, flat_dev + fb.jm, (int)(fb.j1 - fb.jm), 0,
+                                 fb.tiles, sims, 0, nullptr, fb.list_tiles32));
         SelectArgs sa{};
         sa.sims = sims; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = jb; sa.n_jobs = nj; sa.tile_begin = 0; sa.ids_are_rows = 1;

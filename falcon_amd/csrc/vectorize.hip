@@ -107,7 +107,22 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
             const uint32_t e = 256 * p + 4 * lane;
             if ((uint32_t)p < passes && e < d) {
                 float4 o = make_float4(v[p].x * inv, v[p].y * inv, v[p].z * inv, v[p].w * inv);
-                if (OUT_F16) {
+                if (OUT_F16 == 2) {
+                    // hi/lo split of the float32 value: x ~= hi + lo / 2048 to ~2^-22 relative
+                    const __half h0 = __float2half_rn(o.x), h1 = __float2half_rn(o.y), h2 = __float2half_rn(o.z),
+                                 h3 = __float2half_rn(o.w);
+                    const __half2 ha = __halves2half2(h0, h1), hb = __halves2half2(h2, h3);
+                    const __half2 la = __floats2half2_rn((o.x - __half2float(h0)) * 2048.f, (o.y - __half2float(h1)) * 2048.f);
+                    const __half2 lb = __floats2half2_rn((o.z - __half2float(h2)) * 2048.f, (o.w - __half2float(h3)) * 2048.f);
+                    uint2 ph, pl;
+                    ph.x = *reinterpret_cast<const uint32_t*>(&ha);
+                    ph.y = *reinterpret_cast<const uint32_t*>(&hb);
+                    pl.x = *reinterpret_cast<const uint32_t*>(&la);
+                    pl.y = *reinterpret_cast<const uint32_t*>(&lb);
+                    __half* rowp = reinterpret_cast<__half*>(out) + r * (int64_t)(2 * d);
+                    *reinterpret_cast<uint2*>(rowp + e) = ph;
+                    *reinterpret_cast<uint2*>(rowp + d + e) = pl;
+                } else if (OUT_F16) {
                     __half2 a = __floats2half2_rn(o.x, o.y), b = __floats2half2_rn(o.z, o.w);
                     uint2 pk;
                     pk.x = *reinterpret_cast<uint32_t*>(&a);
@@ -151,7 +166,8 @@ int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const i
     FAL_REQUIRE(n >= 0 && bin_size > 0 && n_bins > 0, FAL_EINVAL, "fal_vectorize: bad sizes");
     FAL_REQUIRE(low_dim >= 8 && low_dim <= FAL_MAX_LOW_DIM && low_dim % 8 == 0, FAL_EUNSUPPORTED,
                 "fal_vectorize: low_dim must be a multiple of 8 in [8, %d] (got %u)", FAL_MAX_LOW_DIM, low_dim);
-    FAL_REQUIRE(out_dtype == FAL_DTYPE_F32 || out_dtype == FAL_DTYPE_F16, FAL_EINVAL, "fal_vectorize: bad out_dtype");
+    FAL_REQUIRE(out_dtype == FAL_DTYPE_F32 || out_dtype == FAL_DTYPE_F16 || out_dtype == FAL_DTYPE_SPLIT16, FAL_EINVAL,
+                "fal_vectorize: bad out_dtype");
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(indptr && out, FAL_EINVAL, "fal_vectorize: NULL array");
     ctx->stage_reset(fal::ST_VECTORIZE);
@@ -160,7 +176,10 @@ int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const i
     const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 32);
     {
         fal::StageScope t(ctx, fal::ST_VECTORIZE);
-        if (out_dtype == FAL_DTYPE_F16)
+        if (out_dtype == FAL_DTYPE_SPLIT16)
+            hipLaunchKernelGGL(vectorize_kernel<2>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out);
+        else if (out_dtype == FAL_DTYPE_F16)
             hipLaunchKernelGGL(vectorize_kernel<1>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
                                row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out);
         else

@@ -99,25 +99,42 @@ class Context:
         row_order = None if row_order is None else self.to_dev(row_order, torch.int64)
         n = indptr.numel() - 1
         f16 = dtype in ("f16", "float16")
-        out = self.empty((n, low_dim), torch.float16 if f16 else torch.float32)
+        split = dtype == "split16"
+        if split:
+            out, code = self.empty((n, 2, low_dim), torch.float16), _lib.FAL_DTYPE_SPLIT16
+        else:
+            out = self.empty((n, low_dim), torch.float16 if f16 else torch.float32)
+            code = _lib.FAL_DTYPE_F16 if f16 else _lib.FAL_DTYPE_F32
         check(self.lib.fal_vectorize(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
                                      n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
-                                     int(normalize), _lib.FAL_DTYPE_F16 if f16 else _lib.FAL_DTYPE_F32,
-                                     self._p(out)), "fal_vectorize")
+                                     int(normalize), code, self._p(out)), "fal_vectorize")
         return out
 
 
     # ------------------------------------------------------------------ a6 / a7
-    def ivf_build(self, X, bucket_off: np.ndarray, n_list: np.ndarray, kmeans_iters: int = 10) -> "IvfIndex":
+    def ivf_build(self, X, bucket_off: np.ndarray, n_list: np.ndarray, kmeans_iters: int = 10,
+                  X16=None) -> "IvfIndex":
+        """X: float32 [n, d] (may be None when every bucket is flat and X16 is given);
+        X16: optional float16 [n, d] (plain rows) or [n, 2, d] (hi/lo split) for the f16 flat scan."""
         torch = _torch()
-        assert X.dtype == torch.float32 and X.is_contiguous() and X.device == self.tdev
-        n, d = X.shape
+        if X is not None:
+            assert X.dtype == torch.float32 and X.is_contiguous() and X.device == self.tdev
+            n, d = X.shape
+        else:
+            assert X16 is not None
+            n, d = X16.shape[0], X16.shape[-1]
         bo = np.ascontiguousarray(bucket_off, np.int64)
         nl = np.ascontiguousarray(n_list, np.int32)
         h = C.c_void_p()
         check(self.lib.fal_ivf_build(self._h, self._p(X), n, d, bo.ctypes.data_as(C.c_void_p), len(nl),
                                      nl.ctypes.data_as(C.c_void_p), int(kmeans_iters), C.byref(h)), "fal_ivf_build")
-        return IvfIndex(self, h, X, bo, nl)
+        index = IvfIndex(self, h, X, bo, nl, n, d)
+        if X16 is not None:
+            assert X16.dtype == torch.float16 and X16.is_contiguous() and X16.device == self.tdev
+            planes = 2 if X16.dim() == 3 else 1
+            check(self.lib.fal_ivf_attach_f16(h, self._p(X16), planes), "fal_ivf_attach_f16")
+            index.X16 = X16
+        return index
 
 
     # ------------------------------------------------------------------ sort / a5
@@ -214,10 +231,10 @@ class Context:
 class IvfIndex:
     """Opaque `fal_ivf` handle (keeps the vectors alive: the index borrows them)."""
 
-    def __init__(self, ctx: Context, handle, X, bucket_off, n_list):
-        self.ctx, self._h, self.X = ctx, handle, X
+    def __init__(self, ctx: Context, handle, X, bucket_off, n_list, n, d):
+        self.ctx, self._h, self.X, self.X16 = ctx, handle, X, None
         self.bucket_off, self.n_list = bucket_off, n_list
-        self.n, self.d = X.shape
+        self.n, self.d = n, d
         t = C.c_int64()
         check(ctx.lib.fal_ivf_total_lists(self._h, C.byref(t)))
         self.total_lists = int(t.value)

@@ -38,6 +38,7 @@ extern "C" {
 
 #define FAL_DTYPE_F32 0
 #define FAL_DTYPE_F16 1
+#define FAL_DTYPE_SPLIT16 2   /* per row: low_dim f16 'hi' = f16(x), then low_dim f16 'lo' = f16((x - hi) * 2048) */
 
 #define FAL_MAX_LOW_DIM   1024     /* multiple of 8 */
 #define FAL_MAX_K_ANN      256
@@ -86,8 +87,9 @@ int fal_to_vector_indices(fal_ctx* ctx, const float* mz, int64_t nnz,
 /* ---- a2+a3  CSR peaks -> dense low_dim vectors, L2-normalised: reference
  *          spectrum.py:202-247 `to_vector` with the projection realised as feature
  *          hashing.  Row r of `out` is spectrum row_order[r] (row_order may be NULL).
- *          out: [n, low_dim] float32 or float16 (out_dtype).  Peaks whose bin lies
- *          outside [0, n_bins) are ignored; an all-zero row stays zero. ---------- [dev] */
+ *          out: [n, low_dim] float32 or float16, or [n, 2, low_dim] float16 hi/lo planes of the
+ *          float32 result (out_dtype, FAL_DTYPE_*).  Peaks whose bin lies outside [0, n_bins)
+ *          are ignored; an all-zero row stays zero. ------------------------------- [dev] */
 int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity,
                   const int64_t* indptr, const int64_t* row_order, int64_t n,
                   double min_mz, double bin_size, uint32_t n_bins,
@@ -113,6 +115,12 @@ int fal_precursor_splits(fal_ctx* ctx, const float* precursor_mz_sorted /*[dev]*
 int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim,
                   const int64_t* bucket_off, int64_t n_buckets, const int32_t* n_list,
                   int kmeans_iters, fal_ivf** out);
+/* Optional: float16 copies of the vectors, [n, planes, low_dim] in the same (sorted) row order, that
+ * the FLAT buckets are then scanned with on the f16 matrix cores: planes = 1 plain float16 rows
+ * (fal_vectorize FAL_DTYPE_F16; BASELINE config 5), planes = 2 the hi/lo split of the float32
+ * rows (FAL_DTYPE_SPLIT16; float32-accurate to ~3e-7).  With planes = 1 fal_ivf_build may be given
+ * X = NULL as long as every bucket is flat.  The buffer is borrowed. ------------------- [dev] */
+int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes);
 int fal_ivf_destroy(fal_ivf* ivf);
 int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists);
 /* Copy the index out for inspection (any pointer may be NULL): centroids

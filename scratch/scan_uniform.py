@@ -8,7 +8,11 @@ for nb, bs in ((8, 4096), (32, 2048), (64, 1024), (256, 512), (1024, 256), (2048
     X = torch.rand((n, 400), device=ctx.tdev)
     X = X / X.norm(dim=1, keepdim=True)
     off = np.arange(nb + 1, dtype=np.int64) * bs
-    idx = ctx.ivf_build(X, off, np.ones(nb, np.int32))
+    import os
+    X16 = None
+    if os.environ.get('F16'):
+        hi = X.half(); lo = ((X - hi.float()) * 2048).half(); X16 = torch.stack([hi, lo], 1).contiguous()
+    idx = ctx.ivf_build(X, off, np.ones(nb, np.int32), X16=X16)
     ctx.enable_timing(True)
     for _ in range(2):
         sim, ids = idx.search(16, 128)

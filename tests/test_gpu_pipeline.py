@@ -208,3 +208,25 @@ def test_dbscan_golden(ctx, dbscan_golden):
         if idx.shape[1] >= 8:
             m = {}
             assert all(m.setdefault(int(a), int(b)) == int(b) for a, b in zip(ref, lab))
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16"])
+def test_pipeline_f16_scan_modes(ctx, mode):
+    """whole path with the f16-MFMA flat scan: "f16x3" (float32 vectors, hi/lo split) must reproduce
+    the float32 oracle's clustering (ARI >= 0.99, north_star); "f16" (config 5: low_dim = 800 float16
+    vectors) is compared with the oracle run on float16 vectors."""
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
+    from sklearn.metrics import adjusted_rand_score
+    import warnings
+    d, ds = _dataset(8000, seed=13)
+    if mode == "f16x3":
+        p, kw = AnnParams(scan="f16x3"), {}
+    else:
+        p, kw = AnnParams(dtype="f16", low_dim=800), dict(low_dim=800, dtype=np.float16)
+    labels, medoids = ClusterPipeline(ctx).run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, p)
+    labels, medoids = labels.cpu().numpy(), medoids.cpu().numpy()
+    ref, _ = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"], **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert adjusted_rand_score(ref, labels) >= 0.99
+    assert np.array_equal(labels[medoids], np.arange(len(medoids)))

@@ -118,3 +118,53 @@ def test_ivf_exhaustive_probe_equals_bruteforce(ctx):
     for a, b in zip(off[:-1], off[1:]):
         rs, ri = fo.exhaustive_topk(X[a:b], 64, base=a)
         assert_topk_close(sim[a:b], idx[a:b], rs, ri, X[a:b], base=a)
+
+
+def _f16_planes(X):
+    hi = X.astype(np.float16)
+    lo = ((X - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    return hi, lo
+
+
+@pytest.mark.parametrize("planes,d,k", [(2, 400, 128), (2, 400, 16), (1, 800, 64), (1, 400, 128), (2, 64, 8)])
+def test_f16_mfma_flat_scan(ctx, planes, d, k):
+    """f16 matrix-core scan of flat buckets: planes=2 (hi/lo split of float32 rows) must agree with
+    the float32 brute force to north_star's 1e-5 (observed ~3e-7); planes=1 (config 5: float16
+    vectors) must equal the brute force over the SAME float16 rows."""
+    import torch
+    sizes = [1, 31, 64, 65, 127, 128, 129, 300, 700, 1500]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    X = unit_vectors(off[-1], d, 17)
+    hi, lo = _f16_planes(X)
+    if planes == 2:
+        X16 = np.ascontiguousarray(np.stack([hi, lo], 1))
+        Xref = X
+        Xdev = torch.from_numpy(X).to(ctx.tdev)
+    else:
+        X16 = hi
+        Xref = hi.astype(np.float32)
+        Xdev = None
+    idxr = ctx.ivf_build(Xdev, off, np.ones(len(sizes), np.int32), X16=torch.from_numpy(X16).to(ctx.tdev))
+    sim, idx = idxr.search(16, k)
+    sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
+    worst = 0.0
+    for a, b in zip(off[:-1], off[1:]):
+        rs, ri = fo.exhaustive_topk(Xref[a:b], k, base=a)
+        assert_topk_close(sim[a:b], idx[a:b], rs, ri, Xref[a:b], base=a, what=f"bucket {a}:{b}")
+        ok = ri >= 0
+        worst = max(worst, float(np.abs(sim[a:b][ok] - rs[ok]).max()))
+    assert worst < 2e-6, worst
+
+
+def test_vectorize_split16(ctx):
+    """FAL_DTYPE_SPLIT16 = bit-exact hi/lo planes of the float32 vectors."""
+    from falcon_amd import synth
+    d = synth.generate(2000, seed=4)
+    nb, start, _ = fo.get_dim(101, 1500, 0.05)
+    V = ctx.vectorize(d["mz"], d["intensity"], d["indptr"], None, start, 0.05, nb, 400, dtype="split16").cpu().numpy()
+    ref = fo.vectorize(d["mz"], d["intensity"], d["indptr"], start, 0.05, nb, 400)
+    hi, lo = _f16_planes(ref)
+    assert V.shape == (2000, 2, 400)
+    assert np.array_equal(V[:, 0], hi) and np.array_equal(V[:, 1], lo)
+    rec = V[:, 0].astype(np.float64) + V[:, 1].astype(np.float64) / 2048
+    assert np.abs(rec - ref).max() < 3e-7
