@@ -159,12 +159,12 @@ def main():
     def step(collect=None):
         """one pass of the hot path over this rank's shard; `collect` != None: serial, per-stage timing"""
         if runner is not None and collect is None:
-            outs = runner.run(parts, *run_args, keep_intermediates=keep_nb)       # partitions overlap
+            outs = runner.run(parts, *run_args)                                   # partitions overlap
             lasts = [pp.last for pp in runner.last_pipes] if keep_nb else []
         else:
             outs, lasts = [], []
             for ds in parts:
-                outs.append(pipe.run(ds, *run_args, keep_intermediates=keep_nb))
+                outs.append(pipe.run(ds, *run_args))
                 if keep_nb:
                     lasts.append(dict(pipe.last))
                 if collect is not None:
@@ -187,7 +187,6 @@ def main():
                     gi.append(torch.where(nb_idx >= 0, nb_idx + off, nb_idx))
                     gd.append(nb_dist)
                     off += nb_idx.shape[0]
-                    last["index"].close()
                 g_idx, counts = fdist.allgatherv_rows(torch.cat(gi))
                 g_dist, _ = fdist.allgatherv_rows(torch.cat(gd), counts)
                 del g_idx, g_dist

@@ -138,6 +138,7 @@ class ClusterPipeline:
             # production: a9..a12 fused, counts stay on the device, one synchronisation
             labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
                                                     precursor_tol_mode, rt_tol, order)
+            self.last = dict(nb_idx=nb_idx, nb_dist=nb_dist, order=order)     # the sparse graph (for the exchange)
         if not keep_intermediates:
             index.close()
         return labels, medoids
