@@ -152,6 +152,95 @@ __global__ __launch_bounds__(64, 1) void ivf_fine_kernel(FineArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// List-major fine scan.  The union-of-probes kernel above only pays off when neighbouring queries
+// probe the same lists; on hashed spectra they do not (measured: 32 neighbouring queries probe 101 of
+// 128 lists), so the production path inverts the probe table instead: for every list, the queries
+// that probe it.  One wave = one list x 32 of those queries: the 32 query rows are GATHERED into
+// registers (row-per-lane loads), the list's rows stream through the load ring, and every lane
+// (= query) stores its 16 results per chunk at its own precomputed destination.  No LDS, no masks
+// beyond the list tail, MFMA waste = padding of the list length to 32 only.
+// ------------------------------------------------------------------------------------------------
+template <int DH4>
+__global__ __launch_bounds__(64, 1) void ivf_list_kernel(ListScanArgs a) {
+    // contiguous run of tiles per XCD: tiles cost about the same, and a list's tiles share its rows in L2
+    const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
+    const int64_t lt = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per_xcd) return;
+    const int64_t t = a.tile_begin + lt;
+    if (t >= a.ltile_off[a.list_end]) return;
+    // last list with ltile_off <= t
+    int64_t lo = a.list_begin, hi = a.list_end - 1;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (a.ltile_off[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int64_t L = lo;
+    const int64_t it = t - a.ltile_off[L];                 // tile inside the list
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int d = a.d, dh = d >> 1, dh4 = dh >> 2;
+    const int64_t e0 = a.inv_off[L] + 32 * it;
+    const int nq = (int)min<int64_t>(32, a.inv_off[L + 1] - e0);
+    const int64_t c_row0 = a.list_off[L];
+    const int nc = (int)(a.list_off[L + 1] - c_row0);
+    if (nq <= 0 || nc <= 0) return;
+
+    const bool qvalid = r < nq;
+    const int64_t e = e0 + min(r, nq - 1);
+    float q[DH4 * 4];
+    load_half_row<DH4>(q, a.Xl + (int64_t)a.inv_q[e] * d + (int64_t)h * dh, dh4);
+    float* orow = qvalid ? a.sims + (a.inv_dest[e] - a.sims_base) : a.sink + lane;
+    const int ovalid = qvalid ? nc : 0;                   // candidates >= ovalid go to the sink
+
+    CandStream<DH4> cs;
+    const float* cur = a.Xl + (c_row0 + min(r, nc - 1)) * d + (int64_t)h * dh;
+    cs.prime(cur, dh4);
+    f32x16 prev;
+    int prev_c0 = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) prev[i] = 0.f;
+    // lane = query, registers = 16 candidates of the chunk (D[cand][query]); masked slots -> sink
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = prev_c0 + mfma32_row(i, h);
+            float* p = c < ovalid ? orow + c : a.sink + lane;
+            *p = prev[i];
+        }
+        __builtin_amdgcn_sched_group_barrier(0x040, 16, 0);
+    };
+    for (int c0 = 0; c0 < nc; c0 += 32) {
+        const float* nxt = a.Xl + (c_row0 + min(c0 + 32 + r, nc - 1)) * d + (int64_t)h * dh;
+        const f32x16 acc = cs.template dot<false>(q, cur, nxt, dh4, epilogue);
+        prev = acc;
+        prev_c0 = c0;
+        cur = nxt;
+    }
+    epilogue();
+}
+
+int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a) {
+    if (a.n_tiles_max <= 0) return FAL_OK;
+    const int dh4 = a.d / 8;
+    const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
+    FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
+    dim3 grid((unsigned)(per_xcd * 8)), block(64);
+    StageScope ts(ctx, ST_SCAN);
+#define FAL_LAUNCH_LIST(DH4) hipLaunchKernelGGL(ivf_list_kernel<DH4>, grid, block, 0, ctx->stream, a)
+    if (dh4 <= 8) FAL_LAUNCH_LIST(8);
+    else if (dh4 <= 16) FAL_LAUNCH_LIST(16);
+    else if (dh4 <= 32) FAL_LAUNCH_LIST(32);
+    else if (dh4 <= 50) FAL_LAUNCH_LIST(50);
+    else if (dh4 <= 64) FAL_LAUNCH_LIST(64);
+    else {
+        set_error("float32 scan supports low_dim <= 512 (got %d)", a.d);
+        return FAL_EUNSUPPORTED;
+    }
+#undef FAL_LAUNCH_LIST
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
 int launch_fine(fal_ctx* ctx, const FineArgs& a) {
     if (a.n_tiles <= 0) return FAL_OK;
     const int dh4 = a.d / 8;

@@ -49,6 +49,22 @@ struct FineArgs {
 int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,
                  int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base, int32_t* assign,
                  int64_t xcd_list_tiles = 0);
+// List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
+struct ListScanArgs {
+    const float* Xl;             // vectors in (bucket, list, row) order
+    int d;
+    const int64_t* list_off;     // [total_lists + 1] rows of every list (positions in Xl)
+    const int64_t* inv_off;      // [total_lists + 1] entries of every list in the inverted probe table
+    const int64_t* ltile_off;    // [total_lists + 1] tiles (32 queries each) of every list, prefix
+    const int32_t* inv_q;        // [pairs] query position (row of Xl)
+    const int64_t* inv_dest;     // [pairs] float index in `sims` where that query's sims for this list start
+    int64_t list_begin, list_end;   // lists of this launch
+    int64_t tile_begin, n_tiles_max;   // first tile of list_begin; upper bound on the tiles of the launch
+    float* sims;
+    int64_t sims_base;
+    float* sink;                 // >= 64 floats of scratch for masked stores
+};
+int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a);
 int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks);
 int launch_fine(fal_ctx* ctx, const FineArgs& a);
 // f16-MFMA flat scan (scan16.hip): jobs sorted by decreasing size, xtile0 = 128-query tiles of earlier

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "scan.h"
 #include "ivf.h"
+#include "util.h"
 
 namespace fal {
 
@@ -32,6 +33,53 @@ __global__ void probe_totals_kernel(const int32_t* __restrict__ probes, int np, 
         if (l >= 0) tot += list_off[job.c_row0 + l + 1] - list_off[job.c_row0 + l];
     }
     totals[g] = tot;      // slot g = 32 * tile + lane (tile order, padded)
+}
+
+// ---- inverted probe table: for every list, the queries that probe it ---------------------------
+__global__ void probe_hist_kernel(const int32_t* __restrict__ probes, int np, const DenseJob* __restrict__ jobs,
+                                  int n_jobs, int64_t n_tiles, int32_t* __restrict__ cnt) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t t = g >> 5;
+    if (t >= n_tiles) return;
+    const DenseJob job = jobs[find_job(jobs, n_jobs, t)];
+    const int lt = (int)(t - job.tile0), ql = (int)(g & 31);
+    if (32 * lt + ql >= job.nq) return;
+    const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;
+    for (int j = 0; j < np; ++j) {
+        const int l = probes[p * np + j];
+        if (l >= 0) atomicAdd(&cnt[job.c_row0 + l], 1);
+    }
+}
+
+__global__ void list_tiles_kernel(const int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ tiles) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        tiles[i] = (cnt[i] + 31) >> 5;
+}
+
+// inv_q[e] = query position, inv_dest[e] = where that query's sims for this list start
+// (= its sims offset + the sizes of the lists it probes before this one)
+__global__ void probe_scatter_kernel(const int32_t* __restrict__ probes, int np, const DenseJob* __restrict__ jobs,
+                                     int n_jobs, int64_t n_tiles, const int64_t* __restrict__ list_off,
+                                     const int64_t* __restrict__ q_sim_off, const int64_t* __restrict__ inv_off,
+                                     int32_t* __restrict__ cursor, int32_t* __restrict__ inv_q,
+                                     int64_t* __restrict__ inv_dest) {
+    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t t = g >> 5;
+    if (t >= n_tiles) return;
+    const DenseJob job = jobs[find_job(jobs, n_jobs, t)];
+    const int lt = (int)(t - job.tile0), ql = (int)(g & 31);
+    if (32 * lt + ql >= job.nq) return;
+    const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;
+    int64_t dest = q_sim_off[g];
+    for (int j = 0; j < np; ++j) {
+        const int l = probes[p * np + j];
+        if (l < 0) continue;
+        const int64_t G = job.c_row0 + l;
+        const int64_t e = inv_off[G] + atomicAdd(&cursor[G], 1);
+        inv_q[e] = (int32_t)p;
+        inv_dest[e] = dest;
+        dest += list_off[G + 1] - list_off[G];
+    }
 }
 
 static size_t sims_capacity_floats() {
@@ -229,38 +277,70 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
                            coarse_dev, (int)coarse.size(), ivf_tiles, ivf->list_off, totals);
         FAL_TRY(launch_exclusive_scan(ctx, totals, n_slots, q_sim_off));
     }
-    // one prefix value per tile back to the host to cut the fine scan into buffer-sized batches
-    std::vector<int64_t> qoff((size_t)ivf_tiles + 1);
+    // ---- inverted probe table (list -> queries probing it) ------------------------------------
+    const int64_t TL = ivf->total_lists;
+    const int64_t n_pairs_max = ivf->n * (int64_t)np;
+    int32_t *cnt = nullptr, *inv_q = nullptr;
+    int64_t *inv_off = nullptr, *inv_dest = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_INVCNT, sizeof(int32_t) * (size_t)(3 * TL + 3) + sizeof(int64_t) * (size_t)(2 * TL + 4), (void**)&inv_off));
+    int64_t* ltile_off = inv_off + (TL + 2);
+    cnt = reinterpret_cast<int32_t*>(ltile_off + (TL + 2));
+    int32_t* cursor = cnt + (TL + 1);
+    int32_t* ltiles = cursor + (TL + 1);
+    FAL_TRY(ctx->reserve(SLOT_INV, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)n_pairs_max + 64, (void**)&inv_dest));
+    inv_q = reinterpret_cast<int32_t*>(inv_dest + n_pairs_max);
+    FAL_CHECK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(2 * TL + 2), st));     // cnt, cursor
+    {
+        StageScope ts(ctx, ST_COARSE);
+        const unsigned pg = (unsigned)ceil_div(n_slots, 256);
+        hipLaunchKernelGGL(probe_hist_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
+                           ivf_tiles, cnt);
+        FAL_TRY(device_scan_i32(ctx, cnt, TL, inv_off, SLOT_MISC2));
+        hipLaunchKernelGGL(list_tiles_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024)), dim3(256), 0, st,
+                           cnt, TL, ltiles);
+        FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
+        hipLaunchKernelGGL(probe_scatter_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
+                           ivf_tiles, ivf->list_off, q_sim_off, inv_off, cursor, inv_q, inv_dest);
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    // per-tile sims prefix and per-list tile prefix back to the host to cut bucket-sized batches
+    std::vector<int64_t> qoff((size_t)ivf_tiles + 1), lt_host((size_t)TL + 1);
     FAL_CHECK_HIP(hipMemcpy2DAsync(qoff.data(), sizeof(int64_t), q_sim_off, 32 * sizeof(int64_t), sizeof(int64_t),
                                    (size_t)ivf_tiles + 1, hipMemcpyDeviceToHost, st));
+    FAL_CHECK_HIP(hipMemcpyAsync(lt_host.data(), ltile_off, sizeof(int64_t) * (size_t)(TL + 1), hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipStreamSynchronize(st));
-    std::vector<int64_t> fine_cuts(1, 0);
+    // batches of whole IVF buckets (every list of a bucket touches queries all over the bucket)
+    struct IvfBatch { size_t j0, j1; };
+    std::vector<IvfBatch> ivf_batches;
     size_t need_fine = 0;
     {
-        int64_t first = 0;
-        for (int64_t t = 0; t < ivf_tiles; ++t) {
-            if (qoff[t + 1] - qoff[first] > (int64_t)cap && t > first) {
-                fine_cuts.push_back(t);
-                first = t;
+        size_t j0 = 0;
+        for (size_t j = 0; j < coarse.size(); ++j) {
+            const int64_t t_end = coarse[j].tile0 + ceil_div(coarse[j].nq, 32);
+            const int64_t span = qoff[(size_t)t_end] - qoff[(size_t)coarse[j0].tile0];
+            if (span > (int64_t)cap && j > j0) {
+                ivf_batches.push_back({j0, j});
+                j0 = j;
             }
-            need_fine = std::max(need_fine, (size_t)(qoff[t + 1] - qoff[first]));
+            need_fine = std::max(need_fine, (size_t)(qoff[(size_t)t_end] - qoff[(size_t)coarse[j0].tile0]));
         }
-        if (fine_cuts.back() != ivf_tiles) fine_cuts.push_back(ivf_tiles);
+        ivf_batches.push_back({j0, coarse.size()});
     }
     ctx->counters[0] += qoff[(size_t)ivf_tiles];
-    ctx->counters[2] += (int64_t)fine_cuts.size() - 1;
+    ctx->counters[2] += (int64_t)ivf_batches.size();
     ctx->counters[3] = std::max<int64_t>(ctx->counters[3], (int64_t)(sizeof(float) * need_fine));
-    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * std::max<size_t>(need_fine, 16), (void**)&sims));
-    for (size_t bi = 0; bi + 1 < fine_cuts.size(); ++bi) {
-        const int64_t t0 = fine_cuts[bi], t1 = fine_cuts[bi + 1];
+    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (need_fine + 64), (void**)&sims));
+    for (const IvfBatch& bt : ivf_batches) {
+        const DenseJob &first = coarse[bt.j0], &last = coarse[bt.j1 - 1];
+        const int64_t t0 = first.tile0, t1 = last.tile0 + ceil_div(last.nq, 32);
+        const int64_t L0 = first.c_row0, L1 = last.c_row0 + last.nc;        // lists of these buckets (natural order)
         const int64_t base = qoff[(size_t)t0];
-        FineArgs fa{};
-        fa.Xl = ivf->Xl; fa.d = d; fa.jobs = coarse_dev; fa.n_jobs = (int)coarse.size();
-        fa.tile_begin = t0; fa.n_tiles = t1 - t0; fa.n_probe = np; fa.probes = probes;
-        fa.list_off = ivf->list_off; fa.q_sim_off = q_sim_off; fa.sims = sims; fa.sims_base = base;
-        fa.bm_words = (max_n_list + 31) / 32;
-        fa.u_cap = std::min(32 * np, max_n_list);
-        FAL_TRY(launch_fine(ctx, fa));
+        ListScanArgs la{};
+        la.Xl = ivf->Xl; la.d = d; la.list_off = ivf->list_off; la.inv_off = inv_off; la.ltile_off = ltile_off;
+        la.inv_q = inv_q; la.inv_dest = inv_dest; la.list_begin = L0; la.list_end = L1;
+        la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
+        la.sims = sims; la.sims_base = base; la.sink = sims + need_fine;
+        FAL_TRY(launch_list_scan(ctx, la));
         SelectArgs sa{};
         sa.sims = sims; sa.sims_base = base; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size(); sa.tile_begin = t0;

@@ -1,0 +1,27 @@
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from falcon_amd import synth, device as dv
+from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset, n_list_rule
+N = int(sys.argv[1]); scan = sys.argv[2] if len(sys.argv) > 2 else "f32"
+t = time.time(); data = synth.generate(N); print(f"generated {N} in {time.time()-t:.1f}s", flush=True)
+ctx = dv.Context(0); pipe = ClusterPipeline(ctx)
+p = AnnParams(scan=scan)
+parts = []
+for ch in (2, 3):
+    c = synth.select_charge(data, ch)
+    parts.append(SpectrumDataset(*[ctx.to_dev(c[k], torch.float32) for k in ("precursor_mz", "retention_time", "mz", "intensity")], ctx.to_dev(c["indptr"], torch.int64)))
+del data
+for rep in range(2):
+    torch.cuda.synchronize(); t = time.time()
+    if rep == 1: ctx.enable_timing(True)
+    tot = 0; st = {}
+    for ds in parts:
+        labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, 2**15, p)
+        tot += int(medoids.numel())
+        if rep == 1:
+            for k in ("vectorize", "build", "coarse", "scan", "select", "filter", "dbscan", "tail"):
+                st[k] = st.get(k, 0) + ctx.stage_ms(k)[0]
+            st["pairs"] = st.get("pairs", 0) + ctx.counter(0); st["coarse_pairs"] = st.get("coarse_pairs", 0) + ctx.counter(1)
+    torch.cuda.synchronize(); dt = time.time() - t
+    print(f"rep {rep}: {N} spectra in {dt*1e3:.1f} ms -> {N/dt/1e6:.1f} M spectra/s, {tot} clusters, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB torch", flush=True)
+print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()})
