@@ -52,6 +52,9 @@ struct fal_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux = nullptr;            // second stream: top-k select of batch i under the scan of batch i+1
+    hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_sel[2] = {nullptr, nullptr};
+    int ensure_aux();
     int num_cus = 256;
     bool timing = false;
     // per-stage accumulated event pairs for the LAST call of that stage
@@ -72,8 +75,8 @@ struct fal_ctx {
 
     int reserve(int slot, size_t bytes, void** out);
     void stage_reset(int stage);
-    int stage_begin(int stage, hipEvent_t* stop_out);
-    int stage_end(hipEvent_t stop);
+    int stage_begin(int stage, hipEvent_t* stop_out, hipStream_t on = nullptr);
+    int stage_end(hipEvent_t stop, hipStream_t on = nullptr);
 };
 
 namespace fal {
@@ -83,11 +86,12 @@ struct StageScope {
     fal_ctx* c;
     hipEvent_t stop = nullptr;
     bool on;
-    StageScope(fal_ctx* ctx, int stage) : c(ctx), on(ctx->timing) {
-        if (on) c->stage_begin(stage, &stop);
+    hipStream_t s;
+    StageScope(fal_ctx* ctx, int stage, hipStream_t stream = nullptr) : c(ctx), on(ctx->timing), s(stream) {
+        if (on) c->stage_begin(stage, &stop, s);
     }
     ~StageScope() {
-        if (on && stop) c->stage_end(stop);
+        if (on && stop) c->stage_end(stop, s);
     }
 };
 

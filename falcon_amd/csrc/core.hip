@@ -60,7 +60,17 @@ void fal_ctx::pool_free(void* ptr) {
 
 void fal_ctx::stage_reset(int stage) { timers[stage].used = 0; }
 
-int fal_ctx::stage_begin(int stage, hipEvent_t* stop_out) {
+int fal_ctx::ensure_aux() {
+    if (aux) return FAL_OK;
+    FAL_CHECK_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        FAL_CHECK_HIP(hipEventCreateWithFlags(&ev_scan[i], hipEventDisableTiming));
+        FAL_CHECK_HIP(hipEventCreateWithFlags(&ev_sel[i], hipEventDisableTiming));
+    }
+    return FAL_OK;
+}
+
+int fal_ctx::stage_begin(int stage, hipEvent_t* stop_out, hipStream_t on) {
     StageTimer& t = timers[stage];
     if (t.used == t.ev.size()) {
         hipEvent_t a, b;
@@ -68,14 +78,14 @@ int fal_ctx::stage_begin(int stage, hipEvent_t* stop_out) {
         FAL_CHECK_HIP(hipEventCreate(&b));
         t.ev.push_back({a, b});
     }
-    FAL_CHECK_HIP(hipEventRecord(t.ev[t.used].first, stream));
+    FAL_CHECK_HIP(hipEventRecord(t.ev[t.used].first, on ? on : stream));
     *stop_out = t.ev[t.used].second;
     t.used++;
     return FAL_OK;
 }
 
-int fal_ctx::stage_end(hipEvent_t stop) {
-    FAL_CHECK_HIP(hipEventRecord(stop, stream));
+int fal_ctx::stage_end(hipEvent_t stop, hipStream_t on) {
+    FAL_CHECK_HIP(hipEventRecord(stop, on ? on : stream));
     return FAL_OK;
 }
 
@@ -141,6 +151,14 @@ int fal_ctx_destroy(fal_ctx* c) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
+    if (c->aux) {
+        (void)hipStreamSynchronize(c->aux);
+        (void)hipStreamDestroy(c->aux);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipEventDestroy(c->ev_scan[i]);
+            (void)hipEventDestroy(c->ev_sel[i]);
+        }
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FAL_OK;
@@ -167,6 +185,7 @@ int fal_ctx_counter(fal_ctx* c, int which, int64_t* value) {
 int fal_ctx_stage_ms(fal_ctx* c, int stage, float* ms, int64_t* launches) {
     FAL_REQUIRE(c && ms && stage >= 0 && stage < fal::kNumStages, FAL_EINVAL, "fal_ctx_stage_ms: bad argument");
     FAL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (c->aux) FAL_CHECK_HIP(hipStreamSynchronize(c->aux));
     float total = 0.f;
     auto& t = c->timers[stage];
     for (size_t i = 0; i < t.used; ++i) {

@@ -28,22 +28,6 @@ struct SelectArgs {
     const int32_t* perm;         // [n] list-order position -> sorted row
 };
 
-struct FineArgs {
-    const float* Xl;             // vectors in (bucket, list, row) order
-    int d;
-    const DenseJob* jobs;        // as for MODE_IVF above
-    int n_jobs;
-    int64_t tile_begin, n_tiles;
-    int n_probe;
-    const int32_t* probes;
-    const int64_t* list_off;
-    const int64_t* q_sim_off;
-    float* sims;
-    int64_t sims_base;
-    int bm_words;                // LDS bitmap words  (>= max n_list / 32)
-    int u_cap;                   // LDS union capacity (>= min(32 * n_probe, max n_list))
-};
-
 // xcd_list_tiles > 0 selects XCD-list mode (simtile.h): `jobs` = the launch's jobs sorted by
 // decreasing size with xtile0 filled in, xcd_list_tiles = tiles of the longest of the 8 lists.
 int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,
@@ -65,8 +49,7 @@ struct ListScanArgs {
     float* sink;                 // >= 64 floats of scratch for masked stores
 };
 int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a);
-int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks);
-int launch_fine(fal_ctx* ctx, const FineArgs& a);
+int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks, hipStream_t on = nullptr);
 // f16-MFMA flat scan (scan16.hip): jobs sorted by decreasing size, xtile0 = 128-query tiles of earlier
 // jobs of the same XCD list; list_tiles = longest list.  planes = 1 (f16 rows) or 2 (hi/lo split).
 // sink: >= 64 floats of scratch that idle waves store to.

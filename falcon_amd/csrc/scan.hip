@@ -393,15 +393,16 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     else sort_and_store<4>(sel_u, sel_id, carry, k, lane, osim, oidx);
 }
 
-int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks) {
+int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks, hipStream_t on) {
     if (n_blocks <= 0) return FAL_OK;
     FAL_REQUIRE(a.k >= 1 && a.k <= FAL_MAX_K_ANN, FAL_EUNSUPPORTED, "k must be in [1, %d]", FAL_MAX_K_ANN);
     FAL_REQUIRE(n_blocks < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
-    StageScope ts(ctx, stage);
+    hipStream_t st = on ? on : ctx->stream;
+    StageScope ts(ctx, stage, st);
     if (mode == MODE_DENSE)
-        hipLaunchKernelGGL(select_kernel<MODE_DENSE>, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(select_kernel<MODE_DENSE>, dim3((unsigned)n_blocks), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL(select_kernel<MODE_IVF>, dim3((unsigned)n_blocks), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL(select_kernel<MODE_IVF>, dim3((unsigned)n_blocks), dim3(64), 0, st, a);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

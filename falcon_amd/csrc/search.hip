@@ -51,9 +51,12 @@ __global__ void probe_hist_kernel(const int32_t* __restrict__ probes, int np, co
     }
 }
 
-__global__ void list_tiles_kernel(const int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ tiles) {
+// tiles of a list = 32-row slices of the LIST (each streams all queries probing the list); a list
+// nobody probes needs none
+__global__ void list_tiles_kernel(const int32_t* __restrict__ cnt, const int64_t* __restrict__ list_off, int64_t n,
+                                  int32_t* __restrict__ tiles) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        tiles[i] = (cnt[i] + 31) >> 5;
+        tiles[i] = cnt[i] > 0 ? (int32_t)((list_off[i + 1] - list_off[i] + 31) >> 5) : 0;
 }
 
 // inv_q[e] = query position, inv_dest[e] = where that query's sims for this list start
@@ -226,22 +229,46 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     float* sims = nullptr;
     const size_t sims_floats = std::max(need_flat, need_coarse);
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (sims_floats + 64), (void**)&sims));   // + sink for scan16
+    // scan || select: the top-k select of batch i runs on the auxiliary stream out of buffer i & 1 while
+    // the (matrix-pipe bound) scan of batch i + 1 fills the other buffer on the main stream
+    static const bool overlap = getenv("FALCON_OVERLAP") != nullptr;   // measured: no gain (the scan stretches), opt-in
+    float* sims2 = sims;
+    if (overlap && flat_batches.size() > 1) {
+        FAL_TRY(ctx->ensure_aux());
+        FAL_TRY(ctx->reserve(SLOT_SIMS2, sizeof(float) * (need_flat + 64), (void**)&sims2));
+    }
+    const bool ov = sims2 != sims;
+    bool sel_pending[2] = {false, false};
 
     // ---- A. flat buckets ---------------------------------------------------------------------
-    for (const FlatBatch& fb : flat_batches) {
+    for (size_t bi = 0; bi < flat_batches.size(); ++bi) {
+        const FlatBatch& fb = flat_batches[bi];
+        const int b = ov ? (int)(bi & 1) : 0;
+        float* buf = b ? sims2 : sims;
         const DenseJob* jb = flat_dev + fb.j0;
         const int nj = (int)(fb.j1 - fb.j0);
+        if (ov && sel_pending[b]) FAL_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_sel[b], 0));   // buffer free again
         if (fb.jm > fb.j0)
-            FAL_TRY(launch_scan16(ctx, ivf->x16_planes, ivf->X16, d, jb, (int)(fb.jm - fb.j0), fb.list_tiles16, sims, 0,
-                                  sims + sims_floats));
+            FAL_TRY(launch_scan16(ctx, ivf->x16_planes, ivf->X16, d, jb, (int)(fb.jm - fb.j0), fb.list_tiles16, buf, 0,
+                                  buf + (b ? need_flat : sims_floats)));
         if (fb.j1 > fb.jm)
             FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->Xl, ivf->Xl, d, flat_dev + fb.jm, (int)(fb.j1 - fb.jm), 0,
-                                 fb.tiles, sims, 0, nullptr, fb.list_tiles32));
+                                 fb.tiles, buf, 0, nullptr, fb.list_tiles32));
         SelectArgs sa{};
-        sa.sims = sims; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
+        sa.sims = buf; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = jb; sa.n_jobs = nj; sa.tile_begin = 0; sa.ids_are_rows = 1;
-        FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, fb.tiles * 32));
+        if (ov) {
+            FAL_CHECK_HIP(hipEventRecord(ctx->ev_scan[b], st));
+            FAL_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_scan[b], 0));
+            FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, fb.tiles * 32, ctx->aux));
+            FAL_CHECK_HIP(hipEventRecord(ctx->ev_sel[b], ctx->aux));
+            sel_pending[b] = true;
+        } else {
+            FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, fb.tiles * 32));
+        }
     }
+    for (int b = 0; b < 2; ++b)
+        if (sel_pending[b]) FAL_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_sel[b], 0));     // join
     ctx->counters[0] = 0;
     for (const DenseJob& j : flat) ctx->counters[0] += (int64_t)j.nq * j.nc;
     ctx->counters[1] = 0;
@@ -297,7 +324,7 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
                            ivf_tiles, cnt);
         FAL_TRY(device_scan_i32(ctx, cnt, TL, inv_off, SLOT_MISC2));
         hipLaunchKernelGGL(list_tiles_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024)), dim3(256), 0, st,
-                           cnt, TL, ltiles);
+                           cnt, ivf->list_off, TL, ltiles);
         FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
         hipLaunchKernelGGL(probe_scatter_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
                            ivf_tiles, ivf->list_off, q_sim_off, inv_off, cursor, inv_q, inv_dest);
