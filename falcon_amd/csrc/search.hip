@@ -118,12 +118,30 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     // Flat buckets are visited in order of decreasing size and dealt to the 8 XCD lists round-robin
     // (simtile.h, XCD-list mode): the longest tiles start first, every XCD gets the same mix.
     std::vector<int64_t> border;
-    for (int64_t b = 0; b < n_buckets; ++b)
-        if (ivf->n_list[b] == 1 && ivf->bucket_off[b + 1] > ivf->bucket_off[b]) border.push_back(b);
-    std::stable_sort(border.begin(), border.end(), [&](int64_t x, int64_t y) {
-        return ivf->bucket_off[x + 1] - ivf->bucket_off[x] > ivf->bucket_off[y + 1] - ivf->bucket_off[y];
-    });
+    {
+        // counting sort by size (stable, descending): O(buckets + max size), this runs on the critical path
+        int64_t max_sz = 0, n_flat = 0;
+        for (int64_t b = 0; b < n_buckets; ++b) {
+            const int64_t nb = ivf->bucket_off[b + 1] - ivf->bucket_off[b];
+            if (ivf->n_list[b] == 1 && nb > 0) {
+                max_sz = std::max(max_sz, nb);
+                ++n_flat;
+            }
+        }
+        std::vector<int64_t> start((size_t)max_sz + 2, 0);
+        for (int64_t b = 0; b < n_buckets; ++b) {
+            const int64_t nb = ivf->bucket_off[b + 1] - ivf->bucket_off[b];
+            if (ivf->n_list[b] == 1 && nb > 0) ++start[(size_t)(max_sz - nb) + 1];
+        }
+        for (size_t i = 1; i < start.size(); ++i) start[i] += start[i - 1];
+        border.resize((size_t)n_flat);
+        for (int64_t b = 0; b < n_buckets; ++b) {
+            const int64_t nb = ivf->bucket_off[b + 1] - ivf->bucket_off[b];
+            if (ivf->n_list[b] == 1 && nb > 0) border[(size_t)start[(size_t)(max_sz - nb)]++] = b;
+        }
+    }
     std::vector<DenseJob> flat, coarse;    // coarse doubles as the IVF tile table
+    flat.reserve(border.size());
     // a batch = jobs [j0, j1): [j0, jm) go to the f16-MFMA kernel (128-query tiles), [jm, j1) to the fp32 one
     struct FlatBatch { size_t j0, jm, j1; int64_t tiles, list_tiles16, list_tiles32, floats; };
     std::vector<FlatBatch> flat_batches;

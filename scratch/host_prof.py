@@ -4,7 +4,7 @@ from falcon_amd import synth, device as dv
 from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset, n_list_rule
 data = synth.generate(1000000)
 ctx = dv.Context(0)
-c = synth.select_charge(data, 2)
+c = synth.select_charge(data, int(sys.argv[1]) if len(sys.argv) > 1 else 2)
 ds = SpectrumDataset(*[ctx.to_dev(c[k], torch.float32) for k in ("precursor_mz", "retention_time", "mz", "intensity")], ctx.to_dev(c["indptr"], torch.int64))
 p = AnnParams()
 pipe = ClusterPipeline(ctx)
