@@ -42,7 +42,7 @@ __device__ __forceinline__ void load_half_row(float (&q)[DH4 * 4], const float* 
 // The ring depth divides DH4 so that slot (j % kRing) means the same step in every chunk.
 template <int DH4>
 struct CandStream {
-    static constexpr int kRing = (DH4 % 8 == 0) ? 8 : 10;
+    static constexpr int kRing = (DH4 % 8 == 0) ? 8 : 10;   // (a 25-deep ring was measured: no gain)
     static_assert(DH4 % kRing == 0, "ring depth must divide the number of 16-byte steps per row half");
     float4 ring[kRing];
 
