@@ -170,7 +170,7 @@ def main():
                 if collect is not None:
                     collect.append({k: ctx.stage_ms(k) for k in ("vectorize", "build", "coarse", "scan", "select",
                                                                   "filter", "dbscan", "tail")}
-                                   | {"pairs": ctx.counter(0), "coarse_pairs": ctx.counter(1),
+                                   | {"pairs": ctx.counter(0), "coarse_pairs": ctx.counter(1), "issued": ctx.counter(4),
                                       "scan_launches": ctx.counter(2), "sims_bytes": ctx.counter(3), "n": len(ds)})
         labels_all, current = [], 0
         for labels, medoids in outs:
@@ -266,7 +266,11 @@ def main():
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/r1_pmc_hbm_traffic_per_step.json)",
                          "flops_per_launch": flops / max(scan_launches, 1),
                          "launches": scan_launches, "avg_launch_ms": scan_ms / max(scan_launches, 1),
-                         "pairs_per_step": pairs},
+                         "pairs_per_step": pairs,
+                         # the kernel computes each bucket's similarity matrix on/above the diagonal only
+                         # (bit-identical by symmetry): machine flops actually issued, tile padding included
+                         "issued_tflops": (2.0 * d * sum(s["issued"] for s in stages) / (scan_ms * 1e-3) / 1e12
+                                           if scan_ms > 0 else 0.0)},
             "roofline_hbm": {"kernel": "cosine scan", "bound": "hbm",
                              "achieved": algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -288,6 +288,13 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     for (int b = 0; b < 2; ++b)
         if (sel_pending[b]) FAL_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_sel[b], 0));     // join
     ctx->counters[0] = 0;
+    ctx->counters[4] = 0;                      // inner products the matrix cores actually computed (incl. padding)
+    for (const FlatBatch& fb : flat_batches)
+        for (size_t j = fb.j0; j < fb.j1; ++j) {
+            const int64_t ch = ceil_div(flat[j].nc, 32);
+            // fp32 kernel: blocks on and above the diagonal only (symmetric); f16 kernel: full square
+            ctx->counters[4] += 1024 * (j < fb.jm ? 4 * ceil_div(flat[j].nq, 128) * ch : ch * (ch + 1) / 2);
+        }
     for (const DenseJob& j : flat) ctx->counters[0] += (int64_t)j.nq * j.nc;
     ctx->counters[1] = 0;
     ctx->counters[2] = (int64_t)flat_batches.size();

@@ -68,7 +68,9 @@ int fal_ctx_enable_timing(fal_ctx* ctx, int on);
  * which = 0: (query, candidate) inner products the fine scan produced results for
  *            (= sum over queries of candidates in their probed lists; n_b^2 per flat bucket);
  * which = 1: (query, centroid) inner products of the coarse quantiser;
- * which = 2: number of scan kernel launches (batches);  3: bytes of the sims scratch buffer. */
+ * which = 2: number of scan kernel launches (batches);  3: bytes of the sims scratch buffer;
+ * which = 4: inner products the matrix cores actually computed for the flat buckets (tile padding
+ *            included; the fp32 kernel computes only the blocks on/above each bucket's diagonal). */
 int fal_ctx_counter(fal_ctx* ctx, int which, int64_t* value);
 
 /* ---- a1  bin geometry: reference spectrum.py:172-199 `get_dim` (float32) --- [host] */
