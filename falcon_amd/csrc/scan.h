@@ -52,7 +52,7 @@ int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a);
 int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks, hipStream_t on = nullptr);
 // f16-MFMA flat scan (scan16.hip): jobs sorted by decreasing size, xtile0 = 128-query tiles of earlier
 // jobs of the same XCD list; list_tiles = longest list.  planes = 1 (f16 rows) or 2 (hi/lo split).
-// sink: >= 64 floats of scratch that idle waves store to.
+// sink: >= 256 floats (16-byte aligned) of scratch that idle waves store to.
 int launch_scan16(fal_ctx* ctx, int planes, const void* Xs, int d, const DenseJob* jobs, int n_jobs, int64_t list_tiles,
                   float* sims, int64_t sims_base, float* sink);
 

@@ -84,6 +84,14 @@ __global__ __launch_bounds__(256, 1) void scan16_kernel(const __half* __restrict
     }
     float* out = active ? sims + (job.obase - sims_base) + (int64_t)(32 * tile32) * ncp + r : sink + lane;
     const int ostride = active ? ncp : 0;
+    // Symmetry (queries == candidates of the same bucket; sim(i,j) == sim(j,i) bit for bit because both
+    // are the same products summed in the same order): the workgroup only visits chunks at or above
+    // its first query tile, each wave only computes chunks at or above its own tile and writes every
+    // off-diagonal block a second time, transposed.
+    const int c_first_wg = 128 * T;                 // first chunk (candidate row) the workgroup needs
+    const int c_first = 32 * tile32;                // first chunk this wave computes
+    float* outT = sims + (job.obase - sims_base) + (int64_t)r * ncp + 32 * tile32 + 4 * h;   // used only when `mine`
+    const int tstride = active ? ncp : 0;
 
     // ---- candidate staging: chunk c -> registers (coalesced 16 B/lane) -> LDS buffer c & 1 -----
     const __half* cbase = Xs + job.c_row0 * (int64_t)ROW_HALVES;
@@ -106,13 +114,16 @@ __global__ __launch_bounds__(256, 1) void scan16_kernel(const __half* __restrict
     }
 #define FAL_STAGE_LOAD(C0) { const int stage_c0 = (C0); FAL_FOR_STAGE(FAL_LOAD_ONE) }
 #define FAL_STAGE_STORE(BUF) { const int stage_buf = (BUF); FAL_FOR_STAGE(FAL_STORE_ONE) }
-    FAL_STAGE_LOAD(0)
+    // chunks are walked from the last one DOWN to the workgroup's first (tiles of a bucket running
+    // together then read the same chunk at the same time and stop at their own diagonal)
+    const int c_last = ((nc - 1) >> 5) << 5;
+    FAL_STAGE_LOAD(c_last)
     FAL_STAGE_STORE(0)
     __syncthreads();
 
     int buf = 0;
-    for (int c0 = 0; c0 < nc; c0 += 32) {
-        FAL_STAGE_LOAD(c0 + 32)                     // next chunk (rows clamped), in flight during the MFMAs
+    for (int c0 = c_last; c0 >= c_first_wg; c0 -= 32) {
+        FAL_STAGE_LOAD(max(c0 - 32, 0))             // next chunk, in flight during the MFMAs
         __builtin_amdgcn_sched_group_barrier(0x020, kStage, 0);              // ... so issue them FIRST
         const unsigned char* rowp = lds + (size_t)buf * 32 * RS + r * RS + h * DH * 2;
         half8 rh[NB], rl[NB];
@@ -143,14 +154,24 @@ __global__ __launch_bounds__(256, 1) void scan16_kernel(const __half* __restrict
             __builtin_amdgcn_sched_group_barrier(0x100, PLANES, 0);          // LDS reads of step s + NB
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * PLANES - 1, 0);  // MFMAs of step s
         }
-        // D[query][candidate]: this lane owns candidate c0 + r, registers = 16 query rows
-        const int ocol = active ? c0 : 0;
+        // D[query][candidate]: this lane owns candidate c0 + r, registers = 16 query rows.
+        // Chunks below this wave's diagonal are another tile's job: their (computed) values go to the sink.
+        const bool mine = active && c0 >= c_first;
+        float* o = mine ? out : sink + lane;
+        float* ot = mine ? outT + (int64_t)c0 * tstride : sink + 4 * lane;      // 16-byte aligned either way
+        const int tg = mine ? 8 : 0;
+        const int os = mine ? ostride : 0, ocol = mine ? c0 : 0;
+        float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float v = (PLANES == 2) ? acc_hh[i] + acc_x[i] * (1.0f / 2048.0f) : acc_hh[i];
-            out[mfma32_row(i, h) * ostride + ocol] = v;
+            v[i] = (PLANES == 2) ? acc_hh[i] + acc_x[i] * (1.0f / 2048.0f) : acc_hh[i];
+            o[mfma32_row(i, h) * os + ocol] = v[i];
         }
-        __builtin_amdgcn_sched_group_barrier(0x040, 16, 0);
+        // transposed copy: registers 4g .. 4g+3 are four consecutive columns (query rows 8g + 4h + 0..3)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(ot + tg * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+        __builtin_amdgcn_sched_group_barrier(0x040, 20, 0);
         FAL_STAGE_STORE(buf ^ 1)                    // buffer buf^1 was last read before the previous barrier
         __builtin_amdgcn_sched_group_barrier(0x200, kStage, 0);
         __syncthreads();

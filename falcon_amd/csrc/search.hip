@@ -246,14 +246,14 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
     }
     float* sims = nullptr;
     const size_t sims_floats = std::max(need_flat, need_coarse);
-    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (sims_floats + 64), (void**)&sims));   // + sink for scan16
+    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (sims_floats + 320), (void**)&sims));   // + sink for scan16
     // scan || select: the top-k select of batch i runs on the auxiliary stream out of buffer i & 1 while
     // the (matrix-pipe bound) scan of batch i + 1 fills the other buffer on the main stream
     static const bool overlap = getenv("FALCON_OVERLAP") != nullptr;   // measured: no gain (the scan stretches), opt-in
     float* sims2 = sims;
     if (overlap && flat_batches.size() > 1) {
         FAL_TRY(ctx->ensure_aux());
-        FAL_TRY(ctx->reserve(SLOT_SIMS2, sizeof(float) * (need_flat + 64), (void**)&sims2));
+        FAL_TRY(ctx->reserve(SLOT_SIMS2, sizeof(float) * (need_flat + 320), (void**)&sims2));
     }
     const bool ov = sims2 != sims;
     bool sel_pending[2] = {false, false};
@@ -293,7 +293,7 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         for (size_t j = fb.j0; j < fb.j1; ++j) {
             const int64_t ch = ceil_div(flat[j].nc, 32);
             // fp32 kernel: blocks on and above the diagonal only (symmetric); f16 kernel: full square
-            ctx->counters[4] += 1024 * (j < fb.jm ? 4 * ceil_div(flat[j].nq, 128) * ch : ch * (ch + 1) / 2);
+            ctx->counters[4] += 1024 * (ch * (ch + 1) / 2);   // both kernels: blocks on/above the diagonal (f16: + up to 3 per 128-row tile)
         }
     for (const DenseJob& j : flat) ctx->counters[0] += (int64_t)j.nq * j.nc;
     ctx->counters[1] = 0;
