@@ -55,6 +55,9 @@ struct fal_ctx {
     hipStream_t aux = nullptr;            // second stream: top-k select of batch i under the scan of batch i+1
     hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_sel[2] = {nullptr, nullptr};
     int ensure_aux();
+    void* pinned = nullptr;               // small pinned host staging buffer (single-sync readbacks)
+    size_t pinned_cap = 0;
+    int pinned_reserve(size_t bytes, void** out);
     int num_cus = 256;
     bool timing = false;
     // per-stage accumulated event pairs for the LAST call of that stage

@@ -60,6 +60,18 @@ void fal_ctx::pool_free(void* ptr) {
 
 void fal_ctx::stage_reset(int stage) { timers[stage].used = 0; }
 
+int fal_ctx::pinned_reserve(size_t bytes, void** out) {
+    if (bytes > pinned_cap) {
+        if (pinned) FAL_CHECK_HIP(hipHostFree(pinned));
+        pinned = nullptr;
+        pinned_cap = 0;
+        FAL_CHECK_HIP(hipHostMalloc(&pinned, bytes + 4096, hipHostMallocDefault));
+        pinned_cap = bytes + 4096;
+    }
+    *out = pinned;
+    return FAL_OK;
+}
+
 int fal_ctx::ensure_aux() {
     if (aux) return FAL_OK;
     FAL_CHECK_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
@@ -146,6 +158,7 @@ int fal_ctx_destroy(fal_ctx* c) {
     for (auto& s : c->scratch)
         if (s.ptr) (void)hipFree(s.ptr);
     for (auto& b : c->pool) (void)hipFree(b.ptr);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto& t : c->timers)
         for (auto& p : t.ev) {
             (void)hipEventDestroy(p.first);

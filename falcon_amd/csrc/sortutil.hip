@@ -186,18 +186,33 @@ int fal_precursor_splits(fal_ctx* ctx, const float* mz, int64_t n, double tol, i
         hipLaunchKernelGGL(split_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, mz, n, tol, tol_is_da, mz_interval, flag);
         hipLaunchKernelGGL(nonzero_i32_kernel, dim3(grid), dim3(256), 0, ctx->stream, flag, n, nz);
         FAL_TRY(device_scan_i32(ctx, nz, n, pos, SLOT_SORT));
-        int64_t total = 0;
-        FAL_CHECK_HIP(hipMemcpyAsync(&total, pos + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        // compact on the device right away, then ONE synchronisation: the count and the first K entries
+        // come back through a pinned buffer (a second readback only if there are more than K gaps)
+        FAL_TRY(ctx->reserve(SLOT_SORT2, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)n, (void**)&cidx));
+        cflag = reinterpret_cast<int32_t*>(cidx + n);
+        hipLaunchKernelGGL(compact_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, flag, pos, n, cidx, cflag);
+        const int64_t K = std::min<int64_t>(n, 65536);
+        unsigned char* pin = nullptr;
+        FAL_TRY(ctx->pinned_reserve(sizeof(int64_t) * (size_t)(K + 1) + sizeof(int32_t) * (size_t)K, (void**)&pin));
+        int64_t* h_total = reinterpret_cast<int64_t*>(pin);
+        int64_t* h_idx = h_total + 1;
+        int32_t* h_flag = reinterpret_cast<int32_t*>(h_idx + K);
+        FAL_CHECK_HIP(hipMemcpyAsync(h_total, pos + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipMemcpyAsync(h_idx, cidx, sizeof(int64_t) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipMemcpyAsync(h_flag, cflag, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
         FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        const int64_t total = *h_total;
         if (total > 0) {
-            FAL_TRY(ctx->reserve(SLOT_SORT2, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)total, (void**)&cidx));
-            cflag = reinterpret_cast<int32_t*>(cidx + total);
-            hipLaunchKernelGGL(compact_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, flag, pos, n, cidx, cflag);
             gap_idx.resize(total);
             gap_flag.resize(total);
-            FAL_CHECK_HIP(hipMemcpyAsync(gap_idx.data(), cidx, sizeof(int64_t) * total, hipMemcpyDeviceToHost, ctx->stream));
-            FAL_CHECK_HIP(hipMemcpyAsync(gap_flag.data(), cflag, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx->stream));
-            FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            const int64_t first = std::min(total, K);
+            memcpy(gap_idx.data(), h_idx, sizeof(int64_t) * (size_t)first);
+            memcpy(gap_flag.data(), h_flag, sizeof(int32_t) * (size_t)first);
+            if (total > K) {
+                FAL_CHECK_HIP(hipMemcpyAsync(gap_idx.data() + K, cidx + K, sizeof(int64_t) * (size_t)(total - K), hipMemcpyDeviceToHost, ctx->stream));
+                FAL_CHECK_HIP(hipMemcpyAsync(gap_flag.data() + K, cflag + K, sizeof(int32_t) * (size_t)(total - K), hipMemcpyDeviceToHost, ctx->stream));
+                FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+            }
         }
     }
     // reference cluster.py:183-208 over the gap positions (host; a few entries per bucket)
