@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--scan", choices=["f32", "f16x3"], default="f32",
                     help="flat-scan arithmetic: exact fp32 MFMA (default) or hi/lo float16 split on the f16 MFMA")
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32", help="vector dtype (f16 = BASELINE config 5)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the exchange step's device work (CSR packing, payload) at 1 GPU too (no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="run the charge partitions on two host threads / two streams (PartitionRunner)")
@@ -154,7 +156,10 @@ def main():
             torch.cuda.synchronize()
 
     run_args = (20.0, "ppm", None, 0.05, args.batch_size, p)
-    keep_nb = args.exchange == "neighbors" and world > 1
+    exchanging = args.exchange != "none" and (world > 1 or args.force_exchange)
+    keep_nb = args.exchange == "neighbors" and exchanging
+    exchange = fdist.SparseGraphExchange(dev)
+    pending, csr_buf = [], {}
 
     def step(collect=None):
         """one pass of the hot path over this rank's shard; `collect` != None: serial, per-stage timing"""
@@ -177,28 +182,43 @@ def main():
             labels_all.append(labels + current)                  # falcon.py:189-193
             current += int(medoids.numel())
         labels = torch.cat(labels_all)
-        if world > 1 and args.exchange != "none":
-            if args.exchange == "neighbors":
-                # one all-gatherv of the sparse neighbour lists (ids -> global sorted rows of the job)
-                off = row_offset
-                gi, gd = [], []
-                for last in lasts:
-                    nb_idx, nb_dist = last["nb_idx"], last["nb_dist"]
-                    gi.append(torch.where(nb_idx >= 0, nb_idx + off, nb_idx))
-                    gd.append(nb_dist)
-                    off += nb_idx.shape[0]
-                g_idx, counts = fdist.allgatherv_rows(torch.cat(gi))
-                g_dist, _ = fdist.allgatherv_rows(torch.cat(gd), counts)
-                del g_idx, g_dist
-            labels, _ = fdist.allgatherv_labels(labels, current)
-        return labels.cpu()
+        if not exchanging:
+            return labels.cpu()
+        # ---- the one exchange step: all-gatherv of the sparse neighbour lists (CSR, ids ->
+        # global sorted rows of the job) + labels; asynchronous: it travels while the next step computes
+        if args.exchange == "neighbors":
+            rows = sum(last["nb_idx"].shape[0] for last in lasts)
+            if "buf" not in csr_buf:
+                cap = rows * args.n_neighbors
+                csr_buf["buf"] = (torch.empty(rows + 1, dtype=torch.int64, device=dev),
+                                  torch.empty(cap, dtype=torch.int32, device=dev),
+                                  torch.empty(cap, dtype=torch.float32, device=dev))
+            row0 = 0
+            for last in lasts:                                   # charge partitions chain into one CSR on the device
+                csr = ctx.neighbors_to_csr(last["nb_idx"], last["nb_dist"], row_offset + row0, out=csr_buf["buf"], row0=row0)
+                row0 += last["nb_idx"].shape[0]
+        else:                                                    # labels only: an empty graph
+            csr = (torch.zeros(labels.numel() + 1, dtype=torch.int64, device=dev),
+                   torch.empty(1, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.float32, device=dev))
+        handle = exchange.start(csr[0], csr[1], csr[2], labels, current)
+        done = finish_pending()
+        pending.append(handle)
+        return done
+
+    def finish_pending():
+        if not pending:
+            return None
+        g = exchange.finish(pending.pop())
+        return torch.cat(g["labels"]).cpu()                      # globally unique labels of the whole job
 
     for _ in range(args.warmup):
         step()
+    finish_pending()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish_pending()                                             # the last exchange lands inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -210,6 +230,7 @@ def main():
     ctx.enable_timing(True)
     stages = []
     step(stages)
+    finish_pending()
     ctx.enable_timing(False)
 
     if rank == 0:
@@ -257,7 +278,7 @@ def main():
                                    f"n_neighbors={args.n_neighbors}, n_neighbors_ann={args.n_neighbors_ann}, "
                                    f"n_probe={args.n_probe}, eps={args.eps}, precursor_tol=20ppm, "
                                    f"mz_interval={args.mz_interval}, batch_size={args.batch_size}",
-                       "exchange": args.exchange if world > 1 else "none",
+                       "exchange": (args.exchange + " (CSR all-gatherv, overlapped with the next step)") if exchanging else "none",
                        "partitions": "2 host threads / 2 streams" if args.overlap else "serial",
                        "parallelism": f"bucket-sharded x{world}"},
             "roofline": {"kernel": "dense_kernel<.,STORE> / ivf_fine_kernel (cosine scan, fp32 MFMA 32x32x2)",

@@ -149,6 +149,51 @@ __global__ void dbscan_label_kernel(const int32_t* __restrict__ core, const int3
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// ELL -> CSR of the neighbour lists (the payload of the multi-GPU exchange):
+// one wave per row, entries keep their order, ids are shifted to global rows
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nb_count_kernel(const int32_t* __restrict__ nb_idx, int64_t n, int k,
+                                                       int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+        int c = 0;
+        for (int j = lane; j < k + lane; j += 64) {           // wave-uniform trip count
+            const bool valid = j < k && nb_idx[row * k + j] >= 0;
+            c += __popcll(__ballot(valid));
+        }
+        if (lane == 0) count[row] = c;
+    }
+}
+
+__global__ void nb_chain_kernel(const int64_t* __restrict__ local, int64_t n, int64_t* __restrict__ indptr) {
+    const int64_t base = indptr[0];                           // written by the previous segment (0 for the first)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        indptr[i + 1] = base + local[i + 1];
+}
+
+__global__ __launch_bounds__(256) void nb_pack_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
+                                                      int64_t n, int k, int64_t id_offset,
+                                                      const int64_t* __restrict__ indptr, int32_t* __restrict__ out_idx,
+                                                      float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+        int64_t base = indptr[row];
+        if (indptr[row + 1] == base) continue;                // wave-uniform
+        for (int j = lane; j < k + lane; j += 64) {
+            const int32_t id = j < k ? nb_idx[row * k + j] : -1;
+            const bool valid = id >= 0;
+            const unsigned long long m = __ballot(valid);
+            if (valid) {
+                const int64_t o = base + __popcll(m & ((1ull << lane) - 1ull));
+                out_idx[o] = (int32_t)(id + id_offset);
+                out_dist[o] = nb_dist[row * k + j];
+            }
+            base += __popcll(m);
+        }
+    }
+}
+
 }  // namespace fal
 
 using namespace fal;
@@ -166,6 +211,29 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
     hipLaunchKernelGGL(filter_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, sim, idx, n, k_ann,
                        precursor_mz_sorted, rt_tol >= 0.0 ? rt_sorted : nullptr, tol, tol_is_da, rt_tol, n_neighbors,
                        nb_idx, nb_dist);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, int64_t id_offset,
+                         int64_t row0, int64_t* indptr_out, int32_t* idx_out, float* dist_out) {
+    FAL_REQUIRE(ctx && n >= 0 && k >= 1 && row0 >= 0, FAL_EINVAL, "fal_neighbors_to_csr: bad argument");
+    FAL_REQUIRE(indptr_out, FAL_EINVAL, "fal_neighbors_to_csr: NULL indptr");
+    if (row0 == 0) FAL_CHECK_HIP(hipMemsetAsync(indptr_out, 0, sizeof(int64_t), ctx->stream));
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(nb_idx && nb_dist && idx_out && dist_out, FAL_EINVAL, "fal_neighbors_to_csr: NULL array");
+    int32_t* count = nullptr;
+    int64_t* local = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_DB, sizeof(int32_t) * (size_t)n, (void**)&count));
+    FAL_TRY(ctx->reserve(SLOT_DB2, sizeof(int64_t) * (size_t)(n + 1), (void**)&local));
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64);
+    hipLaunchKernelGGL(nb_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, n, k, count);
+    FAL_TRY(device_scan_i32(ctx, count, n, local, SLOT_DB3));
+    // indptr_out[row0 + 1 + i] = indptr_out[row0] + local[i + 1]: segments chain on the device
+    hipLaunchKernelGGL(nb_chain_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, ctx->stream,
+                       local, n, indptr_out + row0);
+    hipLaunchKernelGGL(nb_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, id_offset,
+                       indptr_out + row0, idx_out, dist_out);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

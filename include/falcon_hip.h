@@ -147,6 +147,18 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
                          double tol, int tol_is_da, double rt_tol, int n_neighbors,
                          int32_t* nb_idx, float* nb_dist);
 
+/* ---- e   neighbour lists ELL -> CSR, ids shifted by id_offset to global rows: the
+ *          payload of the one multi-GPU exchange step (all-gatherv of the
+ *          sparse neighbour lists; the reference's per-block results are likewise
+ *          concatenated with offsets, cluster.py:115-141).  Entry order within a row is
+ *          kept.  Segments (e.g. the charge partitions of falcon.py:151-160) chain on
+ *          the device: a call writes rows [row0, row0 + n) of indptr_out and continues
+ *          at nnz = indptr_out[row0] (row0 = 0 starts a new graph).  indptr i64[rows+1];
+ *          idx_out / dist_out need room for every segment's n*k entries. ---------- [dev] */
+int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n,
+                         int k, int64_t id_offset, int64_t row0, int64_t* indptr_out,
+                         int32_t* idx_out, float* dist_out);
+
 /* ---- a9  DBSCAN(eps, min_samples = 2 as reference cluster.py:66) on the sparse
  *          neighbour graph; spec README.md:143-146.  Order-independent form:
  *          clusters = components of core points, border -> lowest-index core

@@ -53,3 +53,74 @@ def test_allgatherv_world2_gloo():
         assert np.array_equal(gi, exp_idx) and np.array_equal(gd, exp_dist)
     exp_lab = np.concatenate([np.arange(5) % 2, np.arange(3) % 2 + 2])
     assert np.array_equal(gl0, exp_lab) and np.array_equal(gl1, exp_lab)
+
+
+def _ell_to_csr(nb_idx, nb_dist, off):
+    """numpy statement of fal_neighbors_to_csr (row order kept, ids shifted)."""
+    valid = nb_idx >= 0
+    indptr = np.concatenate([[0], np.cumsum(valid.sum(1))]).astype(np.int64)
+    return indptr, (nb_idx[valid] + off).astype(np.int32), nb_dist[valid].astype(np.float32)
+
+
+def _csr_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from falcon_amd import distributed as fd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = fd.SparseGraphExchange(torch.device("cpu"))
+        handles, sent = [], []
+        for step in range(2):                                   # two exchanges in flight, finished in order
+            n = [[7, 4], [2, 9]][step][rank]
+            k = 5
+            rng = np.random.default_rng(10 * step + rank)
+            nb_idx = rng.integers(-1, n, (n, k)).astype(np.int32)
+            if step == 1 and rank == 0:
+                nb_idx[:] = -1                                   # a rank with an empty graph
+            nb_dist = rng.random((n, k)).astype(np.float32)
+            off = 100 * rank
+            indptr, idx, dst = _ell_to_csr(nb_idx, nb_dist, off)
+            cap = n * k
+            idx_buf = np.full(cap, -7, np.int32); idx_buf[:len(idx)] = idx
+            dst_buf = np.full(cap, np.nan, np.float32); dst_buf[:len(dst)] = dst
+            labels = (np.arange(n) % 3).astype(np.int32)
+            handles.append(ex.start(torch.from_numpy(indptr), torch.from_numpy(idx_buf), torch.from_numpy(dst_buf),
+                                    torch.from_numpy(labels), 3))
+            sent.append((indptr, idx, dst, labels))
+        outs = []
+        for h in handles:
+            o = ex.finish(h)
+            outs.append(dict(counts=[c.numpy().copy() for c in o["counts"]], idx=[c.numpy().copy() for c in o["idx"]],
+                             dist=[c.numpy().copy() for c in o["dist"]], labels=[c.numpy().copy() for c in o["labels"]],
+                             n_labels=o["n_labels"]))
+        q.put((rank, sent, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_graph_exchange_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_csr_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sent = [res[0][1], res[1][1]]
+    for rank in range(2):
+        outs = res[rank][2]
+        for step in range(2):
+            o = outs[step]
+            assert o["n_labels"] == 6
+            for r in range(2):
+                indptr, idx, dst, labels = sent[r][step]
+                assert np.array_equal(o["counts"][r], np.diff(indptr))
+                assert np.array_equal(o["idx"][r], idx) and np.array_equal(o["dist"][r], dst)
+                assert np.array_equal(o["labels"][r], labels + 3 * r)
