@@ -124,11 +124,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (falcon_amd has no CPU fallback)")
+    # test hooks (1-GPU box): FALCON_BENCH_DEVICE pins every rank to one device, FALCON_BENCH_BACKEND=gloo
+    # swaps RCCL for gloo so the N-rank control flow can be exercised where only one GPU exists
+    local_rank = int(os.environ.get("FALCON_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("FALCON_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     ctx = Context(local_rank)
     pipe = ClusterPipeline(ctx)
@@ -305,10 +312,17 @@ def main():
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(data, p)
-        print(json.dumps(out))
+        line = json.dumps(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL's banner / warnings sit in the C stdio buffer of this process (NCCL_DEBUG output goes to
+        # stdout): flush them first so that the JSON line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
