@@ -50,6 +50,8 @@ _SIGNATURES = {
     "fal_ivf_search_topk": ([c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p], c_int),
     "fal_filter_neighbors": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_double, c_int,
                               c_double, c_int, c_void_p, c_void_p], c_int),
+    "fal_ivf_search_neighbors": ([c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_double, c_int, c_double, c_int,
+                                  c_void_p, c_void_p], c_int),
     "fal_neighbors_to_csr": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
                              c_int),
     "fal_dbscan": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, P(c_int64)], c_int),

@@ -123,9 +123,14 @@ class ClusterPipeline:
         else:
             X = vec("f32")
         index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16)
-        sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
-        nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
-                                             p.n_neighbors)
+        if keep_intermediates:
+            sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
+            nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
+                                                 p.n_neighbors)
+        else:
+            # production: a7 + a8 in one call, the [n, k_ann] search result never goes to HBM
+            nb_idx, nb_dist = index.search_neighbors(p.n_probe, p.n_neighbors_ann, mzs, rts, precursor_tol_mass,
+                                                     precursor_tol_mode, rt_tol, p.n_neighbors)
         if keep_intermediates:
             # staged calls (one C-ABI call per SURVEY 8a row) so that every intermediate can be inspected
             db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)

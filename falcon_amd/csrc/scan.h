@@ -26,6 +26,16 @@ struct SelectArgs {
     const int64_t* list_off;     // [total_lists + 1] positions in list order
     const int64_t* q_sim_off;    // [32 * tiles] where the sims of tile-order slot 32*t+lane start
     const int32_t* perm;         // [n] list-order position -> sorted row
+    // a8 fused into the selection (nb_idx != nullptr): the k selected candidates are filtered by the
+    // precursor / RT tolerance, only the survivors are sorted, and the neighbour lists are written
+    // instead of out_sim / out_idx
+    const float* f_pmz;          // [n] precursor m/z by sorted row
+    const float* f_rt;           // [n] or nullptr
+    double f_tol, f_rt_tol;
+    int f_is_da;
+    int f_keep;                  // n_neighbors
+    int32_t* nb_idx;             // [rows, f_keep]
+    float* nb_dist;              // [rows, f_keep]
 };
 
 // xcd_list_tiles > 0 selects XCD-list mode (simtile.h): `jobs` = the launch's jobs sorted by

@@ -360,7 +360,91 @@ __device__ __forceinline__ void sort_and_store(const uint32_t* sel_u, const uint
     }
 }
 
-template <int MODE>
+// a8 on the selected set (graph.hip filter_kernel is the staged form): drop self and neighbours outside the
+// precursor / RT tolerance, sort the SURVIVORS by (similarity desc, id asc) with the smallest network that
+// holds them, keep the first f_keep, dist = clip(1 - sim, 0, 1).  Typically a handful of the k_ann
+// candidates survive, so this replaces a 128-key sort + a second kernel by a 16/32-key sort.
+template <int SIZE>
+__device__ __forceinline__ void sort_small(uint32_t& hi, uint32_t& lo, int lane) {
+    uint32_t h[1] = {hi}, l[1] = {lo};
+    bitonic_build<1, SIZE>(h, l, lane);
+    hi = h[0];
+    lo = l[0];
+}
+
+template <int E>
+__device__ __forceinline__ void sort_and_store_nb(const uint32_t* f_u, const uint32_t* f_lo, int c, int keep, int lane,
+                                                  int32_t* __restrict__ onb, float* __restrict__ odist) {
+    uint32_t hi[E], lo[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int e = lane * E + r;
+        hi[r] = e < c ? f_u[e] : 0u;
+        lo[r] = e < c ? f_lo[e] : 0u;
+    }
+    if constexpr (E == 1) {
+        if (c <= 2) sort_small<2>(hi[0], lo[0], lane);
+        else if (c <= 4) sort_small<4>(hi[0], lo[0], lane);
+        else if (c <= 8) sort_small<8>(hi[0], lo[0], lane);
+        else if (c <= 16) sort_small<16>(hi[0], lo[0], lane);
+        else if (c <= 32) sort_small<32>(hi[0], lo[0], lane);
+        else sort_small<64>(hi[0], lo[0], lane);
+    } else {
+        bitonic_build<E, 64 * E>(hi, lo, lane);
+    }
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int e = lane * E + r;
+        if (e < keep) {
+            const bool valid = e < c;
+            onb[e] = valid ? (int32_t)~lo[r] : -1;
+            odist[e] = valid ? fminf(fmaxf(1.0f - sortable_f32(hi[r]), 0.f), 1.f) : INFINITY;
+        }
+    }
+    for (int e = 64 * E + lane; e < keep; e += 64) {
+        onb[e] = -1;
+        odist[e] = INFINITY;
+    }
+}
+
+__device__ __forceinline__ void filter_sort_store(const SelectArgs& a, const uint32_t* sel_u, const uint32_t* sel_id,
+                                                  uint32_t* f_u, uint32_t* f_lo, int carry, int64_t row, int lane) {
+    const float qmz = a.f_pmz[row];
+    const bool use_rt = a.f_rt != nullptr && a.f_rt_tol >= 0.0;
+    const float qrt = use_rt ? a.f_rt[row] : 0.f;
+    int c = 0;
+    for (int e0 = 0; e0 < carry; e0 += 64) {
+        const int e = e0 + lane;
+        bool ok = false;
+        uint32_t u = 0, id = 0;
+        if (e < carry) {
+            u = sel_u[e];
+            id = sel_id[e];
+            if ((int64_t)id != row) {
+                const float nmz = a.f_pmz[id];
+                const float diff = qmz - nmz;     // mass_diff(query, neighbour), the arithmetic of filter_kernel
+                const double md = a.f_is_da ? (double)diff : (double)(diff / nmz) * 1e6;
+                ok = fabs(md) <= a.f_tol;
+                if (ok && use_rt) ok = fabs((double)(qrt - a.f_rt[id])) <= a.f_rt_tol;
+            }
+        }
+        const uint64_t mask = __ballot(ok);
+        if (ok) {
+            const int w = c + __popcll(mask & ((1ull << lane) - 1ull));
+            f_u[w] = u;
+            f_lo[w] = ~id;
+        }
+        c += __popcll(mask);
+    }
+    __syncthreads();
+    int32_t* onb = a.nb_idx + row * a.f_keep;
+    float* odist = a.nb_dist + row * a.f_keep;
+    if (c <= 64) sort_and_store_nb<1>(f_u, f_lo, c, a.f_keep, lane, onb, odist);
+    else if (c <= 128) sort_and_store_nb<2>(f_u, f_lo, c, a.f_keep, lane, onb, odist);
+    else sort_and_store_nb<4>(f_u, f_lo, c, a.f_keep, lane, onb, odist);
+}
+
+template <int MODE, bool FUSE>
 __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     __shared__ uint32_t sel_u[FAL_MAX_K_ANN];
     __shared__ uint32_t sel_id[FAL_MAX_K_ANN];
@@ -413,11 +497,17 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     else if (qy.nc <= 512) carry = select_rounds<MODE, 8>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
     else carry = select_rounds<MODE, 16>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
 
-    float* osim = a.out_sim + out_row * k;
-    int32_t* oidx = a.out_idx + out_row * k;
-    if (k <= 64) sort_and_store<1>(sel_u, sel_id, carry, k, lane, osim, oidx);
-    else if (k <= 128) sort_and_store<2>(sel_u, sel_id, carry, k, lane, osim, oidx);
-    else sort_and_store<4>(sel_u, sel_id, carry, k, lane, osim, oidx);
+    if constexpr (FUSE) {
+        __shared__ uint32_t f_u[FAL_MAX_K_ANN];
+        __shared__ uint32_t f_lo[FAL_MAX_K_ANN];
+        filter_sort_store(a, sel_u, sel_id, f_u, f_lo, carry, out_row, lane);
+    } else {
+        float* osim = a.out_sim + out_row * k;
+        int32_t* oidx = a.out_idx + out_row * k;
+        if (k <= 64) sort_and_store<1>(sel_u, sel_id, carry, k, lane, osim, oidx);
+        else if (k <= 128) sort_and_store<2>(sel_u, sel_id, carry, k, lane, osim, oidx);
+        else sort_and_store<4>(sel_u, sel_id, carry, k, lane, osim, oidx);
+    }
 }
 
 int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks, hipStream_t on) {
@@ -426,10 +516,16 @@ int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_
     FAL_REQUIRE(n_blocks < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
     hipStream_t st = on ? on : ctx->stream;
     StageScope ts(ctx, stage, st);
-    if (mode == MODE_DENSE)
-        hipLaunchKernelGGL(select_kernel<MODE_DENSE>, dim3((unsigned)n_blocks), dim3(64), 0, st, a);
+    const bool fuse = a.nb_idx != nullptr;
+    if (fuse) FAL_REQUIRE(a.f_pmz && a.nb_dist && a.f_keep >= 1 && a.f_keep <= FAL_MAX_K_ANN, FAL_EINVAL, "fused filter: bad arguments");
+    if (mode == MODE_DENSE && fuse)
+        hipLaunchKernelGGL((select_kernel<MODE_DENSE, true>), dim3((unsigned)n_blocks), dim3(64), 0, st, a);
+    else if (mode == MODE_DENSE)
+        hipLaunchKernelGGL((select_kernel<MODE_DENSE, false>), dim3((unsigned)n_blocks), dim3(64), 0, st, a);
+    else if (fuse)
+        hipLaunchKernelGGL((select_kernel<MODE_IVF, true>), dim3((unsigned)n_blocks), dim3(64), 0, st, a);
     else
-        hipLaunchKernelGGL(select_kernel<MODE_IVF>, dim3((unsigned)n_blocks), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((select_kernel<MODE_IVF, false>), dim3((unsigned)n_blocks), dim3(64), 0, st, a);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

@@ -100,12 +100,30 @@ static size_t sims_capacity_floats() {
 
 using namespace fal;
 
-extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann, float* sim, int32_t* idx) {
+namespace {
+struct NeighborFilter {          // a8 fused into the final selection (scan.h SelectArgs::nb_idx)
+    const float* pmz;
+    const float* rt;
+    double tol, rt_tol;
+    int is_da, keep;
+    int32_t* nb_idx;
+    float* nb_dist;
+};
+
+void set_filter(SelectArgs& sa, const NeighborFilter* nf) {
+    if (!nf) return;
+    sa.f_pmz = nf->pmz; sa.f_rt = nf->rt; sa.f_tol = nf->tol; sa.f_rt_tol = nf->rt_tol;
+    sa.f_is_da = nf->is_da; sa.f_keep = nf->keep; sa.nb_idx = nf->nb_idx; sa.nb_dist = nf->nb_dist;
+}
+}  // namespace
+
+static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann, float* sim, int32_t* idx,
+                       const NeighborFilter* nf) {
     FAL_REQUIRE(ctx && ivf, FAL_EINVAL, "fal_ivf_search_topk: NULL ctx/ivf");
     FAL_REQUIRE(k_ann >= 1 && k_ann <= FAL_MAX_K_ANN, FAL_EUNSUPPORTED, "fal_ivf_search_topk: k_ann must be in [1, %d]", FAL_MAX_K_ANN);
     FAL_REQUIRE(n_probe >= 1 && n_probe <= FAL_MAX_N_PROBE, FAL_EUNSUPPORTED, "fal_ivf_search_topk: n_probe must be in [1, %d]", FAL_MAX_N_PROBE);
     if (ivf->n == 0) return FAL_OK;
-    FAL_REQUIRE(sim && idx, FAL_EINVAL, "fal_ivf_search_topk: NULL output");
+    FAL_REQUIRE(nf || (sim && idx), FAL_EINVAL, "fal_ivf_search_topk: NULL output");
     hipStream_t st = ctx->stream;
     const int d = ivf->d;
     const int64_t n_buckets = (int64_t)ivf->n_list.size();
@@ -275,6 +293,7 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         SelectArgs sa{};
         sa.sims = buf; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = jb; sa.n_jobs = nj; sa.tile_begin = 0; sa.ids_are_rows = 1;
+        set_filter(sa, nf);
         if (ov) {
             FAL_CHECK_HIP(hipEventRecord(ctx->ev_scan[b], st));
             FAL_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_scan[b], 0));
@@ -397,8 +416,26 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
         sa.sims = sims; sa.sims_base = base; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size(); sa.tile_begin = t0;
         sa.n_probe = np; sa.probes = probes; sa.list_off = ivf->list_off; sa.q_sim_off = q_sim_off; sa.perm = ivf->perm;
+        set_filter(sa, nf);
         FAL_TRY(launch_select(ctx, ST_SELECT, MODE_IVF, sa, (t1 - t0) * 32));
     }
     FAL_CHECK_HIP(hipStreamSynchronize(st));
     return FAL_OK;
+}
+
+extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann, float* sim, int32_t* idx) {
+    return search_impl(ctx, ivf, n_probe, k_ann, sim, idx, nullptr);
+}
+
+extern "C" int fal_ivf_search_neighbors(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
+                                        const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
+                                        double rt_tol, int n_neighbors, int32_t* nb_idx, float* nb_dist) {
+    FAL_REQUIRE(ctx && ivf, FAL_EINVAL, "fal_ivf_search_neighbors: NULL ctx/ivf");
+    FAL_REQUIRE(n_neighbors >= 1 && n_neighbors <= FAL_MAX_K_ANN, FAL_EUNSUPPORTED,
+                "fal_ivf_search_neighbors: n_neighbors must be in [1, %d]", FAL_MAX_K_ANN);
+    if (ivf->n == 0) return FAL_OK;
+    FAL_REQUIRE(precursor_mz_sorted && nb_idx && nb_dist, FAL_EINVAL, "fal_ivf_search_neighbors: NULL array");
+    NeighborFilter nf{precursor_mz_sorted, rt_tol >= 0.0 ? rt_sorted : nullptr, tol, rt_tol, tol_is_da, n_neighbors, nb_idx, nb_dist};
+    ctx->stage_reset(ST_FILTER);
+    return search_impl(ctx, ivf, n_probe, k_ann, nullptr, nullptr, &nf);
 }

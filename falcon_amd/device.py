@@ -287,6 +287,19 @@ class IvfIndex:
               "fal_ivf_search_topk")
         return sim, idx
 
+    def search_neighbors(self, n_probe: int, k_ann: int, mz_sorted, rt_sorted, tol: float, mode: str, rt_tol,
+                         n_neighbors: int):
+        """a7 + a8 fused (`fal_ivf_search_neighbors`): -> nb_idx i32[n, n_neighbors] (pad -1), nb_dist f32 (pad +inf);
+        identical to `search` followed by `Context.filter_neighbors`."""
+        torch = _torch()
+        c = self.ctx
+        nb_idx = c.empty((self.n, n_neighbors), torch.int32)
+        nb_dist = c.empty((self.n, n_neighbors), torch.float32)
+        check(c.lib.fal_ivf_search_neighbors(c._h, self._h, int(n_probe), int(k_ann), c._p(mz_sorted), c._p(rt_sorted),
+                                             float(tol), int(mode == "Da"), -1.0 if rt_tol is None else float(rt_tol),
+                                             int(n_neighbors), c._p(nb_idx), c._p(nb_dist)), "fal_ivf_search_neighbors")
+        return nb_idx, nb_dist
+
 
 def get_dim(min_mz: float, max_mz: float, bin_size: float):
     """Reference spectrum.py:172-199 (float32 arithmetic), host side of the C ABI."""

@@ -147,6 +147,15 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
                          double tol, int tol_is_da, double rt_tol, int n_neighbors,
                          int32_t* nb_idx, float* nb_dist);
 
+/* ---- a7+a8 in one call: the same search with the neighbour filter applied to the k_ann
+ *          selected candidates inside the selection kernel (only the survivors are sorted;
+ *          the [n, k_ann] result never goes to HBM).  Output identical to
+ *          fal_ivf_search_topk followed by fal_filter_neighbors. ------------------ [dev] */
+int fal_ivf_search_neighbors(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
+                             const float* precursor_mz_sorted, const float* rt_sorted,
+                             double tol, int tol_is_da, double rt_tol, int n_neighbors,
+                             int32_t* nb_idx, float* nb_dist);
+
 /* ---- e   neighbour lists ELL -> CSR, ids shifted by id_offset to global rows: the
  *          payload of the one multi-GPU exchange step (all-gatherv of the
  *          sparse neighbour lists; the reference's per-block results are likewise

@@ -168,3 +168,33 @@ def test_vectorize_split16(ctx):
     assert np.array_equal(V[:, 0], hi) and np.array_equal(V[:, 1], lo)
     rec = V[:, 0].astype(np.float64) + V[:, 1].astype(np.float64) / 2048
     assert np.abs(rec - ref).max() < 3e-7
+
+
+@pytest.mark.parametrize("k_ann,keep,tol,mode,rt_tol", [
+    (128, 64, 20.0, "ppm", None),        # the bench configuration: a handful of survivors per row
+    (128, 64, 5.0, "Da", None),          # everything passes: > 64 survivors -> truncation to n_neighbors
+    (256, 200, 5.0, "Da", None),         # 4 keys per lane
+    (128, 5, 300.0, "ppm", 30.0),        # RT filter, tiny n_neighbors
+    (16, 64, 50.0, "ppm", None),         # n_neighbors > k_ann: padded rows
+])
+def test_search_neighbors_equals_search_then_filter(ctx, k_ann, keep, tol, mode, rt_tol):
+    """a7+a8 fused (`fal_ivf_search_neighbors`) == `fal_ivf_search_topk` -> `fal_filter_neighbors`, bit for bit,
+    on flat and IVF buckets (exact duplicates included: ties in similarity)."""
+    import torch
+    sizes, nlists = [1, 40, 700, 1500, 2600, 90], [1, 1, 1, 1, 8, 1]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(off[-1])
+    X = unit_vectors(n, 400, 11)
+    X[off[2]:off[2] + 6] = X[off[2]]
+    rng = np.random.default_rng(5)
+    mz = np.sort(500.0 + rng.random(n).astype(np.float32) * 0.05).astype(np.float32)    # ~100 ppm wide
+    rt = (rng.random(n) * 100).astype(np.float32)
+    idxr = ctx.ivf_build(torch.from_numpy(X).to(ctx.tdev), off, np.array(nlists, np.int32), kmeans_iters=3)
+    mz_d, rt_d = torch.from_numpy(mz).to(ctx.tdev), torch.from_numpy(rt).to(ctx.tdev)
+    sim, idx = idxr.search(4, k_ann)
+    e_idx, e_dist = ctx.filter_neighbors(sim, idx, mz_d, rt_d, tol, mode, rt_tol, keep)
+    g_idx, g_dist = idxr.search_neighbors(4, k_ann, mz_d, rt_d, tol, mode, rt_tol, keep)
+    e_idx, e_dist, g_idx, g_dist = (t.cpu().numpy() for t in (e_idx, e_dist, g_idx, g_dist))
+    assert (e_idx >= 0).sum() > 0
+    assert np.array_equal(g_idx, e_idx)
+    assert np.array_equal(g_dist.view(np.uint32), e_dist.view(np.uint32))
