@@ -8,6 +8,10 @@ namespace fal {
 enum { EPI_STORE = 0, EPI_ARGMAX = 1 };
 enum { MODE_DENSE = 0, MODE_IVF = 1 };
 
+// every sims buffer is allocated with this many floats of slack after its last row: the select kernel
+// reads whole 64*R-key rounds without bounds checks, the f16 scan parks idle waves' stores there
+constexpr size_t kSimsSlack = 2048;
+
 struct SelectArgs {
     const float* sims;       // sims buffer of the current batch
     int64_t sims_base;       // float index the buffer starts at
@@ -18,6 +22,7 @@ struct SelectArgs {
     const DenseJob* jobs;
     int n_jobs;
     int64_t tile_begin;
+    const int32_t* tile_job; // [tiles of the launch] job of every tile (filled by launch_select)
     int ids_are_rows;        // ids = job.c_row0 + position (else position)
     // MODE_IVF: queries are the rows of IVF tiles (jobs: q_row0 = first list-order position of
     // the bucket, c_row0 = global id of its list 0, nc = its n_list)

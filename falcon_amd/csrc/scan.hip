@@ -8,6 +8,7 @@
 #include "common.h"
 #include "simtile.h"
 #include "scan.h"
+#include "ivf.h"
 
 namespace fal {
 
@@ -182,97 +183,147 @@ struct SelQuery {
     int64_t id0;          // MODE_DENSE: id = id0 + position
 };
 
+// One round of the selection: R*64 fresh keys from the query's sims row (slot s = i*64 + lane) plus, in
+// later rounds (CARRY), the survivors of the previous round.  Keep the k best: threshold by bitwise
+// search with ballot counts (early exit when a threshold isolates exactly k keys), ties at the
+// threshold by id, survivors compacted into LDS.  Returns how many were kept.
+//  * loads are unconditional and unclamped (the sims buffer has kSimsSlack floats of slack), so the R
+//    loads of a round are in flight together with immediate offsets;
+//  * MODE_DENSE ids are implicit (id0 + stream position): no id registers, none written until compaction.
+template <int MODE, int R, bool CARRY>
+__device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery& qy, int k, int lane, int64_t pos,
+                                            int fresh, int carry, uint32_t* sel_u, uint32_t* sel_id,
+                                            const int64_t* seg_off, const int64_t* seg_src) {
+    constexpr int E = FAL_MAX_K_ANN / 64;          // carried keys per lane
+    constexpr int G = MODE == MODE_DENSE ? 1 : R;
+    uint32_t u[R], gid[G], cu[E], cid[E];
+    const float* rl = qy.row + pos + lane;
+    float fv[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) fv[i] = rl[i * 64];
+    if (MODE != MODE_DENSE) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int64_t pp = min<int64_t>(pos + i * 64 + lane, qy.nc - 1);
+            int lo = 0, hi = a.n_probe - 1;          // last segment with seg_off <= pp
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
+            }
+            gid[i] = (uint32_t)(seg_src[lo] + (pp - seg_off[lo]));      // position in list order
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) gid[i] = (uint32_t)a.perm[gid[i]];
+    }
+    const uint32_t id_lane = (uint32_t)(qy.id0 + pos + lane);
+    auto id_of = [&](int i) -> uint32_t { return MODE == MODE_DENSE ? id_lane + (uint32_t)(i * 64) : gid[MODE == MODE_DENSE ? 0 : i]; };
+#pragma unroll
+    for (int i = 0; i < R; ++i) u[i] = (i * 64 + lane < fresh) ? max(f32_sortable(fv[i]), 1u) : 0u;
+    if (CARRY) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int e = j * 64 + lane;
+            cu[j] = e < carry ? sel_u[e] : 0u;
+            cid[j] = sel_id[e];
+        }
+        __syncthreads();             // all reads of sel_* done before they are rewritten
+    }
+    const int m = carry + fresh;
+
+    uint32_t T = 1, I = 0xFFFFFFFFu;
+    if (m > k) {
+        // largest T with count(key >= T) >= k
+        T = 0;
+        bool exact = false;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t c = T | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) cnt += wave_count(u[i] >= c);
+            if (CARRY) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) cnt += wave_count(cu[j] >= c);
+            }
+            if (cnt >= k) T = c;
+            if (cnt == k) {
+                exact = true;
+                break;
+            }
+        }
+        if (!exact) {
+            int gt = 0, eq = 0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                gt += wave_count(u[i] > T);
+                eq += wave_count(u[i] == T);
+            }
+            if (CARRY) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    gt += wave_count(cu[j] > T);
+                    eq += wave_count(cu[j] == T);
+                }
+            }
+            const int need = k - gt;
+            if (eq > need) {
+                uint32_t lo = 0;      // largest value with count(key == T && id < lo) < need
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t c = lo | (1u << bit);
+                    int cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < R; ++i) cnt += wave_count(u[i] == T && id_of(i) < c);
+                    if (CARRY) {
+#pragma unroll
+                        for (int j = 0; j < E; ++j) cnt += wave_count(cu[j] == T && cid[j] < c);
+                    }
+                    if (cnt < need) lo = c;
+                }
+                I = lo;
+            }
+        }
+    }
+    // ---- compact survivors into LDS ------------------------------------------------------
+    int base = 0;
+    if (CARRY) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool keep = cu[j] != 0 && ((cu[j] > T) || (cu[j] == T && cid[j] <= I));
+            const uint64_t mask = __ballot(keep);
+            if (keep) {
+                const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
+                sel_u[w] = cu[j];
+                sel_id[w] = cid[j];
+            }
+            base += __popcll(mask);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const bool keep = u[i] != 0 && ((u[i] > T) || (u[i] == T && id_of(i) <= I));
+        const uint64_t mask = __ballot(keep);
+        if (keep) {
+            const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
+            sel_u[w] = u[i];
+            sel_id[w] = id_of(i);
+        }
+        base += __popcll(mask);
+    }
+    return base;
+}
+
 template <int MODE, int R>
 __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery& qy, int k, int lane,
                                              uint32_t* sel_u, uint32_t* sel_id, const int64_t* seg_off,
                                              const int64_t* seg_src) {
-    uint32_t u[R], id[R];
-    int carry = 0;
-    int64_t pos = 0;
-    bool first = true;
-    while (first || pos < qy.nc) {
-        first = false;
-        // ---- fill: slot s = i*64 + lane; the first `carry` slots come from LDS ---------------
-        const int64_t fresh = min<int64_t>(qy.nc - pos, 64 * R - carry);
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int s = i * 64 + lane;
-            u[i] = 0;
-            id[i] = 0xFFFFFFFFu;
-            if (s < carry) {
-                u[i] = sel_u[s];
-                id[i] = sel_id[s];
-            } else if (s - carry < fresh) {
-                const int64_t pp = pos + (s - carry);
-                u[i] = max(f32_sortable(qy.row[pp]), 1u);
-                if (MODE == MODE_DENSE) {
-                    id[i] = (uint32_t)(qy.id0 + pp);
-                } else {
-                    int lo = 0, hi = a.n_probe - 1;      // last segment with seg_off <= pp
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
-                    }
-                    id[i] = (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])];
-                }
-            }
+    int fresh = (int)min<int64_t>(qy.nc, 64 * R);
+    int carry = select_round<MODE, R, false>(a, qy, k, lane, 0, fresh, 0, sel_u, sel_id, seg_off, seg_src);
+    __syncthreads();
+    if constexpr (R == 16) {         // more than 1024 candidates: further rounds carry the survivors along
+        for (int64_t pos = fresh; pos < qy.nc; pos += fresh) {
+            fresh = (int)min<int64_t>(qy.nc - pos, 64 * R);
+            carry = select_round<MODE, R, true>(a, qy, k, lane, pos, fresh, carry, sel_u, sel_id, seg_off, seg_src);
+            __syncthreads();
         }
-        const int m = carry + (int)fresh;
-        pos += fresh;
-        __syncthreads();   // all reads of sel_* done before they are rewritten
-
-        uint32_t T = 1, I = 0xFFFFFFFFu;
-        if (m > k) {
-            // largest T with count(u >= T) >= k; stop early when a threshold isolates exactly k keys
-            T = 0;
-            bool exact = false;
-            for (int bit = 31; bit >= 0; --bit) {
-                const uint32_t c = T | (1u << bit);
-                int cnt = 0;
-#pragma unroll
-                for (int i = 0; i < R; ++i) cnt += wave_count(u[i] >= c);
-                if (cnt >= k) T = c;
-                if (cnt == k) {
-                    exact = true;
-                    break;
-                }
-            }
-            if (!exact) {
-                int gt = 0, eq = 0;
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    gt += wave_count(u[i] > T);
-                    eq += wave_count(u[i] == T);
-                }
-                const int need = k - gt;
-                if (eq > need) {
-                    uint32_t lo = 0;      // largest value with count(u == T && id < lo) < need
-                    for (int bit = 31; bit >= 0; --bit) {
-                        const uint32_t c = lo | (1u << bit);
-                        int cnt = 0;
-#pragma unroll
-                        for (int i = 0; i < R; ++i) cnt += wave_count(u[i] == T && id[i] < c);
-                        if (cnt < need) lo = c;
-                    }
-                    I = lo;
-                }
-            }
-        }
-        // ---- compact survivors into LDS --------------------------------------------------
-        int base = 0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const bool keep = u[i] != 0 && ((u[i] > T) || (u[i] == T && id[i] <= I));
-            const uint64_t mask = __ballot(keep);
-            if (keep) {
-                const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
-                sel_u[w] = u[i];
-                sel_id[w] = id[i];
-            }
-            base += __popcll(mask);
-        }
-        carry = base;
-        __syncthreads();
     }
     return carry;
 }
@@ -458,7 +509,7 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     int64_t out_row = 0;
     const int64_t t = a.tile_begin + (blockIdx.x >> 5);
     const int ql = blockIdx.x & 31;
-    const DenseJob job = a.jobs[find_job(a.jobs, a.n_jobs, t)];
+    const DenseJob job = a.jobs[a.tile_job[blockIdx.x >> 5]];
     const int lt = (int)(t - job.tile0);
     if (32 * lt + ql >= job.nq) return;
     if (MODE == MODE_DENSE) {
@@ -493,8 +544,11 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     }
 
     int carry;
-    if (qy.nc <= 256) carry = select_rounds<MODE, 4>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
+    if (qy.nc <= 128) carry = select_rounds<MODE, 2>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
+    else if (qy.nc <= 256) carry = select_rounds<MODE, 4>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
+    else if (qy.nc <= 384) carry = select_rounds<MODE, 6>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
     else if (qy.nc <= 512) carry = select_rounds<MODE, 8>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
+    else if (qy.nc <= 768) carry = select_rounds<MODE, 12>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
     else carry = select_rounds<MODE, 16>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
 
     if constexpr (FUSE) {
@@ -510,8 +564,24 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     }
 }
 
-int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a, int64_t n_blocks, hipStream_t on) {
+__global__ void tile_job_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t tile_begin, int64_t n_tiles,
+                                int32_t* __restrict__ tile_job) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n_tiles) tile_job[i] = find_job(jobs, n_jobs, tile_begin + i);
+}
+
+int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a_in, int64_t n_blocks, hipStream_t on) {
     if (n_blocks <= 0) return FAL_OK;
+    SelectArgs a = a_in;
+    {
+        // tile -> job once per tile instead of a binary search in every query's workgroup
+        const int64_t n_tiles = n_blocks / 32;
+        int32_t* tj = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)std::max<int64_t>(n_tiles, 1 << 16), (void**)&tj));
+        hipLaunchKernelGGL(tile_job_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, on ? on : ctx->stream, a.jobs,
+                           a.n_jobs, a.tile_begin, n_tiles, tj);
+        a.tile_job = tj;
+    }
     FAL_REQUIRE(a.k >= 1 && a.k <= FAL_MAX_K_ANN, FAL_EUNSUPPORTED, "k must be in [1, %d]", FAL_MAX_K_ANN);
     FAL_REQUIRE(n_blocks < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
     hipStream_t st = on ? on : ctx->stream;

@@ -264,14 +264,14 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     }
     float* sims = nullptr;
     const size_t sims_floats = std::max(need_flat, need_coarse);
-    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (sims_floats + 320), (void**)&sims));   // + sink for scan16
+    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (sims_floats + kSimsSlack), (void**)&sims));   // slack: scan16 sink, select over-reads
     // scan || select: the top-k select of batch i runs on the auxiliary stream out of buffer i & 1 while
     // the (matrix-pipe bound) scan of batch i + 1 fills the other buffer on the main stream
     static const bool overlap = getenv("FALCON_OVERLAP") != nullptr;   // measured: no gain (the scan stretches), opt-in
     float* sims2 = sims;
     if (overlap && flat_batches.size() > 1) {
         FAL_TRY(ctx->ensure_aux());
-        FAL_TRY(ctx->reserve(SLOT_SIMS2, sizeof(float) * (need_flat + 320), (void**)&sims2));
+        FAL_TRY(ctx->reserve(SLOT_SIMS2, sizeof(float) * (need_flat + kSimsSlack), (void**)&sims2));
     }
     const bool ov = sims2 != sims;
     bool sel_pending[2] = {false, false};
@@ -400,7 +400,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     ctx->counters[0] += qoff[(size_t)ivf_tiles];
     ctx->counters[2] += (int64_t)ivf_batches.size();
     ctx->counters[3] = std::max<int64_t>(ctx->counters[3], (int64_t)(sizeof(float) * need_fine));
-    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (need_fine + 64), (void**)&sims));
+    FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (need_fine + kSimsSlack), (void**)&sims));
     for (const IvfBatch& bt : ivf_batches) {
         const DenseJob &first = coarse[bt.j0], &last = coarse[bt.j1 - 1];
         const int64_t t0 = first.tile0, t1 = last.tile0 + ceil_div(last.nq, 32);
