@@ -319,9 +319,10 @@ __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery
     int carry = select_round<MODE, R, false>(a, qy, k, lane, 0, fresh, 0, sel_u, sel_id, seg_off, seg_src);
     __syncthreads();
     if constexpr (R == 16) {         // more than 1024 candidates: further rounds carry the survivors along
+        constexpr int RC = 8;        // (fewer fresh keys per round: the carried keys' registers come on top)
         for (int64_t pos = fresh; pos < qy.nc; pos += fresh) {
-            fresh = (int)min<int64_t>(qy.nc - pos, 64 * R);
-            carry = select_round<MODE, R, true>(a, qy, k, lane, pos, fresh, carry, sel_u, sel_id, seg_off, seg_src);
+            fresh = (int)min<int64_t>(qy.nc - pos, 64 * RC);
+            carry = select_round<MODE, RC, true>(a, qy, k, lane, pos, fresh, carry, sel_u, sel_id, seg_off, seg_src);
             __syncthreads();
         }
     }
