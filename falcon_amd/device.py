@@ -183,6 +183,39 @@ class Context:
                                             self._p(nb_idx), self._p(nb_dist)), "fal_filter_neighbors")
         return nb_idx, nb_dist
 
+    SCALING = {None: 0, "off": 0, "root": 1, "log": 2, "rank": 3}
+
+    def process_spectra(self, mz, intensity, indptr, precursor_mz, precursor_charge, min_peaks: int,
+                        min_mz_range: float, mz_min=None, mz_max=None, remove_precursor_tolerance=None,
+                        min_intensity=None, max_peaks_used=None, scaling=None):
+        """f1 (`fal_process_spectra`): batch `process_spectrum` (reference spectrum.py:73-169) over raw CSR peaks
+        (mz float64 sorted per spectrum, intensity float32, charge 0 = unknown).
+        -> valid bool[n], out_indptr i64[n+1], out_mz f32[nnz_out], out_intensity f32[nnz_out] (device tensors)."""
+        torch = _torch()
+        mz = self.to_dev(mz, torch.float64)
+        intensity = self.to_dev(intensity, torch.float32)
+        indptr = self.to_dev(indptr, torch.int64)
+        pmz = self.to_dev(precursor_mz, torch.float64)
+        charge = self.to_dev(precursor_charge, torch.int32)
+        n, nnz = indptr.numel() - 1, mz.numel()
+        if scaling not in self.SCALING:
+            raise ValueError(f"unknown scaling {scaling!r}")
+        valid = self.empty((n,), torch.int32)
+        out_indptr = self.empty((n + 1,), torch.int64)
+        out_mz = self.empty((max(nnz, 1),), torch.float32)
+        out_it = self.empty((max(nnz, 1),), torch.float32)
+        nan = float("nan")
+        check(self.lib.fal_process_spectra(
+            self._h, self._p(mz), self._p(intensity), self._p(indptr), n, nnz, self._p(pmz), self._p(charge),
+            int(min_peaks), float(min_mz_range), nan if mz_min is None else float(mz_min),
+            nan if mz_max is None else float(mz_max),
+            -1.0 if remove_precursor_tolerance is None else float(remove_precursor_tolerance),
+            -1.0 if min_intensity is None else float(min_intensity), 0 if max_peaks_used is None else int(max_peaks_used),
+            self.SCALING[scaling], self._p(valid), self._p(out_indptr), self._p(out_mz), self._p(out_it)),
+            "fal_process_spectra")
+        nnz_out = int(out_indptr[-1].item())
+        return valid.bool(), out_indptr, out_mz[:nnz_out], out_it[:nnz_out]
+
     def neighbors_to_csr(self, nb_idx, nb_dist, id_offset: int = 0, out=None, row0: int = 0):
         """ELL neighbour lists -> CSR (indptr i64[rows+1], idx i32[cap], dist f32[cap]); entries beyond
         indptr[-1] are unspecified.  `out` = (indptr, idx, dist) buffers to fill; with `row0` > 0 the call

@@ -5,8 +5,9 @@ read peak files, preprocess, cluster every precursor charge independently throug
 (+ optional `<out>.mgf` of cluster representatives).
 
 Differences kept deliberately small and listed in DESIGN.md: spectra are held in memory /
-`.npz` files in `work_dir` instead of Lance datasets (lance is not available), and only
-MGF input is built (mzML / mzXML are host XML parsing, out of scope).
+`.npz` files in `work_dir` instead of Lance datasets (lance is not available), only MGF input is built
+(mzML / mzXML are host XML parsing, out of scope), and `process_spectrum` runs as one batched device call
+per peak file (`fal_process_spectra`) instead of a Python loop over spectra.
 """
 from __future__ import annotations
 
@@ -105,19 +106,19 @@ def _run(args) -> int:
     if config.overwrite:
         for fn in os.listdir(spectra_dir):
             os.remove(os.path.join(spectra_dir, fn))
+    pipe = cluster.ClusterPipeline(device=config.device)
     charge_path = os.path.join(spectra_dir, "charges.json")
     if os.path.isfile(charge_path) and not config.overwrite:                                   # falcon.py:143-149
         with open(charge_path) as f:
             charges = json.load(f)
     else:
-        charges = _prepare_spectra(spectra_dir, min_mz, max_mz)
+        charges = _prepare_spectra(spectra_dir, min_mz, max_mz, pipe.ctx)
         with open(charge_path, "w") as f:
             json.dump(charges, f)
 
     ann = cluster.AnnParams(eps=config.eps, low_dim=config.low_dim, n_probe=config.n_probe,
                             n_neighbors=config.n_neighbors, n_neighbors_ann=config.n_neighbors_ann,
                             mz_interval=config.mz_interval, min_mz=config.min_mz, max_mz=config.max_mz)
-    pipe = cluster.ClusterPipeline(device=config.device)
     rows_all, current_label, representatives = [], 0, []
     for charge in charges:                                                                     # falcon.py:153
         part = np.load(os.path.join(spectra_dir, f"spectra_charge_{charge}.npz"), allow_pickle=True)
@@ -162,39 +163,77 @@ def _run(args) -> int:
     return 0
 
 
-def _prepare_spectra(spectra_dir: str, min_mz: float, max_mz: float) -> List[str]:
-    """falcon.py:247-328, in memory: read + preprocess every peak file, partition by precursor
-    charge, store one CSR `.npz` per charge."""
+def _raw_csr(specs):
+    """spectra read from one peak file -> raw CSR (peaks sorted by m/z inside every spectrum, which is
+    what spectrum_utils does when the reference constructs an MsmsSpectrum)."""
+    sizes = np.array([len(s["mz"]) for s in specs], np.int64)
+    indptr = np.zeros(len(specs) + 1, np.int64)
+    np.cumsum(sizes, out=indptr[1:])
+    mz = np.concatenate([np.asarray(s["mz"], np.float64) for s in specs]) if len(specs) else np.zeros(0)
+    it = np.concatenate([np.asarray(s["intensity"], np.float32) for s in specs]) if len(specs) else np.zeros(0, np.float32)
+    order = np.lexsort((mz, np.repeat(np.arange(len(specs)), sizes)))
+    return mz[order], it[order], indptr
+
+
+def _take_rows(indptr: np.ndarray, rows: np.ndarray):
+    """positions of the peaks of `rows` in CSR order, and the CSR offsets of the selection"""
+    cnt = indptr[rows + 1] - indptr[rows]
+    out = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum(cnt, out=out[1:])
+    pos = np.repeat(indptr[rows] - out[:-1], cnt) + np.arange(out[-1])
+    return pos, out
+
+
+def _prepare_spectra(spectra_dir: str, min_mz: float, max_mz: float, ctx) -> List[str]:
+    """falcon.py:247-328: read every peak file, preprocess (`process_spectrum`, spectrum.py:73-169 -- here one
+    `fal_process_spectra` call per file on the GPU), partition by precursor charge, one CSR `.npz` per charge."""
     filenames = [fn for pattern in config.input_filenames for fn in glob.glob(pattern)]
     logger.info("Read spectra from %d peak file(s)", len(filenames))
-    by_charge: Dict[str, List[dict]] = {}
+    parts: Dict[str, Dict[str, list]] = {}
     low_quality = 0
     for fn in filenames:
         fn = os.path.abspath(fn)
-        for spec in ms_io.get_spectra(fn):
-            spec["filename"] = fn
-            out = spectrum.process_spectrum(
-                spec, config.min_peaks, config.min_mz_range, min_mz, max_mz, config.remove_precursor_tol,
-                config.min_intensity, config.max_peaks_used, None if config.scaling == "off" else config.scaling)
-            if out is None:
-                low_quality += 1
-            else:
-                by_charge.setdefault(str(out["precursor_charge"]), []).append(out)
+        specs = list(ms_io.get_spectra(fn))
+        if not specs:
+            continue
+        mz, it, indptr = _raw_csr(specs)
+        pmz = np.array([s["precursor_mz"] for s in specs], np.float64)
+        charge = np.array([int(s["precursor_charge"]) if s.get("precursor_charge") else 0 for s in specs], np.int32)
+        valid, oip, omz, oit = ctx.process_spectra(
+            mz, it, indptr, pmz, charge, config.min_peaks, config.min_mz_range, min_mz, max_mz,
+            config.remove_precursor_tol, config.min_intensity, config.max_peaks_used,
+            None if config.scaling == "off" else config.scaling)
+        valid, oip, omz, oit = valid.cpu().numpy(), oip.cpu().numpy(), omz.cpu().numpy(), oit.cpu().numpy()
+        low_quality += int((~valid).sum())
+        ident = np.array([s["identifier"] for s in specs], dtype=object)
+        rt = np.array([s.get("retention_time", -1) for s in specs], np.float32)
+        for z in np.unique(charge[valid]):
+            rows = np.flatnonzero(valid & (charge == z))
+            pos, off = _take_rows(oip, rows)
+            p = parts.setdefault("None" if z == 0 else str(int(z)),
+                                 dict(identifier=[], filename=[], precursor_mz=[], retention_time=[], mz=[], intensity=[],
+                                      counts=[]))
+            p["identifier"].append(ident[rows])
+            p["filename"].append(np.array([fn] * len(rows), dtype=object))
+            p["precursor_mz"].append(pmz[rows].astype(np.float32))
+            p["retention_time"].append(rt[rows])
+            p["mz"].append(omz[pos])
+            p["intensity"].append(oit[pos])
+            p["counts"].append(np.diff(off))
     n_total = 0
-    for charge, specs in by_charge.items():
-        indptr = np.zeros(len(specs) + 1, np.int64)
-        np.cumsum([len(s["mz"]) for s in specs], out=indptr[1:])
+    for charge, p in parts.items():
+        counts = np.concatenate(p["counts"])
+        indptr = np.zeros(len(counts) + 1, np.int64)
+        np.cumsum(counts, out=indptr[1:])
         np.savez(os.path.join(spectra_dir, f"spectra_charge_{charge}.npz"),
-                 identifier=np.array([s["identifier"] for s in specs], dtype=object),
-                 filename=np.array([s["filename"] for s in specs], dtype=object),
-                 precursor_mz=np.array([s["precursor_mz"] for s in specs], np.float32),
-                 retention_time=np.array([s["retention_time"] for s in specs], np.float32),
-                 mz=np.concatenate([s["mz"] for s in specs]).astype(np.float32),
-                 intensity=np.concatenate([s["intensity"] for s in specs]).astype(np.float32), indptr=indptr)
-        n_total += len(specs)
+                 identifier=np.concatenate(p["identifier"]), filename=np.concatenate(p["filename"]),
+                 precursor_mz=np.concatenate(p["precursor_mz"]), retention_time=np.concatenate(p["retention_time"]),
+                 mz=np.concatenate(p["mz"]).astype(np.float32), intensity=np.concatenate(p["intensity"]).astype(np.float32),
+                 indptr=indptr)
+        n_total += len(counts)
     logger.info("Read %d spectra from %d peak files", n_total, len(filenames))
     logger.info("Skipped %d low-quality spectra", low_quality)
-    return sorted(by_charge, key=_natural_key)
+    return sorted(parts, key=_natural_key)
 
 
 def _write_cluster_info(rows) -> None:

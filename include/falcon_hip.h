@@ -202,6 +202,24 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
                       int32_t* labels_sorted_scratch, int32_t* labels_out, int32_t* medoids_out,
                       int64_t* n_clusters /*[host]*/, int64_t* n_labels /*[host]*/);
 
+/* ---- f1  spectrum preprocessing, the step in front of the path: reference
+ *          spectrum.py:73-169 `process_spectrum` over a CSR of raw peaks (m/z float64
+ *          sorted per spectrum, intensity float32): m/z range cut (135), precursor-peak
+ *          removal for charge states z..1 (139-149; charge 0 = unknown -> 1), base-peak
+ *          intensity filter + the max_peaks_used most intense (151-155), validity check
+ *          after every step (27-52), scaling 0 none / 1 root / 2 log / 3 rank (157), L2
+ *          normalisation (55-70, 158).  Unset options: mz_min / mz_max = NaN,
+ *          remove_precursor_tol < 0, min_intensity < 0, max_peaks_used = 0.
+ *          valid_out i32[n]; out_indptr i64[n+1] (invalid spectra hold 0 peaks);
+ *          out_mz / out_intensity f32 with room for nnz peaks. ---------------- [dev] */
+int fal_process_spectra(fal_ctx* ctx, const double* mz, const float* intensity,
+                        const int64_t* indptr, int64_t n, int64_t nnz,
+                        const double* precursor_mz, const int32_t* precursor_charge,
+                        int min_peaks, double min_mz_range, double mz_min, double mz_max,
+                        double remove_precursor_tol, double min_intensity, int max_peaks_used,
+                        int scaling, int32_t* valid_out, int64_t* out_indptr, float* out_mz,
+                        float* out_intensity);
+
 /* ---- sort by precursor m/z (reference cluster.py:73-85 `.sort_values`): stable.
  *          order_out i64[n] (dataset row of sorted position), mz_sorted_out f32[n]. [dev] */
 int fal_sort_by_precursor(fal_ctx* ctx, const float* precursor_mz, int64_t n,

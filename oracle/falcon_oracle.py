@@ -16,6 +16,10 @@ Pinning status (see DESIGN.md "Oracle"):
     reference's `to_vector` driven with a hash projection matrix (same .npz).
   * a9 (DBSCAN) is pinned against scikit-learn's DBSCAN on sparse precomputed
     graphs (tests/golden/sklearn_dbscan.npz).
+  * f1 (`process_spectra`, the preprocessing step in front of the path, spectrum.py:73-169):
+    the spectrum_utils 0.3.5 calls it makes are an absent dependency (setup.cfg:20-34);
+    restated from SURVEY Appendix B.  PARITY UNPINNED; cross-checked against the host
+    implementation `falcon_amd.cluster.spectrum.process_spectrum`.
   * a6/a7 (IVF build, n_probe search): the reference snapshot contains NO
     implementation (Faiss is an un-vendored dependency, setup.cfg:25, and the call
     sites are gone -- SURVEY section 0).  PARITY UNPINNED for the index itself; the
@@ -675,3 +679,82 @@ def generate_clusters(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
         return labels, medoids, dict(order=order, X=X, splits=splits, sim=sim, idx=idx,
                                      nb_idx=nb_idx, nb_dist=nb_dist, db=db, lab_sorted=lab_sorted)
     return labels, medoids
+
+
+# --------------------------------------------------------------------------- f1
+PROTON = 1.0072766
+
+
+def process_spectra(mz: np.ndarray, intensity: np.ndarray, indptr: np.ndarray, precursor_mz: np.ndarray,
+                    precursor_charge: np.ndarray, min_peaks: int, min_mz_range: float, mz_min: Optional[float] = None,
+                    mz_max: Optional[float] = None, remove_precursor_tolerance: Optional[float] = None,
+                    min_intensity: Optional[float] = None, max_peaks_used: Optional[int] = None,
+                    scaling: Optional[str] = None):
+    """Batch restatement of `process_spectrum` (reference spectrum.py:73-169) over a CSR of raw peaks
+    (mz float64, sorted per spectrum; intensity float32; charge 0 = unknown).
+
+    -> valid bool[n], out_indptr i64[n+1] (invalid spectra hold 0 peaks), out_mz f32, out_intensity f32.
+
+    Conventions where the reference leaves arithmetic open (PARITY UNPINNED): m/z comparisons in float64;
+    the base-peak threshold `min_intensity * max` in float32; top-`max_peaks_used` ties keep the lower m/z;
+    sqrt / log2 computed in float64 and rounded to float32; the L2 norm = (float32)sqrt(l2_norm_sq_tree)
+    and a float32 divide.
+    """
+    n = len(indptr) - 1
+    valid = np.zeros(n, bool)
+    out_mz, out_it, counts = [], [], np.zeros(n, np.int64)
+
+    def ok(m):                                                     # spectrum.py:27-52
+        return len(m) >= max(min_peaks, 1) and (m.max() - m.min()) >= min_mz_range
+
+    for i in range(n):
+        m = np.asarray(mz[indptr[i]:indptr[i + 1]], f64)
+        it = np.asarray(intensity[indptr[i]:indptr[i + 1]], f32)
+        keep = np.ones(len(m), bool)                               # set_mz_range (spectrum.py:135)
+        if mz_min is not None:
+            keep &= m >= mz_min
+        if mz_max is not None:
+            keep &= m <= mz_max
+        m, it = m[keep], it[keep]
+        if not ok(m):
+            continue
+        if remove_precursor_tolerance is not None:                 # spectrum.py:139-149
+            z = abs(int(precursor_charge[i])) if precursor_charge[i] != 0 else 1
+            neutral = (f64(precursor_mz[i]) - f64(PROTON)) * f64(z)
+            keep = np.ones(len(m), bool)
+            for c in range(z, 0, -1):
+                keep &= np.abs(m - (neutral / f64(c) + f64(PROTON))) > remove_precursor_tolerance
+            m, it = m[keep], it[keep]
+            if not ok(m):
+                continue
+        if min_intensity is not None or max_peaks_used is not None:   # spectrum.py:151-155
+            mi = f32(0.0 if min_intensity is None else min_intensity)
+            keep = it >= f32(mi * it.max())
+            if max_peaks_used is not None and keep.sum() > max_peaks_used:
+                idx = np.flatnonzero(keep)
+                top = idx[np.argsort(-it[idx], kind="stable")[:max_peaks_used]]
+                keep = np.zeros(len(m), bool)
+                keep[top] = True
+            m, it = m[keep], it[keep]
+            if not ok(m):
+                continue
+        k = len(it)
+        if scaling == "root":                                      # spectrum.py:157
+            it = np.sqrt(it.astype(f64)).astype(f32)
+        elif scaling == "log":
+            it = np.log2((f32(1.0) + it).astype(f64)).astype(f32)
+        elif scaling == "rank":
+            max_rank = max_peaks_used if max_peaks_used is not None else k
+            ranks = np.empty(k, np.int64)
+            ranks[np.argsort(it, kind="stable")] = np.arange(1, k + 1)
+            it = (max_rank - (k - ranks)).astype(f32)
+        nrm = f32(np.sqrt(l2_norm_sq_tree(it[None, :])[0]))        # spectrum.py:55-70, 158
+        with np.errstate(divide="ignore", invalid="ignore"):
+            it = (it / nrm).astype(f32)
+        valid[i] = True
+        counts[i] = k
+        out_mz.append(m.astype(f32))
+        out_it.append(it)
+    out_indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, f32)
+    return valid, out_indptr, cat(out_mz), cat(out_it)

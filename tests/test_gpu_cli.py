@@ -56,3 +56,40 @@ def test_main_mgf_to_csv(tmp_path):
     # outputs exist -> a second run without --overwrite aborts with 1 (falcon.py:120-122)
     assert main(args) == 1
     assert main(args + ["--overwrite"]) == 0
+
+
+def test_main_preprocesses_raw_spectra_on_the_device(tmp_path):
+    """raw MGF peaks (outside the m/z window, on the precursor ions, below 1 % of the base peak, > 50 peaks) go
+    through `fal_process_spectra` inside main(); what lands in work_dir equals the host `process_spectrum`."""
+    from falcon_amd.cluster.spectrum import get_dim, process_spectrum
+    from falcon_amd.falcon import main
+    from falcon_amd.ms_io import ms_io
+    from tests.prep_cases import raw_spectra
+    mz, it, indptr, pmz, ch = raw_spectra(400, 9, max_peaks=300)
+    ch[ch == 0] = 2                                         # (the MGF writer needs a charge)
+    specs = [{"identifier": f"s{i}", "precursor_mz": float(pmz[i]), "precursor_charge": int(ch[i]),
+              "retention_time": float(i), "mz": mz[indptr[i]:indptr[i + 1]], "intensity": it[indptr[i]:indptr[i + 1]]}
+             for i in range(400) if indptr[i + 1] > indptr[i]]
+    mgf = str(tmp_path / "raw.mgf")
+    ms_io.write_spectra(mgf, specs)
+    work = tmp_path / "work"
+    assert main([mgf, str(tmp_path / "out"), "--work_dir", str(work), "--scaling", "root"]) == 0
+    _, min_mz, max_mz = get_dim(101.0, 1500.0, 0.05)
+    expected = {}
+    for s in ms_io.get_spectra(mgf):                        # what the reader hands over (text round trip included)
+        out = process_spectrum(dict(s), 5, 250.0, min_mz, max_mz, 1.5, 0.01, 50, "root")
+        if out is not None:
+            expected[(str(out["precursor_charge"]), out["identifier"])] = out
+    seen = 0
+    for fn in os.listdir(work / "spectra"):
+        if not fn.endswith(".npz"):
+            continue
+        part = np.load(work / "spectra" / fn, allow_pickle=True)
+        charge = fn[len("spectra_charge_"):-4]
+        for r, ident in enumerate(part["identifier"]):
+            e = expected[(charge, str(ident))]
+            a, b = part["indptr"][r], part["indptr"][r + 1]
+            assert np.array_equal(part["mz"][a:b], e["mz"])
+            np.testing.assert_allclose(part["intensity"][a:b], e["intensity"], rtol=3e-6)
+            seen += 1
+    assert seen == len(expected) and 50 < seen < len(specs)
