@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--scan", choices=["f32", "f16x3"], default="f32",
                     help="flat-scan arithmetic: exact fp32 MFMA (default) or hi/lo float16 split on the f16 MFMA")
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32", help="vector dtype (f16 = BASELINE config 5)")
+    ap.add_argument("--rescore", action="store_true",
+                    help="re-score the neighbours with the matched-peak cosine before DBSCAN (SURVEY 8f-4; not the headline)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange step's device work (CSR packing, payload) at 1 GPU too (no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,7 +143,8 @@ def main():
     pipe = ClusterPipeline(ctx)
     runner = PartitionRunner(local_rank, 2) if args.overlap else None
     p = AnnParams(eps=args.eps, low_dim=args.low_dim, n_probe=args.n_probe, n_neighbors=args.n_neighbors,
-                  n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval, scan=args.scan, dtype=args.dtype)
+                  n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval, scan=args.scan, dtype=args.dtype,
+                  rescore=args.rescore, min_matches=6 if args.rescore else 0)
 
     # ---- this rank's shard: its own generator blocks, resident in HBM ------------------------
     blocks_per_rank = (args.spectra + synth.BLOCK - 1) // synth.BLOCK

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "fal_process_spectra": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_double,
                              c_double, c_double, c_double, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p,
                              c_void_p], c_int),
+    "fal_rescore_neighbors": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
+                               c_int], c_int),
     "fal_neighbors_to_csr": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
                              c_int),
     "fal_dbscan": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, P(c_int64)], c_int),

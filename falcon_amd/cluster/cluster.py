@@ -40,6 +40,9 @@ class AnnParams:
     dtype: str = "f32"            # "f32", or "f16": float16 vectors + f16 MFMA scan (BASELINE config 5)
     scan: str = "f32"             # flat-bucket scan arithmetic for float32 vectors: "f32" (exact fp32 MFMA) or
                                   # "f16x3" (hi/lo float16 split, 3 f16 MFMAs per step, ~3e-7 absolute error)
+    rescore: bool = False         # re-score the ANN neighbours with the reference's matched-peak cosine
+                                  # (similarity.py:17-80) before DBSCAN; uses fragment_tol and min_matches
+    min_matches: int = 0          # (set from generate_clusters' `min_matches` when rescore is on)
 
 
 def n_list_rule(sizes: np.ndarray, n_probe: int) -> np.ndarray:
@@ -131,6 +134,9 @@ class ClusterPipeline:
             # production: a7 + a8 in one call, the [n, k_ann] search result never goes to HBM
             nb_idx, nb_dist = index.search_neighbors(p.n_probe, p.n_neighbors_ann, mzs, rts, precursor_tol_mass,
                                                      precursor_tol_mode, rt_tol, p.n_neighbors)
+        if p.rescore:
+            nb_dist = c.rescore_neighbors(nb_idx, nb_dist, ds.mz, ds.intensity, ds.indptr, order, fragment_tol,
+                                          p.min_matches)
         if keep_intermediates:
             # staged calls (one C-ABI call per SURVEY 8a row) so that every intermediate can be inspected
             db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)
@@ -206,7 +212,8 @@ def generate_clusters(dataset, linkage: str, distance_threshold: float, min_matc
                       pipeline: Optional[ClusterPipeline] = None) -> Tuple[np.ndarray, np.ndarray]:
     """Same call as the reference (cluster.py:24-34).  `distance_threshold` is the cosine
     distance threshold and plays the role of DBSCAN's eps (README.md:73-79); `linkage` and
-    `min_matches` belong to the snapshot's exact-cosine path and are accepted but unused.
+    `min_matches` belong to the snapshot's exact-cosine path: `min_matches` is used when `ann.rescore` is on
+    (matched-peak re-scoring of the ANN neighbours, similarity.py:17-80), `linkage` is accepted but unused.
 
     Returns (labels int32[N] by dataset row with noise renumbered as singletons --
     cluster.py:144-155 --, medoids int32[n_labels]: medoids[c] = dataset row representing
@@ -219,6 +226,8 @@ def generate_clusters(dataset, linkage: str, distance_threshold: float, min_matc
     p = ann or AnnParams()
     if ann is None:
         p.eps = distance_threshold
+    if p.rescore:
+        p.min_matches = int(min_matches)
     pipe = pipeline or _default_pipeline
     if pipe is None:
         pipe = _default_pipeline = ClusterPipeline()

@@ -56,6 +56,9 @@ class Config:
         p.add_argument("--low_dim", type=int, default=400, help="Length of the hashed vectors.")
         p.add_argument("--mz_interval", type=float, default=1.0,
                        help="Width in m/z of the precursor windows that bound an index (0 = off).")
+        p.add_argument("--rescore", action="store_true",
+                       help="Re-score the nearest neighbours with the matched-peak cosine (fragment_tol, "
+                            "min_matched_peaks) before clustering.")
         p.add_argument("--device", type=int, default=0, help="HIP device ordinal.")
         # PREPROCESSING  (config.py:126-183)
         p.add_argument("--min_peaks", default=5, type=int)

@@ -216,6 +216,19 @@ class Context:
         nnz_out = int(out_indptr[-1].item())
         return valid.bool(), out_indptr, out_mz[:nnz_out], out_it[:nnz_out]
 
+    def rescore_neighbors(self, nb_idx, nb_dist, mz, intensity, indptr, order, fragment_tol: float, min_matches: int):
+        """f4 (`fal_rescore_neighbors`): nb_dist <- 1 - matched-peak cosine (reference similarity.py:17-80), in place."""
+        torch = _torch()
+        n, k = nb_idx.shape
+        mz = self.to_dev(mz, torch.float32)
+        intensity = self.to_dev(intensity, torch.float32)
+        indptr = self.to_dev(indptr, torch.int64)
+        order = self.to_dev(order, torch.int64)
+        check(self.lib.fal_rescore_neighbors(self._h, self._p(nb_idx), self._p(nb_dist), n, k, self._p(mz), self._p(intensity),
+                                             self._p(indptr), self._p(order), float(fragment_tol), int(min_matches)),
+              "fal_rescore_neighbors")
+        return nb_dist
+
     def neighbors_to_csr(self, nb_idx, nb_dist, id_offset: int = 0, out=None, row0: int = 0):
         """ELL neighbour lists -> CSR (indptr i64[rows+1], idx i32[cap], dist f32[cap]); entries beyond
         indptr[-1] are unspecified.  `out` = (indptr, idx, dist) buffers to fill; with `row0` > 0 the call

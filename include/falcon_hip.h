@@ -156,6 +156,18 @@ int fal_ivf_search_neighbors(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int 
                              double tol, int tol_is_da, double rt_tol, int n_neighbors,
                              int32_t* nb_idx, float* nb_dist);
 
+/* ---- f4  exact re-scoring of the stored neighbours with the matched-peak cosine the
+ *          reference ships: similarity.py:17-80 `cosine_fast` (pairs of peaks within
+ *          fragment_tol, optimal assignment, sum of the positive pair scores), used as
+ *          cluster.py:593-639 does: nb_dist = 1 - sim, sim = 0 when fewer than min_matches
+ *          peaks match.  In place on nb_dist; entry order is not changed.  mz / intensity /
+ *          indptr: the preprocessed spectra (dataset rows), row_order: sorted position ->
+ *          dataset row.  Synchronises (FAL_EUNSUPPORTED if more than 32 peaks of one
+ *          spectrum chain inside the tolerance). ------------------------------- [dev] */
+int fal_rescore_neighbors(fal_ctx* ctx, const int32_t* nb_idx, float* nb_dist, int64_t n, int k,
+                          const float* mz, const float* intensity, const int64_t* indptr,
+                          const int64_t* row_order, double fragment_tol, int min_matches);
+
 /* ---- e   neighbour lists ELL -> CSR, ids shifted by id_offset to global rows: the
  *          payload of the one multi-GPU exchange step (all-gatherv of the
  *          sparse neighbour lists; the reference's per-block results are likewise

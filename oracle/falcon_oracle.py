@@ -20,6 +20,8 @@ Pinning status (see DESIGN.md "Oracle"):
     the spectrum_utils 0.3.5 calls it makes are an absent dependency (setup.cfg:20-34);
     restated from SURVEY Appendix B.  PARITY UNPINNED; cross-checked against the host
     implementation `falcon_amd.cluster.spectrum.process_spectrum`.
+  * f4 (`cosine_fast`, similarity.py:17-80 -- the matched-peak cosine the snapshot ships) is pinned
+    against the reference's own function body (tests/golden/cosine_fast.npz, 320 pairs).
   * a6/a7 (IVF build, n_probe search): the reference snapshot contains NO
     implementation (Faiss is an un-vendored dependency, setup.cfg:25, and the call
     sites are gone -- SURVEY section 0).  PARITY UNPINNED for the index itself; the
@@ -758,3 +760,56 @@ def process_spectra(mz: np.ndarray, intensity: np.ndarray, indptr: np.ndarray, p
     out_indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, f32)
     return valid, out_indptr, cat(out_mz), cat(out_it)
+
+
+# --------------------------------------------------------------------------- f4
+def cosine_fast(mz_a: np.ndarray, it_a: np.ndarray, mz_b: np.ndarray, it_b: np.ndarray, tol: float) -> Tuple[float, int]:
+    """Matched-peak cosine of two spectra, reference similarity.py:17-80: every pair of peaks within the
+    fragment tolerance gets cost it_a * it_b (float32), the optimal assignment is taken
+    (`scipy.optimize.linear_sum_assignment`, maximize) and the positive pair scores are summed in row
+    order (float64).  -> (score clipped to [0, 1], number of matched peaks).  Arithmetic as numba types it:
+    `peak_mz - tol` in float64, `abs(peak_mz - other_mz)` in float32 compared against the float64 tolerance."""
+    import scipy.optimize
+    mz_a = np.asarray(mz_a, f32); mz_b = np.asarray(mz_b, f32)
+    it_a = np.asarray(it_a, f32); it_b = np.asarray(it_b, f32)
+    if len(mz_a) == 0 or len(mz_b) == 0:
+        return 0.0, 0
+    tol = f64(tol)
+    cost = np.zeros((len(mz_a), len(mz_b)), f32)
+    o = 0
+    for p in range(len(mz_a)):                                     # similarity.py:45-63
+        while o < len(mz_b) - 1 and f64(mz_a[p]) - tol > f64(mz_b[o]):
+            o += 1
+        q = o
+        while q < len(mz_b) and f64(abs(f32(mz_a[p] - mz_b[q]))) <= tol:
+            cost[p, q] = it_a[p] * it_b[q]
+            q += 1
+    rows, cols = scipy.optimize.linear_sum_assignment(cost, maximize=True)     # similarity.py:65-68
+    score, n_match = 0.0, 0
+    for r, c in zip(rows, cols):                                   # similarity.py:70-78
+        if cost[r, c] > 0.0:
+            score += float(cost[r, c])
+            n_match += 1
+    return max(0.0, min(score, 1.0)), n_match
+
+
+def rescore_neighbors(nb_idx: np.ndarray, nb_dist: np.ndarray, mz: np.ndarray, intensity: np.ndarray,
+                      indptr: np.ndarray, order: np.ndarray, tol: float, min_matches: int) -> np.ndarray:
+    """Exact re-scoring of the ANN neighbour lists: every stored neighbour's distance becomes
+    1 - cosine_fast(query, neighbour), or 1 when fewer than `min_matches` peaks match (reference
+    cluster.py:621-630).  Rows / ids are sorted positions; `order` maps them to dataset rows."""
+    out = nb_dist.copy()
+    n, k = nb_idx.shape
+    for i in range(n):
+        a = order[i]
+        for s in range(k):
+            j = nb_idx[i, s]
+            if j < 0:
+                continue
+            b = order[j]
+            sim, nm = cosine_fast(mz[indptr[a]:indptr[a + 1]], intensity[indptr[a]:indptr[a + 1]],
+                                  mz[indptr[b]:indptr[b + 1]], intensity[indptr[b]:indptr[b + 1]], tol)
+            if nm < min_matches:
+                sim = 0.0
+            out[i, s] = f32(1.0 - sim)
+    return out

@@ -313,6 +313,46 @@ def main():
     np.savez_compressed(os.path.join(HERE, "sklearn_dbscan.npz"), **db)
     print("wrote sklearn_dbscan.npz")
 
+    # ---- f4 cosine_fast (similarity.py:17-80): matched-peak cosine, optimal assignment ---------------
+    # pairs of spectra: jittered copies (inside / outside the tolerance), dense peak groups (several
+    # candidates inside one tolerance window -> assignment components larger than 1x1), empty spectra.
+    r2 = np.random.default_rng(4242)
+    cf = {k: [] for k in ("a_mz", "a_it", "b_mz", "b_it")}
+    a_ptr, b_ptr, tols, scores, nmatch = [0], [0], [], [], []
+    for case in range(320):
+        tol = float(r2.choice([0.05, 0.02, 0.5]))
+        p = int(r2.integers(0, 60)) if case % 9 else int(r2.integers(0, 3))
+        mz_a = np.sort(r2.uniform(101.0, 1500.0, p))
+        if p > 8 and case % 3 == 0:                          # groups of peaks closer than the tolerance
+            g = r2.integers(0, p - 4)
+            mz_a[g:g + 4] = mz_a[g] + np.sort(r2.uniform(0, 1.5 * tol, 4))
+            mz_a = np.sort(mz_a)
+        keep = r2.random(p) < 0.8
+        mz_b = mz_a[keep] + r2.choice([0.0, 0.3, 0.9, 1.0, 1.1, 3.0], keep.sum()) * tol * r2.choice([-1, 1], keep.sum())
+        mz_b = np.sort(np.concatenate([mz_b, r2.uniform(101.0, 1500.0, int(r2.integers(0, 10)))]))
+        it_a = r2.lognormal(0, 1, len(mz_a)); it_b = r2.lognormal(0, 1, len(mz_b))
+        if case % 11 == 0 and len(it_a) > 3:
+            it_a[:] = 1.0                                     # equal intensities: ties between assignments
+        it_a = (it_a / max(np.linalg.norm(it_a), 1e-30)).astype(f32)
+        it_b = (it_b / max(np.linalg.norm(it_b), 1e-30)).astype(f32)
+        mz_a = mz_a.astype(f32); mz_b = mz_b.astype(f32)
+        sa = similarity.SpectrumTuple(f32(500.0), 2, mz_a, it_a)
+        sb = similarity.SpectrumTuple(f32(500.0), 2, mz_b, it_b)
+        if len(mz_a) == 0 or len(mz_b) == 0:
+            sc, nm = 0.0, 0                                   # (the reference never scores an empty spectrum)
+        else:
+            # (np.float64 tolerance: numba types the Python float as float64; a bare Python float would be
+            #  a weak scalar under NumPy 2 and the comparisons would run in float32)
+            sc, nm = similarity.cosine_fast(sa, sb, np.float64(tol))
+        cf["a_mz"].append(mz_a); cf["a_it"].append(it_a); cf["b_mz"].append(mz_b); cf["b_it"].append(it_b)
+        a_ptr.append(a_ptr[-1] + len(mz_a)); b_ptr.append(b_ptr[-1] + len(mz_b))
+        tols.append(tol); scores.append(float(sc)); nmatch.append(int(nm))
+    np.savez_compressed(os.path.join(HERE, "cosine_fast.npz"),
+                        a_mz=np.concatenate(cf["a_mz"]), a_it=np.concatenate(cf["a_it"]), a_ptr=np.array(a_ptr, np.int64),
+                        b_mz=np.concatenate(cf["b_mz"]), b_it=np.concatenate(cf["b_it"]), b_ptr=np.array(b_ptr, np.int64),
+                        tol=np.array(tols, np.float64), score=np.array(scores, np.float64), n_match=np.array(nmatch, np.int64))
+    print("wrote cosine_fast.npz")
+
 
 if __name__ == "__main__":
     main()

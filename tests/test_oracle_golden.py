@@ -141,3 +141,19 @@ def test_dbscan_matches_sklearn(dbscan_golden):
             assert len(np.unique(comp[(ref == c) & core])) == 1, (i, c)
         if idx.shape[1] >= 8:
             assert adjusted_rand_score(ref, comp) >= 0.99, i
+
+
+def test_cosine_fast_matches_reference_golden():
+    """f4: the oracle's matched-peak cosine == the reference's `cosine_fast` (similarity.py:17-80) on 320 pairs
+    (jittered copies, peak groups denser than the tolerance, equal intensities, empty spectra)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cosine_fast.npz"))
+    n = len(g["tol"])
+    assert n == 320 and (g["n_match"] > 0).sum() > 250
+    for c in range(n):
+        a0, a1, b0, b1 = g["a_ptr"][c], g["a_ptr"][c + 1], g["b_ptr"][c], g["b_ptr"][c + 1]
+        sc, nm = fo.cosine_fast(g["a_mz"][a0:a1], g["a_it"][a0:a1], g["b_mz"][b0:b1], g["b_it"][b0:b1], float(g["tol"][c]))
+        assert nm == int(g["n_match"][c]), c
+        # same matched pairs; the golden was produced without numba, where NumPy 2 keeps the running sum in
+        # float32 (`0.0 += np.float32`), while numba -- and the oracle -- accumulate in float64: last-bit slack
+        assert abs(sc - float(g["score"][c])) <= 4e-7, c
