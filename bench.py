@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange step's device work (CSR packing, payload) at 1 GPU too (no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="run the charge partitions strictly one after the other (default: software-pipelined, "
+                         "ClusterPipeline.run_many)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the charge partitions on two host threads / two streams (PartitionRunner)")
     args = ap.parse_args()
@@ -174,8 +177,11 @@ def main():
     def step(collect=None):
         """one pass of the hot path over this rank's shard; `collect` != None: serial, per-stage timing"""
         if runner is not None and collect is None:
-            outs = runner.run(parts, *run_args)                                   # partitions overlap
+            outs = runner.run(parts, *run_args)                                   # partitions on two threads/streams
             lasts = [pp.last for pp in runner.last_pipes] if keep_nb else []
+        elif collect is None and not args.serial:
+            outs = pipe.run_many(parts, *run_args)                                # partitions software-pipelined
+            lasts = [dict(x) for x in pipe.lasts] if keep_nb else []
         else:
             outs, lasts = [], []
             for ds in parts:
@@ -221,13 +227,24 @@ def main():
         g = exchange.finish(pending.pop())
         return torch.cat(g["labels"]).cpu()                      # globally unique labels of the whole job
 
+    # setup, like the data generation above: the first passes grow the library's scratch pool and torch's caching
+    # allocator to their steady-state sizes (GB-sized hipMallocs, tens of ms each) -- prime them before the contract's
+    # W warmup steps so that neither W nor the timed K steps contain one-off allocations
+    for _ in range(3):
+        step()
+    finish_pending()
     for _ in range(args.warmup):
         step()
     finish_pending()
     barrier()
+    trace = os.environ.get("FALCON_BENCH_TRACE") is not None      # per-step wall times on stderr (adds a sync per step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        if trace:
+            torch.cuda.synchronize()
+            print(f"[bench] step {(time.perf_counter() - ts) * 1e3:.2f} ms", file=sys.stderr)
     finish_pending()                                             # the last exchange lands inside the timed region
     barrier()
     dt = time.perf_counter() - t0

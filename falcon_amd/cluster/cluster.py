@@ -95,21 +95,23 @@ class ClusterPipeline:
         self.ctx = ctx or _device.Context(device)
         self.last = {}
 
-    def run(self, ds: SpectrumDataset, precursor_tol_mass: float, precursor_tol_mode: str,
-            rt_tol: Optional[float], fragment_tol: float, batch_size: int, p: AnnParams,
-            keep_intermediates: bool = False):
-        """-> (labels_dev i32[N], medoids_dev i32[n_labels]) as device tensors."""
+    # The path in three phases, so that independent partitions (precursor charges, falcon.py:151-160) can be
+    # pipelined: `_front` ends with the path's first host synchronisation (bucket boundaries), `_search` only
+    # enqueues, `_graph` ends with the second (cluster counts).
+    def _front(self, c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p):
+        """sort by precursor m/z (cluster.py:73-85) + bucket boundaries (a5), on context `c`."""
         import torch
-        c = self.ctx
-        n = len(ds)
-        if n == 0:
-            return c.empty((0,), torch.int32), c.empty((0,), torch.int32)
-        n_bins, start, _ = _device.get_dim(p.min_mz, p.max_mz, fragment_tol)      # falcon.py:124-126
         pmz = c.to_dev(ds.precursor_mz, torch.float32)
-        order, mzs = c.sort_by_precursor(pmz)                                      # cluster.py:73-85
+        order, mzs = c.sort_by_precursor(pmz)
         rts = c.gather_f32(ds.retention_time, order) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
-        n_list = n_list_rule(np.diff(splits), p.n_probe)
+        return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list_rule(np.diff(splits), p.n_probe))
+
+    def _search(self, ds, st, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, p, keep_intermediates):
+        """a2/a3 vectorise, a6 index, a7 search, a8 filter (+ f4 re-scoring): fills st["nb_idx"], st["nb_dist"]."""
+        c = self.ctx
+        order, mzs, rts, splits, n_list = st["order"], st["mzs"], st["rts"], st["splits"], st["n_list"]
+        n_bins, start, _ = _device.get_dim(p.min_mz, p.max_mz, fragment_tol)      # falcon.py:124-126
         all_flat = bool((n_list == 1).all())
         vec = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
                                      p.hash_seed, True, dt)
@@ -130,6 +132,7 @@ class ClusterPipeline:
             sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
             nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
                                                  p.n_neighbors)
+            st.update(sim=sim, idx=idx)
         else:
             # production: a7 + a8 in one call, the [n, k_ann] search result never goes to HBM
             nb_idx, nb_dist = index.search_neighbors(p.n_probe, p.n_neighbors_ann, mzs, rts, precursor_tol_mass,
@@ -137,22 +140,82 @@ class ClusterPipeline:
         if p.rescore:
             nb_dist = c.rescore_neighbors(nb_idx, nb_dist, ds.mz, ds.intensity, ds.indptr, order, fragment_tol,
                                           p.min_matches)
+        st.update(X=X, X16=X16, index=index, nb_idx=nb_idx, nb_dist=nb_dist)
+
+    def _graph(self, st, precursor_tol_mass, precursor_tol_mode, rt_tol, p, keep_intermediates):
+        """a9 DBSCAN, a10 refinement, a11/a12 medoids + labels -> (labels, medoids); `last` describes the partition."""
+        c = self.ctx
+        order, mzs, rts, nb_idx, nb_dist, index = (st[k] for k in ("order", "mzs", "rts", "nb_idx", "nb_dist", "index"))
         if keep_intermediates:
             # staged calls (one C-ABI call per SURVEY 8a row) so that every intermediate can be inspected
             db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)
-            self.last = dict(order=order, mz_sorted=mzs, rt_sorted=rts, splits=splits, X=X, X16=X16, n_list=n_list,
-                             sim=sim, idx=idx, nb_idx=nb_idx, nb_dist=nb_dist, db=db.clone(), n_db=n_db, index=index)
+            last = dict(order=order, mz_sorted=mzs, rt_sorted=rts, splits=st["splits"], X=st["X"], X16=st["X16"],
+                        n_list=st["n_list"], sim=st["sim"], idx=st["idx"], nb_idx=nb_idx, nb_dist=nb_dist, db=db.clone(),
+                        n_db=n_db, index=index)
             lab, n_cl = c.refine_clusters(db, n_db, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol)
-            self.last.update(lab_sorted=lab, n_clusters=n_cl)
+            last.update(lab_sorted=lab, n_clusters=n_cl)
             labels, medoids = c.finalize(lab, n_cl, order, nb_idx, nb_dist)
         else:
             # production: a9..a12 fused, counts stay on the device, one synchronisation
             labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
                                                     precursor_tol_mode, rt_tol, order)
-            self.last = dict(nb_idx=nb_idx, nb_dist=nb_dist, order=order)     # the sparse graph (for the exchange)
-        if not keep_intermediates:
+            last = dict(nb_idx=nb_idx, nb_dist=nb_dist, order=order)     # the sparse graph (for the exchange)
             index.close()
+        return labels, medoids, last
+
+    def run(self, ds: SpectrumDataset, precursor_tol_mass: float, precursor_tol_mode: str,
+            rt_tol: Optional[float], fragment_tol: float, batch_size: int, p: AnnParams,
+            keep_intermediates: bool = False):
+        """-> (labels_dev i32[N], medoids_dev i32[n_labels]) as device tensors."""
+        import torch
+        c = self.ctx
+        if len(ds) == 0:
+            return c.empty((0,), torch.int32), c.empty((0,), torch.int32)
+        st = self._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p)
+        self._search(ds, st, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, p, keep_intermediates)
+        labels, medoids, self.last = self._graph(st, precursor_tol_mass, precursor_tol_mode, rt_tol, p, keep_intermediates)
         return labels, medoids
+
+    def run_many(self, datasets, precursor_tol_mass: float, precursor_tol_mode: str, rt_tol: Optional[float],
+                 fragment_tol: float, batch_size: int, p: AnnParams):
+        """Several independent partitions, software-pipelined on one GPU: the light front end of partition i + 1
+        (sort + bucket boundaries, on a second stream / context) and its host planning run while the scan of
+        partition i occupies the matrix cores; all heavy kernels stay on the pipeline's own stream, in order.
+        Same results as `run` per partition.  -> [(labels, medoids), ...]; `self.lasts` holds every `last`."""
+        import torch
+        c = self.ctx
+        args = (precursor_tol_mass, precursor_tol_mode, rt_tol)
+        if not hasattr(self, "_front_ctx"):
+            self._front_stream = torch.cuda.Stream(device=c.tdev)
+            with torch.cuda.stream(self._front_stream):
+                self._front_ctx = _device.Context(c.device)               # bound to the front stream
+        live = [i for i, ds in enumerate(datasets) if len(ds) > 0]
+        states = {}
+
+        def front(i):
+            with torch.cuda.stream(self._front_stream):
+                states[i] = self._front(self._front_ctx, datasets[i], *args, batch_size, p)
+
+        if live:
+            # inputs may have been produced on the caller's stream
+            self._front_stream.wait_stream(torch.cuda.current_stream(c.tdev))
+            front(live[0])
+        for pos, i in enumerate(live):
+            self._search(datasets[i], states[i], *args, fragment_tol, p, False)   # enqueue only
+            if pos + 1 < len(live):
+                front(live[pos + 1])                                               # overlaps the scan just enqueued
+        outs, self.lasts = [], []
+        for i, ds in enumerate(datasets):
+            if len(ds) == 0:
+                outs.append((c.empty((0,), torch.int32), c.empty((0,), torch.int32)))
+                self.lasts.append({})
+                continue
+            labels, medoids, last = self._graph(states[i], *args, p, False)
+            outs.append((labels, medoids))
+            self.lasts.append(last)
+        if self.lasts:
+            self.last = self.lasts[-1]
+        return outs
 
 
 class PartitionRunner:

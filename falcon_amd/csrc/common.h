@@ -58,6 +58,11 @@ struct fal_ctx {
     void* pinned = nullptr;               // small pinned host staging buffer (single-sync readbacks)
     size_t pinned_cap = 0;
     int pinned_reserve(size_t bytes, void** out);
+    // host -> device copy of a small table through a pinned ring: truly asynchronous (a pageable source makes
+    // hipMemcpyAsync wait for everything queued on the stream before it)
+    unsigned char* arena = nullptr;
+    size_t arena_off = 0;
+    int upload(void* dst, const void* src, size_t bytes);
     int num_cus = 256;
     bool timing = false;
     // per-stage accumulated event pairs for the LAST call of that stage

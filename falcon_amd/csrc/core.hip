@@ -1,6 +1,7 @@
 // Context, error reporting and the two host-side helpers (a1 get_dim, a3 hash table).
 #include <math.h>
 #include <stdarg.h>
+#include <string.h>
 #include "common.h"
 #include "hash.h"
 
@@ -69,6 +70,25 @@ int fal_ctx::pinned_reserve(size_t bytes, void** out) {
         pinned_cap = bytes + 4096;
     }
     *out = pinned;
+    return FAL_OK;
+}
+
+int fal_ctx::upload(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kArena = 32u << 20;
+    if (bytes == 0) return FAL_OK;
+    if (bytes > kArena / 4) {                       // big tables: plain (host-synchronous) copy
+        FAL_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+        return FAL_OK;
+    }
+    if (!arena) FAL_CHECK_HIP(hipHostMalloc((void**)&arena, kArena, hipHostMallocDefault));
+    size_t off = (arena_off + 63) & ~(size_t)63;
+    if (off + bytes > kArena) {                     // ring wrapped: earlier copies out of the arena must have landed
+        FAL_CHECK_HIP(hipStreamSynchronize(stream));
+        off = 0;
+    }
+    memcpy(arena + off, src, bytes);
+    FAL_CHECK_HIP(hipMemcpyAsync(dst, arena + off, bytes, hipMemcpyHostToDevice, stream));
+    arena_off = off + bytes;
     return FAL_OK;
 }
 
@@ -159,6 +179,7 @@ int fal_ctx_destroy(fal_ctx* c) {
         if (s.ptr) (void)hipFree(s.ptr);
     for (auto& b : c->pool) (void)hipFree(b.ptr);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->arena) (void)hipHostFree(c->arena);
     for (auto& t : c->timers)
         for (auto& p : t.ev) {
             (void)hipEventDestroy(p.first);

@@ -290,8 +290,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         std::vector<int64_t> cnt_host(total + 1, 0), qlb;
         for (int64_t b = 0; b < n_buckets; ++b)
             if (n_list[b] == 1) cnt_host[ivf->list_base[b]] = bucket_off[b + 1] - bucket_off[b];
-        // pageable source: hipMemcpyAsync returns once the data sits in the runtime's staging buffer
-        B_HIP(hipMemcpyAsync(ivf->counts, cnt_host.data(), sizeof(int64_t) * (total + 1), hipMemcpyHostToDevice, st));
+        B_TRY(ctx->upload(ivf->counts, cnt_host.data(), sizeof(int64_t) * (total + 1)));
     }
     B_HIP(hipMemsetAsync(ivf->assign, 0, sizeof(int32_t) * (size_t)n, st));
     B_HIP(hipMemsetAsync(ivf->centroids, 0, sizeof(float) * (size_t)total * low_dim, st));
@@ -302,7 +301,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
     }
     if (!bk.empty()) {
         B_TRY(ctx->pool_alloc(sizeof(BucketDev) * bk.size(), (void**)&ivf->bk_dev));
-        B_HIP(hipMemcpyAsync(ivf->bk_dev, bk.data(), sizeof(BucketDev) * bk.size(), hipMemcpyHostToDevice, st));
+        B_TRY(ctx->upload(ivf->bk_dev, bk.data(), sizeof(BucketDev) * bk.size()));
         // dense jobs: rows of the bucket x centroids of the bucket
         std::vector<DenseJob> jobs;
         int64_t tiles = 0;
@@ -312,7 +311,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         }
         DenseJob* jobs_dev = nullptr;
         B_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * jobs.size(), (void**)&jobs_dev));
-        B_HIP(hipMemcpyAsync(jobs_dev, jobs.data(), sizeof(DenseJob) * jobs.size(), hipMemcpyHostToDevice, st));
+        B_TRY(ctx->upload(jobs_dev, jobs.data(), sizeof(DenseJob) * jobs.size()));
         const BucketDev* bkd = (const BucketDev*)ivf->bk_dev;
         const int nbk = (int)bk.size();
         {

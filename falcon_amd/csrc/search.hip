@@ -256,11 +256,11 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     DenseJob *flat_dev = nullptr, *coarse_dev = nullptr;
     if (!flat.empty()) {
         FAL_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * flat.size(), (void**)&flat_dev));
-        FAL_CHECK_HIP(hipMemcpyAsync(flat_dev, flat.data(), sizeof(DenseJob) * flat.size(), hipMemcpyHostToDevice, st));
+        FAL_TRY(ctx->upload(flat_dev, flat.data(), sizeof(DenseJob) * flat.size()));
     }
     if (!coarse.empty()) {
         FAL_TRY(ctx->reserve(SLOT_JOBS2, sizeof(DenseJob) * coarse.size(), (void**)&coarse_dev));
-        FAL_CHECK_HIP(hipMemcpyAsync(coarse_dev, coarse.data(), sizeof(DenseJob) * coarse.size(), hipMemcpyHostToDevice, st));
+        FAL_TRY(ctx->upload(coarse_dev, coarse.data(), sizeof(DenseJob) * coarse.size()));
     }
     float* sims = nullptr;
     const size_t sims_floats = std::max(need_flat, need_coarse);
@@ -318,7 +318,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     ctx->counters[1] = 0;
     ctx->counters[2] = (int64_t)flat_batches.size();
     ctx->counters[3] = (int64_t)(sizeof(float) * std::max(need_flat, need_coarse));
-    if (coarse.empty()) return FAL_OK;   // (job tables were copied from pageable memory: already staged)
+    if (coarse.empty()) return FAL_OK;   // (job tables went through the pinned upload ring: nothing to wait for)
     for (const DenseJob& j : coarse) ctx->counters[1] += (int64_t)j.nq * j.nc;
 
     // ---- B. IVF buckets: coarse quantiser ------------------------------------------------------

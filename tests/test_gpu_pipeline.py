@@ -230,3 +230,32 @@ def test_pipeline_f16_scan_modes(ctx, mode):
         warnings.simplefilter("ignore")
         assert adjusted_rand_score(ref, labels) >= 0.99
     assert np.array_equal(labels[medoids], np.arange(len(medoids)))
+
+
+def test_run_many_equals_run_per_partition(ctx):
+    """the software-pipelined multi-partition entry gives exactly the per-partition results (labels, medoids,
+    neighbour lists), including an empty partition in the middle."""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    data = synth.generate(6000, seed=13)
+    parts = []
+    for ch in (2, 3):
+        d = synth.select_charge(data, ch)
+        parts.append(SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"]))
+    empty = SpectrumDataset(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32),
+                            np.zeros(0, np.float32), np.zeros(1, np.int64))
+    parts = [parts[0], empty, parts[1]]
+    pipe = ClusterPipeline(ctx)
+    p = AnnParams(eps=0.3)
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, p)
+    ref = []
+    for ds in parts:
+        lab, med = pipe.run(ds, *args)
+        ref.append((lab.cpu().numpy(), med.cpu().numpy(), pipe.last["nb_idx"].cpu().numpy() if len(ds) else None))
+    for _ in range(2):                                       # twice: the second call reuses the front context
+        outs = pipe.run_many(parts, *args)
+        for (lab, med), last, (rl, rm, rnb) in zip(outs, pipe.lasts, ref):
+            assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm)
+            if rnb is not None:
+                assert np.array_equal(last["nb_idx"].cpu().numpy(), rnb)
