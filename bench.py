@@ -211,7 +211,8 @@ def main():
                                   torch.empty(cap, dtype=torch.float32, device=dev))
             row0 = 0
             for last in lasts:                                   # charge partitions chain into one CSR on the device
-                csr = ctx.neighbors_to_csr(last["nb_idx"], last["nb_dist"], row_offset + row0, out=csr_buf["buf"], row0=row0)
+                csr = ctx.neighbors_to_csr(last["nb_idx"], last["nb_dist"], row_offset + row0, out=csr_buf["buf"], row0=row0,
+                                           nb_count=last.get("nb_count"))
                 row0 += last["nb_idx"].shape[0]
         else:                                                    # labels only: an empty graph
             csr = (torch.zeros(labels.numel() + 1, dtype=torch.int64, device=dev),
@@ -225,7 +226,9 @@ def main():
         if not pending:
             return None
         g = exchange.finish(pending.pop())
-        return torch.cat(g["labels"]).cpu()                      # globally unique labels of the whole job
+        # the gathered graph and the globally unique labels of the whole job stay device-resident on every rank;
+        # a rank copies its own shard's labels to the host
+        return g["labels"][rank].cpu()
 
     # setup, like the data generation above: the first passes grow the library's scratch pool and torch's caching
     # allocator to their steady-state sizes (GB-sized hipMallocs, tens of ms each) -- prime them before the contract's

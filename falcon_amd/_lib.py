@@ -51,13 +51,13 @@ _SIGNATURES = {
     "fal_filter_neighbors": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_double, c_int,
                               c_double, c_int, c_void_p, c_void_p], c_int),
     "fal_ivf_search_neighbors": ([c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_double, c_int, c_double, c_int,
-                                  c_void_p, c_void_p], c_int),
+                                  c_void_p, c_void_p, c_void_p], c_int),
     "fal_process_spectra": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_double,
                              c_double, c_double, c_double, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p,
                              c_void_p], c_int),
     "fal_rescore_neighbors": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double,
                                c_int], c_int),
-    "fal_neighbors_to_csr": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
+    "fal_neighbors_to_csr": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
                              c_int),
     "fal_dbscan": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, P(c_int64)], c_int),
     "fal_refine_clusters": ([c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_double, c_int, c_double,

@@ -140,7 +140,8 @@ class ClusterPipeline:
         if p.rescore:
             nb_dist = c.rescore_neighbors(nb_idx, nb_dist, ds.mz, ds.intensity, ds.indptr, order, fragment_tol,
                                           p.min_matches)
-        st.update(X=X, X16=X16, index=index, nb_idx=nb_idx, nb_dist=nb_dist)
+        st.update(X=X, X16=X16, index=index, nb_idx=nb_idx, nb_dist=nb_dist,
+                  nb_count=None if keep_intermediates else index.nb_count)
 
     def _graph(self, st, precursor_tol_mass, precursor_tol_mode, rt_tol, p, keep_intermediates):
         """a9 DBSCAN, a10 refinement, a11/a12 medoids + labels -> (labels, medoids); `last` describes the partition."""
@@ -159,7 +160,7 @@ class ClusterPipeline:
             # production: a9..a12 fused, counts stay on the device, one synchronisation
             labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
                                                     precursor_tol_mode, rt_tol, order)
-            last = dict(nb_idx=nb_idx, nb_dist=nb_dist, order=order)     # the sparse graph (for the exchange)
+            last = dict(nb_idx=nb_idx, nb_dist=nb_dist, nb_count=st["nb_count"], order=order)   # the sparse graph (exchange)
             index.close()
         return labels, medoids, last
 

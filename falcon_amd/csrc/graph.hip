@@ -166,6 +166,22 @@ __global__ __launch_bounds__(256) void nb_count_kernel(const int32_t* __restrict
     }
 }
 
+// rows known to be front-packed with indptr[row + 1] - indptr[row] entries: only that prefix is read
+__global__ __launch_bounds__(256) void nb_pack_prefix_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
+                                                             int64_t n, int k, int64_t id_offset,
+                                                             const int64_t* __restrict__ indptr, int32_t* __restrict__ out_idx,
+                                                             float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+        const int64_t base = indptr[row];
+        const int cnt = (int)(indptr[row + 1] - base);
+        for (int j = lane; j < cnt; j += 64) {
+            out_idx[base + j] = (int32_t)(nb_idx[row * k + j] + id_offset);
+            out_dist[base + j] = nb_dist[row * k + j];
+        }
+    }
+}
+
 __global__ void nb_chain_kernel(const int64_t* __restrict__ local, int64_t n, int64_t* __restrict__ indptr) {
     const int64_t base = indptr[0];                           // written by the previous segment (0 for the first)
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -215,8 +231,8 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
     return FAL_OK;
 }
 
-int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, int64_t id_offset,
-                         int64_t row0, int64_t* indptr_out, int32_t* idx_out, float* dist_out) {
+int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, const int32_t* nb_count, int64_t n, int k,
+                         int64_t id_offset, int64_t row0, int64_t* indptr_out, int32_t* idx_out, float* dist_out) {
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && row0 >= 0, FAL_EINVAL, "fal_neighbors_to_csr: bad argument");
     FAL_REQUIRE(indptr_out, FAL_EINVAL, "fal_neighbors_to_csr: NULL indptr");
     if (row0 == 0) FAL_CHECK_HIP(hipMemsetAsync(indptr_out, 0, sizeof(int64_t), ctx->stream));
@@ -227,13 +243,21 @@ int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_di
     FAL_TRY(ctx->reserve(SLOT_DB, sizeof(int32_t) * (size_t)n, (void**)&count));
     FAL_TRY(ctx->reserve(SLOT_DB2, sizeof(int64_t) * (size_t)(n + 1), (void**)&local));
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64);
-    hipLaunchKernelGGL(nb_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, n, k, count);
+    if (nb_count) {
+        count = const_cast<int32_t*>(nb_count);          // rows are front-packed and their lengths known (fused a7+a8)
+    } else {
+        hipLaunchKernelGGL(nb_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, n, k, count);
+    }
     FAL_TRY(device_scan_i32(ctx, count, n, local, SLOT_DB3));
     // indptr_out[row0 + 1 + i] = indptr_out[row0] + local[i + 1]: segments chain on the device
     hipLaunchKernelGGL(nb_chain_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, ctx->stream,
                        local, n, indptr_out + row0);
-    hipLaunchKernelGGL(nb_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, id_offset,
-                       indptr_out + row0, idx_out, dist_out);
+    if (nb_count)
+        hipLaunchKernelGGL(nb_pack_prefix_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, id_offset,
+                           indptr_out + row0, idx_out, dist_out);
+    else
+        hipLaunchKernelGGL(nb_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, id_offset,
+                           indptr_out + row0, idx_out, dist_out);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

@@ -41,6 +41,7 @@ struct SelectArgs {
     int f_keep;                  // n_neighbors
     int32_t* nb_idx;             // [rows, f_keep]
     float* nb_dist;              // [rows, f_keep]
+    int32_t* nb_count;           // [rows] stored neighbours per row, or nullptr
 };
 
 // xcd_list_tiles > 0 selects XCD-list mode (simtile.h): `jobs` = the launch's jobs sorted by

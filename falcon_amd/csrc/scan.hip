@@ -491,6 +491,7 @@ __device__ __forceinline__ void filter_sort_store(const SelectArgs& a, const uin
     __syncthreads();
     int32_t* onb = a.nb_idx + row * a.f_keep;
     float* odist = a.nb_dist + row * a.f_keep;
+    if (a.nb_count && lane == 0) a.nb_count[row] = min(c, a.f_keep);
     if (c <= 64) sort_and_store_nb<1>(f_u, f_lo, c, a.f_keep, lane, onb, odist);
     else if (c <= 128) sort_and_store_nb<2>(f_u, f_lo, c, a.f_keep, lane, onb, odist);
     else sort_and_store_nb<4>(f_u, f_lo, c, a.f_keep, lane, onb, odist);

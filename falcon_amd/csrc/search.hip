@@ -3,7 +3,7 @@
 // Flat buckets (one list): dense tile scan of the bucket against itself + wavefront select.
 // IVF buckets: coarse quantiser (dense scan vs the bucket's centroids + select k = n_probe),
 // candidate-count prefix, fine scan over the union of probed lists, select.
-// The sims of a batch of buckets live in one scratch buffer (default 1 GiB, FALCON_SIMS_MB): big
+// The sims of a batch of buckets live in one scratch buffer (default 2 GiB, FALCON_SIMS_MB): big
 // enough that a launch holds many tiles per wave slot (short launches lose more to their tail than
 // the buffer's HBM round trip costs; measured 160 MiB: 4.5 ms, 1 GiB: 3.5 ms of scan at 1 M spectra).
 #include <algorithm>
@@ -89,7 +89,7 @@ static size_t sims_capacity_floats() {
     static size_t cap = 0;
     if (!cap) {
         const char* e = getenv("FALCON_SIMS_MB");
-        size_t mb = e ? (size_t)atoll(e) : 1024;
+        size_t mb = e ? (size_t)atoll(e) : 2048;
         if (mb < 16) mb = 16;
         cap = mb * 1024 * 1024 / sizeof(float);
     }
@@ -108,12 +108,14 @@ struct NeighborFilter {          // a8 fused into the final selection (scan.h Se
     int is_da, keep;
     int32_t* nb_idx;
     float* nb_dist;
+    int32_t* nb_count;
 };
 
 void set_filter(SelectArgs& sa, const NeighborFilter* nf) {
     if (!nf) return;
     sa.f_pmz = nf->pmz; sa.f_rt = nf->rt; sa.f_tol = nf->tol; sa.f_rt_tol = nf->rt_tol;
     sa.f_is_da = nf->is_da; sa.f_keep = nf->keep; sa.nb_idx = nf->nb_idx; sa.nb_dist = nf->nb_dist;
+    sa.nb_count = nf->nb_count;
 }
 }  // namespace
 
@@ -429,13 +431,15 @@ extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe
 
 extern "C" int fal_ivf_search_neighbors(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                                         const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
-                                        double rt_tol, int n_neighbors, int32_t* nb_idx, float* nb_dist) {
+                                        double rt_tol, int n_neighbors, int32_t* nb_idx, float* nb_dist,
+                                        int32_t* nb_count) {
     FAL_REQUIRE(ctx && ivf, FAL_EINVAL, "fal_ivf_search_neighbors: NULL ctx/ivf");
     FAL_REQUIRE(n_neighbors >= 1 && n_neighbors <= FAL_MAX_K_ANN, FAL_EUNSUPPORTED,
                 "fal_ivf_search_neighbors: n_neighbors must be in [1, %d]", FAL_MAX_K_ANN);
     if (ivf->n == 0) return FAL_OK;
     FAL_REQUIRE(precursor_mz_sorted && nb_idx && nb_dist, FAL_EINVAL, "fal_ivf_search_neighbors: NULL array");
-    NeighborFilter nf{precursor_mz_sorted, rt_tol >= 0.0 ? rt_sorted : nullptr, tol, rt_tol, tol_is_da, n_neighbors, nb_idx, nb_dist};
+    NeighborFilter nf{precursor_mz_sorted, rt_tol >= 0.0 ? rt_sorted : nullptr, tol, rt_tol, tol_is_da, n_neighbors, nb_idx, nb_dist,
+                      nb_count};
     ctx->stage_reset(ST_FILTER);
     return search_impl(ctx, ivf, n_probe, k_ann, nullptr, nullptr, &nf);
 }

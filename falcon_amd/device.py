@@ -229,7 +229,7 @@ class Context:
               "fal_rescore_neighbors")
         return nb_dist
 
-    def neighbors_to_csr(self, nb_idx, nb_dist, id_offset: int = 0, out=None, row0: int = 0):
+    def neighbors_to_csr(self, nb_idx, nb_dist, id_offset: int = 0, out=None, row0: int = 0, nb_count=None):
         """ELL neighbour lists -> CSR (indptr i64[rows+1], idx i32[cap], dist f32[cap]); entries beyond
         indptr[-1] are unspecified.  `out` = (indptr, idx, dist) buffers to fill; with `row0` > 0 the call
         appends a further segment (rows row0.. of `out`, ids shifted by its own id_offset).  No sync."""
@@ -241,7 +241,8 @@ class Context:
         indptr, idx, dist = out
         if indptr.numel() < row0 + n + 1:
             raise FalconHipError("neighbors_to_csr: indptr buffer too small")
-        check(self.lib.fal_neighbors_to_csr(self._h, self._p(nb_idx), self._p(nb_dist), n, k, int(id_offset), int(row0),
+        check(self.lib.fal_neighbors_to_csr(self._h, self._p(nb_idx), self._p(nb_dist), self._p(nb_count), n, k, int(id_offset),
+                                            int(row0),
                                             self._p(indptr), self._p(idx), self._p(dist)), "fal_neighbors_to_csr")
         return indptr, idx, dist
 
@@ -341,9 +342,11 @@ class IvfIndex:
         c = self.ctx
         nb_idx = c.empty((self.n, n_neighbors), torch.int32)
         nb_dist = c.empty((self.n, n_neighbors), torch.float32)
+        self.nb_count = c.empty((self.n,), torch.int32)         # stored neighbours per row (rows are front-packed)
         check(c.lib.fal_ivf_search_neighbors(c._h, self._h, int(n_probe), int(k_ann), c._p(mz_sorted), c._p(rt_sorted),
                                              float(tol), int(mode == "Da"), -1.0 if rt_tol is None else float(rt_tol),
-                                             int(n_neighbors), c._p(nb_idx), c._p(nb_dist)), "fal_ivf_search_neighbors")
+                                             int(n_neighbors), c._p(nb_idx), c._p(nb_dist), c._p(self.nb_count)),
+              "fal_ivf_search_neighbors")
         return nb_idx, nb_dist
 
 

@@ -150,11 +150,12 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
 /* ---- a7+a8 in one call: the same search with the neighbour filter applied to the k_ann
  *          selected candidates inside the selection kernel (only the survivors are sorted;
  *          the [n, k_ann] result never goes to HBM).  Output identical to
- *          fal_ivf_search_topk followed by fal_filter_neighbors. ------------------ [dev] */
+ *          fal_ivf_search_topk followed by fal_filter_neighbors; nb_count (optional)
+ *          receives the number of stored neighbours of every row. ------------------ [dev] */
 int fal_ivf_search_neighbors(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                              const float* precursor_mz_sorted, const float* rt_sorted,
                              double tol, int tol_is_da, double rt_tol, int n_neighbors,
-                             int32_t* nb_idx, float* nb_dist);
+                             int32_t* nb_idx, float* nb_dist, int32_t* nb_count /*[n] or NULL*/);
 
 /* ---- f4  exact re-scoring of the stored neighbours with the matched-peak cosine the
  *          reference ships: similarity.py:17-80 `cosine_fast` (pairs of peaks within
@@ -176,8 +177,9 @@ int fal_rescore_neighbors(fal_ctx* ctx, const int32_t* nb_idx, float* nb_dist, i
  *          the device: a call writes rows [row0, row0 + n) of indptr_out and continues
  *          at nnz = indptr_out[row0] (row0 = 0 starts a new graph).  indptr i64[rows+1];
  *          idx_out / dist_out need room for every segment's n*k entries. ---------- [dev] */
-int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n,
-                         int k, int64_t id_offset, int64_t row0, int64_t* indptr_out,
+int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
+                         const int32_t* nb_count /*[n] lengths of front-packed rows, or NULL*/,
+                         int64_t n, int k, int64_t id_offset, int64_t row0, int64_t* indptr_out,
                          int32_t* idx_out, float* dist_out);
 
 /* ---- a9  DBSCAN(eps, min_samples = 2 as reference cluster.py:66) on the sparse

@@ -102,3 +102,22 @@ def test_sparse_graph_exchange_rccl_one_rank(ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_row_counts_from_fused_search_and_prefix_packing(ctx):
+    """the fused a7+a8 kernel reports how many neighbours every row stores; CSR packing driven by those counts
+    (prefix reads only) equals the count-by-scanning form."""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    d = synth.select_charge(synth.generate(5000, seed=3), 2)
+    ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+    pipe = ClusterPipeline(ctx)
+    pipe.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, AnnParams(eps=0.3, n_neighbors=8))      # small k: full rows occur
+    nb_idx, nb_dist, cnt = pipe.last["nb_idx"], pipe.last["nb_dist"], pipe.last["nb_count"]
+    ref_cnt = (nb_idx >= 0).sum(1).to(torch.int32)
+    assert torch.equal(cnt, ref_cnt) and int(cnt.max()) == 8 and int(cnt.min()) == 0
+    a = ctx.neighbors_to_csr(nb_idx, nb_dist, 77)
+    b = ctx.neighbors_to_csr(nb_idx, nb_dist, 77, nb_count=cnt)
+    nnz = int(a[0][-1])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1][:nnz], b[1][:nnz]) and torch.equal(a[2][:nnz], b[2][:nnz])
