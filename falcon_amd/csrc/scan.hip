@@ -63,8 +63,12 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
     // read the same chunk at the same time (shared L2 lines) and simply stop at their own diagonal;
     // walking upwards from the diagonal would spread the running tiles over the whole bucket
     // (measured: 2.84 vs 2.60 ms of scan per 1 M spectra; alternating the direction per bucket: 2.68).
+    // (The arg-max form keeps the ascending walk: with ids arriving in ascending order "s > best" alone breaks
+    //  ties towards the lowest id; the longer tie test made hipcc demote the query registers to scratch, 3.5x
+    //  slower k-means.)
     const int c_last = ((nc - 1) >> 5) << 5;
-    const int c_begin = c_last, c_step = -32;
+    constexpr bool kDown = EPI == EPI_STORE;
+    const int c_begin = kDown ? c_last : 0, c_step = kDown ? -32 : 32;
     const int n_chunks = (c_last - c_first) / 32 + 1;
     CandStream<DH4> cs;
     const float* cur = Cm + (job.c_row0 + min(c_begin + r, nc - 1)) * d + (int64_t)h * dh;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
             for (int i = 0; i < 16; ++i) {
                 const int c = prev_c0 + mfma32_row(i, h);
                 const float s = prev[i];
-                if (c < nc && (s > best || (s == best && c < bestc))) {   // ties -> lowest id (chunks arrive in descending order)
+                if (c < nc && s > best) {   // ids arrive in ascending order: ties keep the lowest id
                     best = s;
                     bestc = c;
                 }
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
         }
     };
     for (int ci = 0, c0 = c_begin; ci < n_chunks; ++ci, c0 += c_step) {
-        const float* nxt = Cm + (job.c_row0 + min(max(c0 + c_step, 0) + r, nc - 1)) * d + (int64_t)h * dh;
+        const float* nxt = Cm + (job.c_row0 + min(max(c0 + c_step, 0) + r, nc - 1)) * d + (int64_t)h * dh;   // (clamped prefetch)
         const f32x16 acc = (EPI == EPI_STORE) ? cs.template dot<true>(q, cur, nxt, dh4, epilogue)
                                               : cs.template dot<false>(q, cur, nxt, dh4, epilogue);
         prev = acc;
