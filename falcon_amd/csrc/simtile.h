@@ -98,62 +98,6 @@ struct CandStream {
     }
 };
 
-// Two candidate streams (two 32-row chunks) advanced together: two INDEPENDENT accumulator chains keep
-// the matrix pipe issuing while one chain waits for its previous result.
-template <int DH4>
-struct CandStream2 {
-    static constexpr int kRing = (DH4 % 8 == 0) ? 8 : 10;
-    static constexpr int kMidStep = (DH4 > 24) ? 12 : DH4 / 2;
-    float4 ra[kRing], rb[kRing];
-
-    __device__ __forceinline__ void prime(const float* __restrict__ a_half, const float* __restrict__ b_half, int dh4) {
-        const float4* pa = reinterpret_cast<const float4*>(a_half);
-        const float4* pb = reinterpret_cast<const float4*>(b_half);
-#pragma unroll
-        for (int j = 0; j < kRing; ++j) {
-            ra[j] = pa[j < dh4 ? j : dh4 - 1];
-            rb[j] = pb[j < dh4 ? j : dh4 - 1];
-        }
-    }
-
-    // D[query][cand] for both chunks (QUERY_IS_A orientation of CandStream::dot<true>)
-    template <class Mid>
-    __device__ __forceinline__ void dot(const float (&q)[DH4 * 4], const float* __restrict__ cur_a,
-                                        const float* __restrict__ cur_b, const float* __restrict__ nxt_a,
-                                        const float* __restrict__ nxt_b, int dh4, f32x16& acc_a, f32x16& acc_b, Mid&& mid) {
-        const float4 *pca = reinterpret_cast<const float4*>(cur_a), *pcb = reinterpret_cast<const float4*>(cur_b);
-        const float4 *pna = reinterpret_cast<const float4*>(nxt_a), *pnb = reinterpret_cast<const float4*>(nxt_b);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            acc_a[i] = 0.f;
-            acc_b[i] = 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < DH4; ++j) {
-            const float4 a = ra[j % kRing], b = rb[j % kRing];
-            const int jj = j + kRing;
-            if (jj < DH4) {
-                ra[j % kRing] = pca[jj < dh4 ? jj : dh4 - 1];
-                rb[j % kRing] = pcb[jj < dh4 ? jj : dh4 - 1];
-            } else {
-                ra[j % kRing] = pna[(jj - DH4) < dh4 ? (jj - DH4) : dh4 - 1];
-                rb[j % kRing] = pnb[(jj - DH4) < dh4 ? (jj - DH4) : dh4 - 1];
-            }
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 0], a.x, acc_a, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 0], b.x, acc_b, 0, 0, 0);
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 1], a.y, acc_a, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 1], b.y, acc_b, 0, 0, 0);
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 2], a.z, acc_a, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 2], b.z, acc_b, 0, 0, 0);
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 3], a.w, acc_a, 0, 0, 0);
-            acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 3], b.w, acc_b, 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            if (j == kMidStep) mid();
-        }
-    }
-};
-
 // float -> uint32 whose unsigned order equals the float order (and back).
 __device__ __forceinline__ uint32_t f32_sortable(float f) {
     uint32_t b = __float_as_uint(f);

@@ -97,7 +97,8 @@ class Context:
         intensity = self.to_dev(intensity, torch.float32)
         indptr = self.to_dev(indptr, torch.int64)
         row_order = None if row_order is None else self.to_dev(row_order, torch.int64)
-        n = indptr.numel() - 1
+        # output row i is spectrum row_order[i] of the CSR: a subset / permutation of the dataset is fine
+        n = indptr.numel() - 1 if row_order is None else row_order.numel()
         f16 = dtype in ("f16", "float16")
         split = dtype == "split16"
         if split:

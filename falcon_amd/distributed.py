@@ -167,3 +167,106 @@ class SparseGraphExchange:
             out["idx"].append(blk[2 * n_max:2 * n_max + nnz_r])
             out["dist"].append(blk[2 * n_max + nnz_max:2 * n_max + nnz_max + nnz_r].view(torch.float32))
         return out
+
+
+# ---------------------------------------------------------------------------------------------
+# One dataset, N GPUs: buckets -> ranks by cost (LPT), every rank runs the path on its buckets,
+# one all-gatherv of (dataset rows, labels, medoids).  SURVEY 8e; reference analogue: blocks are
+# clustered independently and their labels concatenated with offsets (cluster.py:115-155).
+# ---------------------------------------------------------------------------------------------
+def bucket_costs(sizes: np.ndarray, n_list: np.ndarray, n_probe: int) -> np.ndarray:
+    """scan cost of a bucket ~ n_b * candidates per query: n_b for a flat bucket, the probed fraction of
+    it for an IVF bucket, plus the k-means passes (11 x n_list centroids per row)."""
+    sizes = np.asarray(sizes, np.float64)
+    n_list = np.asarray(n_list, np.float64)
+    cand = np.where(n_list <= 1, sizes, sizes * np.minimum(1.0, n_probe / np.maximum(n_list, 1.0)) + 12.0 * n_list)
+    return sizes * cand
+
+
+def shard_rows(splits: np.ndarray, owner: np.ndarray, rank: int):
+    """sorted positions of the rows of this rank's buckets (buckets stay whole and in order), the
+    bucket boundaries of that subset, and the bucket ids."""
+    mine = np.flatnonzero(owner == rank)
+    sizes = (splits[1:] - splits[:-1])[mine]
+    sub_splits = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    if len(mine) == 0:
+        return np.zeros(0, np.int64), sub_splits, mine
+    rows = np.repeat(splits[:-1][mine] - sub_splits[:-1], sizes) + np.arange(sub_splits[-1])
+    return rows.astype(np.int64), sub_splits, mine
+
+
+def merge_shards(n_total: int, shards):
+    """shards: per rank (dataset_rows i64[n_r], labels i32[n_r] in [0, n_labels_r), medoid_rows i32[n_labels_r]).
+    -> labels i32[n_total] made globally unique rank by rank (the per-block offset of cluster.py:144-155),
+    medoids i32[sum n_labels_r] (dataset rows)."""
+    labels = np.full(n_total, -1, np.int32)
+    medoids, off = [], 0
+    for rows, lab, med in shards:
+        labels[np.asarray(rows, np.int64)] = np.asarray(lab, np.int32) + off
+        medoids.append(np.asarray(med, np.int32))
+        off += len(med)
+    if (labels < 0).any():
+        raise ValueError("merge_shards: some spectra were not assigned to any rank")
+    return labels, (np.concatenate(medoids) if medoids else np.zeros(0, np.int32))
+
+
+def run_sharded(pipe, ds, precursor_tol_mass: float, precursor_tol_mode: str, rt_tol, fragment_tol: float,
+                batch_size: int, p, rank: Optional[int] = None, world_size: Optional[int] = None, gather=None,
+                local_only: bool = False):
+    """Cluster ONE dataset on `world_size` GPUs.  Every rank holds the dataset, sorts it and derives the same
+    bucket boundaries (cheap, deterministic); buckets are dealt to ranks by longest-processing-time on
+    `bucket_costs`; a rank runs vectorise -> ... -> labels on its buckets only; one all-gatherv assembles the
+    result on every rank.  `gather(rows, labels, medoids) -> [(rows, labels, medoids) per rank]` defaults to
+    the `torch.distributed` all-gatherv of this module.  -> (labels i32[N], medoids i32[n_labels]) numpy
+    (`local_only`: this rank's (dataset rows, labels, medoid rows) without the collective, for `merge_shards`).
+    The partition equals the single-GPU one; label ids are rank-major instead of bucket-major."""
+    import torch
+    r0, w0 = world()
+    rank = r0 if rank is None else rank
+    world_size = w0 if world_size is None else world_size
+    c = pipe.ctx
+    n = len(ds)
+    st = pipe._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p)
+    splits = np.asarray(st["splits"], np.int64)
+    owner = shard_units(bucket_costs(np.diff(splits), st["n_list"], p.n_probe), world_size)
+    rows, sub_splits, mine = shard_rows(splits, owner, rank)
+    n_sub = len(rows)
+    if n_sub:
+        rows_d = c.to_dev(rows, torch.int64)
+        order_sub = st["order"][rows_d]                       # dataset rows of my buckets, in sorted order
+        sub = dict(order=order_sub, mzs=st["mzs"][rows_d], rts=None if st["rts"] is None else st["rts"][rows_d],
+                   splits=sub_splits, n_list=np.asarray(st["n_list"])[mine])
+        pipe._search(ds, sub, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, p, False)
+        sub["order"] = torch.arange(n_sub, dtype=torch.int64, device=c.tdev)      # label the subset locally ...
+        labels_sub, medoids_sub, _ = pipe._graph(sub, precursor_tol_mass, precursor_tol_mode, rt_tol, p, False)
+        mine_rows = order_sub.cpu().numpy()                                       # ... and map back to dataset rows
+        mine_lab = labels_sub.cpu().numpy()
+        mine_med = mine_rows[medoids_sub.cpu().numpy()].astype(np.int32)
+    else:
+        mine_rows, mine_lab, mine_med = np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32)
+    if local_only:
+        return mine_rows, mine_lab, mine_med
+    if gather is None:
+        gather = lambda a, b, m: _gather_shards(a, b, m, c.tdev)
+    return merge_shards(n, gather(mine_rows, mine_lab, mine_med))
+
+
+def _gather_shards(rows, labels, medoids, device):
+    """one all-gatherv round (counts, then max-count padded slots) for the three per-rank arrays"""
+    import torch
+    rank, ws = world()
+    if ws == 1:
+        return [(rows, labels, medoids)]
+    t_rows = torch.from_numpy(np.ascontiguousarray(rows)).to(device)
+    t_lab = torch.from_numpy(np.ascontiguousarray(labels)).to(device)
+    t_med = torch.from_numpy(np.ascontiguousarray(medoids)).to(device)
+    g_rows, counts = allgatherv_rows(t_rows)
+    g_lab, _ = allgatherv_rows(t_lab, counts)
+    g_med, mcounts = allgatherv_rows(t_med)
+    g_rows, g_lab, g_med = g_rows.cpu().numpy(), g_lab.cpu().numpy(), g_med.cpu().numpy()
+    out, a, b = [], 0, 0
+    for r in range(ws):
+        out.append((g_rows[a:a + counts[r]], g_lab[a:a + counts[r]], g_med[b:b + mcounts[r]]))
+        a += counts[r]
+        b += mcounts[r]
+    return out

@@ -124,3 +124,33 @@ def test_sparse_graph_exchange_world2_gloo():
                 assert np.array_equal(o["counts"][r], np.diff(indptr))
                 assert np.array_equal(o["idx"][r], idx) and np.array_equal(o["dist"][r], dst)
                 assert np.array_equal(o["labels"][r], labels + 3 * r)
+
+
+def test_shard_rows_and_merge_shards():
+    """bucket -> rank assignment keeps buckets whole; merging the per-rank results gives globally unique labels."""
+    from falcon_amd import distributed as fd
+    splits = np.array([0, 5, 5, 12, 13, 40, 47], np.int64)                 # 6 buckets, one empty
+    n_list = np.array([1, 1, 1, 1, 4, 1])
+    cost = fd.bucket_costs(np.diff(splits), n_list, 2)
+    assert cost[1] == 0 and cost[2] == 49 and cost[4] == 27 * (27 * 0.5 + 12 * 4)      # flat: n^2; IVF: probed half + k-means
+    owner = fd.shard_units(cost, 3)
+    seen = np.zeros(47, int)
+    shards = []
+    for r in range(3):
+        rows, sub_splits, mine = fd.shard_rows(splits, owner, r)
+        seen[rows] += 1
+        assert np.array_equal(np.diff(sub_splits), np.diff(splits)[mine])
+        for b, (a0, a1) in zip(mine, zip(sub_splits[:-1], sub_splits[1:])):
+            assert np.array_equal(rows[a0:a1], np.arange(splits[b], splits[b + 1]))    # whole buckets, in order
+        lab = (np.arange(len(rows)) // 3).astype(np.int32)                  # fake local labels
+        n_lab = int(lab.max()) + 1 if len(lab) else 0
+        shards.append((rows, lab, rows[:n_lab].astype(np.int32)))
+    assert (seen == 1).all()                                                # every row on exactly one rank
+    labels, medoids = fd.merge_shards(47, shards)
+    assert labels.min() == 0 and np.array_equal(np.unique(labels), np.arange(len(medoids)))
+    off = 0
+    for rows, lab, med in shards:                                           # rank-major offsets
+        assert np.array_equal(labels[rows], lab + off)
+        off += len(med)
+    with pytest.raises(ValueError):
+        fd.merge_shards(48, shards)

@@ -259,3 +259,28 @@ def test_run_many_equals_run_per_partition(ctx):
             assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm)
             if rnb is not None:
                 assert np.array_equal(last["nb_idx"].cpu().numpy(), rnb)
+
+
+def test_run_sharded_equals_single_gpu_partition(ctx):
+    """one dataset dealt to 3 'ranks' bucket by bucket (run one after the other here, the all-gatherv replaced by
+    a list) gives exactly the single-GPU partition; world_size 1 goes through the real entry."""
+    from sklearn.metrics import adjusted_rand_score
+    from falcon_amd import distributed as fd, synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    d = synth.select_charge(synth.generate(6000, seed=23), 2)
+    ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+    pipe = ClusterPipeline(ctx)
+    p = AnnParams(eps=0.3)
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, p)
+    lab1, med1 = pipe.run(ds, *args)
+    lab1, med1 = lab1.cpu().numpy(), med1.cpu().numpy()
+    parts = [fd.run_sharded(pipe, ds, *args, rank=r, world_size=3, local_only=True) for r in range(3)]
+    assert sum(len(x[0]) for x in parts) == len(ds) and min(len(x[0]) for x in parts) > 0
+    labels, medoids = fd.merge_shards(len(ds), parts)
+    assert sorted(medoids.tolist()) == sorted(med1.tolist())
+    assert adjusted_rand_score(lab1, labels) == 1.0
+    labels_w1, medoids_w1 = fd.run_sharded(pipe, ds, *args)                 # not under torch.distributed: world of 1
+    # same partition and representatives; noise singletons are numbered in sorted order here, in dataset order by `run`
+    assert adjusted_rand_score(lab1, labels_w1) == 1.0 and sorted(medoids_w1.tolist()) == sorted(med1.tolist())
+    assert np.array_equal(np.unique(labels_w1), np.arange(len(medoids_w1)))
+    assert np.array_equal(labels_w1[medoids_w1], np.arange(len(medoids_w1)))          # medoids[c] represents cluster c
