@@ -302,16 +302,6 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
     if (!bk.empty()) {
         B_TRY(ctx->pool_alloc(sizeof(BucketDev) * bk.size(), (void**)&ivf->bk_dev));
         B_TRY(ctx->upload(ivf->bk_dev, bk.data(), sizeof(BucketDev) * bk.size()));
-        // dense jobs: rows of the bucket x centroids of the bucket
-        std::vector<DenseJob> jobs;
-        int64_t tiles = 0;
-        for (const BucketDev& b : bk) {
-            jobs.push_back({b.row0, b.list0, 0, tiles, b.n, b.n_list, 0});
-            tiles += ceil_div(b.n, 32);
-        }
-        DenseJob* jobs_dev = nullptr;
-        B_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * jobs.size(), (void**)&jobs_dev));
-        B_TRY(ctx->upload(jobs_dev, jobs.data(), sizeof(DenseJob) * jobs.size()));
         const BucketDev* bkd = (const BucketDev*)ivf->bk_dev;
         const int nbk = (int)bk.size();
         {
@@ -320,9 +310,43 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
                                ivf->centroids);
         B_HIP(hipGetLastError());
         }
+        // Buckets with few lists (<= kAssignMaxLists) are assigned by the shared-stream kernel (assign.hip): jobs =
+        // (row segment) x (group of <= 128 centroids).  Buckets with many lists keep the row-resident kernel, whose
+        // 32-row tile is amortised over their many centroid chunks.
+        static const bool row_major = getenv("FALCON_ASSIGN_ROWMAJOR") != nullptr;    // force the row-resident form (A/B runs)
+        constexpr int kAssignMaxLists = 512;
+        std::vector<AssignJob> ajobs;
+        std::vector<DenseJob> djobs;
+        int64_t dtiles = 0;
+        for (const BucketDev& b : bk) {
+            if (!row_major && b.n_list <= kAssignMaxLists) {
+                for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg)
+                    for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)
+                        ajobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0),
+                                         std::min(kAssignGroup, b.n_list - t0), t0, 0});
+            } else {
+                djobs.push_back({b.row0, b.list0, 0, dtiles, b.n, b.n_list, 0});
+                dtiles += ceil_div(b.n, 32);
+            }
+        }
+        AssignJob* ajobs_dev = nullptr;
+        DenseJob* djobs_dev = nullptr;
+        unsigned long long* keys = nullptr;
+        if (!ajobs.empty()) {
+            B_TRY(ctx->reserve(SLOT_JOBS2, sizeof(AssignJob) * ajobs.size(), (void**)&ajobs_dev));
+            B_TRY(ctx->upload(ajobs_dev, ajobs.data(), sizeof(AssignJob) * ajobs.size()));
+            B_TRY(ctx->reserve(SLOT_SIMS, sizeof(unsigned long long) * (size_t)n, (void**)&keys));
+        }
+        if (!djobs.empty()) {
+            B_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * djobs.size(), (void**)&djobs_dev));
+            B_TRY(ctx->upload(djobs_dev, djobs.data(), sizeof(DenseJob) * djobs.size()));
+        }
         for (int it = 0; it <= kmeans_iters; ++it) {
-            B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, jobs_dev, (int)jobs.size(), 0,
-                               tiles, nullptr, 0, ivf->assign));
+            if (!djobs.empty())
+                B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,
+                                   dtiles, nullptr, 0, ivf->assign));
+            B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, (int64_t)ajobs.size(), n, keys,
+                                ivf->assign));
             if (it == kmeans_iters) break;   // final assignment against the final centroids
             StageScope ts(ctx, ST_BUILD);
             hipLaunchKernelGGL(list_walk_kernel<0>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign,

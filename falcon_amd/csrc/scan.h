@@ -49,6 +49,20 @@ struct SelectArgs {
 int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,
                  int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base, int32_t* assign,
                  int64_t xcd_list_tiles = 0);
+// Shared-stream list assignment (assign.hip): job = (a segment of a bucket's rows) x (up to 128 of its centroids)
+constexpr int kAssignSeg = 2048;      // rows per segment
+constexpr int kAssignGroup = 128;     // centroids per job: one 32-centroid tile per wave
+struct AssignJob {
+    int64_t row0;        // first row of the segment (sorted rows = rows of X)
+    int64_t cent0;       // global row of the group's first centroid
+    int32_t nrows;       // rows in the segment (<= kAssignSeg)
+    int32_t ncent;       // centroids in the group (1..kAssignGroup)
+    int32_t id_base;     // bucket-local list id of the group's first centroid
+    int32_t pad;
+};
+// keys: u64[n] scratch (cleared here); assign[i] is written for every row a job covers
+int launch_assign(fal_ctx* ctx, int stage, const float* X, const float* centroids, int d, const AssignJob* jobs, int64_t n_jobs,
+                  int64_t n, unsigned long long* keys, int32_t* assign);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order
