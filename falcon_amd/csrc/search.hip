@@ -54,9 +54,9 @@ __global__ void probe_hist_kernel(const int32_t* __restrict__ probes, int np, co
 // tiles of a list = 32-row slices of the LIST (each streams all queries probing the list); a list
 // nobody probes needs none
 __global__ void list_tiles_kernel(const int32_t* __restrict__ cnt, const int64_t* __restrict__ list_off, int64_t n,
-                                  int32_t* __restrict__ tiles) {
+                                  int shift, int32_t* __restrict__ tiles) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        tiles[i] = cnt[i] > 0 ? (int32_t)((list_off[i + 1] - list_off[i] + 31) >> 5) : 0;
+        tiles[i] = cnt[i] > 0 ? (int32_t)((list_off[i + 1] - list_off[i] + (1 << shift) - 1) >> shift) : 0;
 }
 
 // inv_q[e] = query position, inv_dest[e] = where that query's sims for this list start
@@ -350,6 +350,9 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                            coarse_dev, (int)coarse.size(), ivf_tiles, ivf->list_off, totals);
         FAL_TRY(launch_exclusive_scan(ctx, totals, n_slots, q_sim_off));
     }
+    // fine-scan tiles: groups of four 32-row list slices for the 4-wave shared-stream kernel (ivf_fine.hip)
+    static const bool single_wave = getenv("FALCON_FINE_SINGLEWAVE") != nullptr;      // the one-wave-per-slice form (A/B runs)
+    const int group_shift = single_wave ? 5 : 7;
     // ---- inverted probe table (list -> queries probing it) ------------------------------------
     const int64_t TL = ivf->total_lists;
     const int64_t n_pairs_max = ivf->n * (int64_t)np;
@@ -370,7 +373,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                            ivf_tiles, cnt);
         FAL_TRY(device_scan_i32(ctx, cnt, TL, inv_off, SLOT_MISC2));
         hipLaunchKernelGGL(list_tiles_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024)), dim3(256), 0, st,
-                           cnt, ivf->list_off, TL, ltiles);
+                           cnt, ivf->list_off, TL, group_shift, ltiles);
         FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
         hipLaunchKernelGGL(probe_scatter_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
                            ivf_tiles, ivf->list_off, q_sim_off, inv_off, cursor, inv_q, inv_dest);
@@ -402,6 +405,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     ctx->counters[0] += qoff[(size_t)ivf_tiles];
     ctx->counters[2] += (int64_t)ivf_batches.size();
     ctx->counters[3] = std::max<int64_t>(ctx->counters[3], (int64_t)(sizeof(float) * need_fine));
+    FAL_REQUIRE(need_fine + kSimsSlack < ((size_t)1 << 32), FAL_EUNSUPPORTED, "sims batch too large (lower FALCON_SIMS_MB)");
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (need_fine + kSimsSlack), (void**)&sims));
     for (const IvfBatch& bt : ivf_batches) {
         const DenseJob &first = coarse[bt.j0], &last = coarse[bt.j1 - 1];
@@ -410,7 +414,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         const int64_t base = qoff[(size_t)t0];
         ListScanArgs la{};
         la.Xl = ivf->Xl; la.d = d; la.list_off = ivf->list_off; la.inv_off = inv_off; la.ltile_off = ltile_off;
-        la.inv_q = inv_q; la.inv_dest = inv_dest; la.list_begin = L0; la.list_end = L1;
+        la.inv_q = inv_q; la.inv_dest = inv_dest; la.list_begin = L0; la.list_end = L1; la.group_shift = group_shift;
         la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
         la.sims = sims; la.sims_base = base; la.sink = sims + need_fine;
         FAL_TRY(launch_list_scan(ctx, la));

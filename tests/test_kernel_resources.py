@@ -35,6 +35,7 @@ def _kernel_scratch(src, tmp_path):
     ("scan.hip", "dense_kernel", 10),          # DH4 in {8,16,32,50,64} x {store, arg-max}
     ("scan16.hip", "scan16_kernel", 10),
     ("ivf_fine.hip", "ivf_list_kernel", 5),
+    ("ivf_fine.hip", "ivf_list4_kernel", 5),
     ("assign.hip", "assign_kernel", 5),
 ])
 def test_scan_kernels_use_no_scratch(tmp_path, src, pattern, expected):
