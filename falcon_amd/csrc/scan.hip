@@ -199,28 +199,27 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
                                             int fresh, int carry, uint32_t* sel_u, uint32_t* sel_id,
                                             const int64_t* seg_off, const int64_t* seg_src) {
     constexpr int E = FAL_MAX_K_ANN / 64;          // carried keys per lane
-    constexpr int G = MODE == MODE_DENSE ? 1 : R;
-    uint32_t u[R], gid[G], cu[E], cid[E];
+    uint32_t u[R], cu[E], cid[E];
     const float* rl = qy.row + pos + lane;
     float fv[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) fv[i] = rl[i * 64];
-    if (MODE != MODE_DENSE) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int64_t pp = min<int64_t>(pos + i * 64 + lane, qy.nc - 1);
-            int lo = 0, hi = a.n_probe - 1;          // last segment with seg_off <= pp
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
-            }
-            gid[i] = (uint32_t)(seg_src[lo] + (pp - seg_off[lo]));      // position in list order
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) gid[i] = (uint32_t)a.perm[gid[i]];
-    }
+    // ids.  MODE_DENSE: implicit (id0 + stream position).  MODE_IVF: the id of stream position pp is
+    // perm[list-order position of pp] -- a segment search plus a gather -- so it is resolved LAZILY: only for
+    // the k survivors after the rounds (select_rounds), and here only in the rare tie-at-the-threshold path.
     const uint32_t id_lane = (uint32_t)(qy.id0 + pos + lane);
-    auto id_of = [&](int i) -> uint32_t { return MODE == MODE_DENSE ? id_lane + (uint32_t)(i * 64) : gid[MODE == MODE_DENSE ? 0 : i]; };
+    auto real_id = [&](int64_t pp) -> uint32_t {
+        pp = min<int64_t>(pp, qy.nc - 1);
+        int lo = 0, hi = a.n_probe - 1;              // last segment with seg_off <= pp
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
+        }
+        return (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])];
+    };
+    auto id_of = [&](int i) -> uint32_t {
+        return MODE == MODE_DENSE ? id_lane + (uint32_t)(i * 64) : real_id(pos + i * 64 + lane);
+    };
 #pragma unroll
     for (int i = 0; i < R; ++i) u[i] = (i * 64 + lane < fresh) ? max(f32_sortable(fv[i]), 1u) : 0u;
     if (CARRY) {
@@ -303,16 +302,46 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        const bool keep = u[i] != 0 && ((u[i] > T) || (u[i] == T && id_of(i) <= I));
+        // (I is wave-uniform; all-ones = no tie-break in force: ids need not be resolved)
+        const bool keep = u[i] != 0 && ((u[i] > T) || (u[i] == T && (I == 0xFFFFFFFFu || id_of(i) <= I)));
         const uint64_t mask = __ballot(keep);
         if (keep) {
             const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
             sel_u[w] = u[i];
-            sel_id[w] = id_of(i);
+            // MODE_IVF: the stream position, flagged; select_rounds turns the survivors' positions into ids
+            sel_id[w] = MODE == MODE_DENSE ? id_of(i) : (0x80000000u | (uint32_t)(pos + i * 64 + lane));
         }
         base += __popcll(mask);
     }
     return base;
+}
+
+// MODE_IVF: survivors kept as flagged stream positions -> real ids (k / 64 gathers per lane, all in flight together)
+__device__ __forceinline__ void resolve_ids(const SelectArgs& a, const SelQuery& qy, int carry, int lane, uint32_t* sel_id,
+                                            const int64_t* seg_off, const int64_t* seg_src) {
+    constexpr int E = FAL_MAX_K_ANN / 64;
+    uint32_t v[E];
+    int64_t at[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int e = j * 64 + lane;
+        v[j] = e < carry ? sel_id[e] : 0u;
+        const int64_t pp = min<int64_t>((int64_t)(v[j] & 0x7FFFFFFFu), qy.nc - 1);
+        int lo = 0, hi = a.n_probe - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
+        }
+        at[j] = seg_src[lo] + (pp - seg_off[lo]);
+    }
+    uint32_t g[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) g[j] = (uint32_t)a.perm[at[j]];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int e = j * 64 + lane;
+        if (e < carry && (v[j] & 0x80000000u)) sel_id[e] = g[j];
+    }
 }
 
 template <int MODE, int R>
@@ -322,12 +351,20 @@ __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery
     int fresh = (int)min<int64_t>(qy.nc, 64 * R);
     int carry = select_round<MODE, R, false>(a, qy, k, lane, 0, fresh, 0, sel_u, sel_id, seg_off, seg_src);
     __syncthreads();
+    if (MODE != MODE_DENSE) {
+        resolve_ids(a, qy, carry, lane, sel_id, seg_off, seg_src);
+        __syncthreads();
+    }
     if constexpr (R == 16) {         // more than 1024 candidates: further rounds carry the survivors along
         constexpr int RC = 8;        // (fewer fresh keys per round: the carried keys' registers come on top)
         for (int64_t pos = fresh; pos < qy.nc; pos += fresh) {
             fresh = (int)min<int64_t>(qy.nc - pos, 64 * RC);
             carry = select_round<MODE, RC, true>(a, qy, k, lane, pos, fresh, carry, sel_u, sel_id, seg_off, seg_src);
             __syncthreads();
+            if (MODE != MODE_DENSE) {
+                resolve_ids(a, qy, carry, lane, sel_id, seg_off, seg_src);
+                __syncthreads();
+            }
         }
     }
     return carry;

@@ -348,7 +348,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         StageScope ts(ctx, ST_COARSE);
         hipLaunchKernelGGL(probe_totals_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, st, probes, np,
                            coarse_dev, (int)coarse.size(), ivf_tiles, ivf->list_off, totals);
-        FAL_TRY(launch_exclusive_scan(ctx, totals, n_slots, q_sim_off));
+        FAL_TRY(device_scan_i64(ctx, totals, n_slots, q_sim_off, SLOT_MISC2));      // (millions of slots: multi-block)
     }
     // fine-scan tiles: groups of four 32-row list slices for the 4-wave shared-stream kernel (ivf_fine.hip)
     static const bool single_wave = getenv("FALCON_FINE_SINGLEWAVE") != nullptr;      // the one-wave-per-slice form (A/B runs)

@@ -16,7 +16,8 @@ namespace fal {
 // ------------------------------------------------------------------------------------------
 constexpr int kScanBlock = 1024;
 
-__global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t n,
+template <class T>
+__global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(const T* __restrict__ in, int64_t n,
                                                                      int64_t* __restrict__ block_sums) {
     __shared__ int64_t ws[kScanBlock / 64];
     const int64_t i = blockIdx.x * (int64_t)kScanBlock + threadIdx.x;
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(const int32
     }
 }
 
-__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const int32_t* __restrict__ in, int64_t n,
+template <class T>
+__global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const T* __restrict__ in, int64_t n,
                                                                 const int64_t* __restrict__ block_off,
                                                                 int64_t* __restrict__ out) {
     __shared__ int64_t ws[kScanBlock / 64];
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const int32_t* _
 }
 
 // out[0..n) exclusive prefix of in[0..n) ; out[n] = total.  tmp: ceil(n/1024)+1 int64 (x2).
-int device_scan_i32(fal_ctx* ctx, const int32_t* in, int64_t n, int64_t* out, int scratch_slot) {
+template <class T>
+static int device_scan_t(fal_ctx* ctx, const T* in, int64_t n, int64_t* out, int scratch_slot) {
     if (n <= 0) {
         FAL_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(int64_t), ctx->stream));
         return FAL_OK;
@@ -63,13 +66,21 @@ int device_scan_i32(fal_ctx* ctx, const int32_t* in, int64_t n, int64_t* out, in
     FAL_TRY(ctx->reserve(scratch_slot, sizeof(int64_t) * (size_t)(2 * nb + 2), (void**)&tmp));
     int64_t* sums = tmp;
     int64_t* offs = tmp + nb + 1;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel<T>, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, sums);
     FAL_TRY(launch_exclusive_scan(ctx, sums, nb, offs));
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, offs, out);
+    hipLaunchKernelGGL(scan_apply_kernel<T>, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, offs, out);
     // total
     FAL_CHECK_HIP(hipMemcpyAsync(out + n, offs + nb, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
+}
+
+int device_scan_i32(fal_ctx* ctx, const int32_t* in, int64_t n, int64_t* out, int scratch_slot) {
+    return device_scan_t<int32_t>(ctx, in, n, out, scratch_slot);
+}
+
+int device_scan_i64(fal_ctx* ctx, const int64_t* in, int64_t n, int64_t* out, int scratch_slot) {
+    return device_scan_t<int64_t>(ctx, in, n, out, scratch_slot);
 }
 
 // ------------------------------------------------------------------------------------------
