@@ -59,8 +59,14 @@ def test_flat_many_small_batches(ctx, monkeypatch):
         assert_topk_close(sim[a:b], idx[a:b], rs, ri, X[a:b], base=a)
 
 
-@pytest.mark.parametrize("sizes,nlists,d", [([3000], [64], 400), ([900, 40, 2500, 130], [16, 1, 32, 2], 400),
-                                            ([1200], [16], 64)])
+@pytest.mark.parametrize("sizes,nlists,d", [
+    ([3000], [64], 400), ([900, 40, 2500, 130], [16, 1, 32, 2], 400), ([1200], [16], 64),
+    # the shared-stream assignment kernel: two centroid groups (128 + 72, last tile 8 centroids), a 33-list bucket
+    # (second tile holds one centroid), three 2,048-row segments
+    ([5000, 2100], [200, 33], 400),
+    # more than 512 lists: the row-resident assignment kernel
+    ([24000], [600], 64),
+])
 def test_ivf_build_matches_oracle(ctx, sizes, nlists, d):
     import torch
     off = np.concatenate([[0], np.cumsum(sizes)])
