@@ -284,3 +284,31 @@ def test_run_sharded_equals_single_gpu_partition(ctx):
     assert adjusted_rand_score(lab1, labels_w1) == 1.0 and sorted(medoids_w1.tolist()) == sorted(med1.tolist())
     assert np.array_equal(np.unique(labels_w1), np.arange(len(medoids_w1)))
     assert np.array_equal(labels_w1[medoids_w1], np.arange(len(medoids_w1)))          # medoids[c] represents cluster c
+
+
+@pytest.mark.parametrize("rt_tol", [None, 5.0])
+def test_refine_small_and_large_clusters_match_oracle(ctx, rt_tol):
+    """a10 on DBSCAN clusters of 2 ... 700 members: the LDS path (<= 64 members) and the global-scratch path of the
+    refine kernel against the oracle's `postprocess_cluster` (itself pinned to the reference's by the goldens)."""
+    import torch
+    rng = np.random.default_rng(12)
+    sizes = [2, 3, 17, 63, 64, 65, 130, 700, 1, 40]
+    n = sum(sizes)
+    lab = np.concatenate([np.full(s, c, np.int32) for c, s in enumerate(sizes)])
+    # precursor-sorted rows; inside a cluster a few groups 30 ppm apart (split by the 20 ppm rule) plus jitter
+    mz = np.sort(500.0 + 0.015 * rng.integers(0, 4, n) + rng.normal(0, 0.002, n)).astype(np.float32)
+    rt = (rng.integers(0, 3, n) * 8.0 + rng.normal(0, 1.0, n)).astype(np.float32)
+    perm = rng.permutation(n)                       # clusters interleaved over the sorted rows
+    lab = lab[perm]
+    exp = lab.copy()
+    total = 0
+    for c in range(len(sizes)):                     # reference order: cluster by cluster, labels offset by the running total
+        idx = np.flatnonzero(lab == c)
+        sub = np.zeros(len(idx), np.int32)
+        k = fo.postprocess_cluster(sub, mz[idx], rt[idx], 20.0, "ppm", rt_tol, 2, total)
+        exp[idx] = sub
+        total += k
+    out, n_out = ctx.refine_clusters(torch.from_numpy(lab).to(ctx.tdev), len(sizes), ctx.to_dev(mz, torch.float32),
+                                     ctx.to_dev(rt, torch.float32), 20.0, "ppm", rt_tol)
+    assert n_out == total and total > 10
+    assert np.array_equal(out.cpu().numpy(), exp)
