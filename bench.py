@@ -311,7 +311,7 @@ def main():
                        "exchange": (args.exchange + " (CSR all-gatherv, overlapped with the next step)") if exchanging else "none",
                        "partitions": "2 host threads / 2 streams" if args.overlap else "serial",
                        "parallelism": f"bucket-sharded x{world}"},
-            "roofline": {"kernel": "dense_kernel<.,STORE> / ivf_fine_kernel (cosine scan, fp32 MFMA 32x32x2)",
+            "roofline": {"kernel": "dense_kernel<.,STORE> (flat buckets) / ivf_list4_kernel (IVF buckets): cosine scan, fp32 MFMA 32x32x2",
                          "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_MFMA_F32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tf / PEAK_MFMA_F32_TFLOPS, "traffic": pmc_traffic(args),
                          "traffic_unit": "HBM bytes per launch (PMC, profiles/r1_pmc_hbm_traffic_per_step.json)",
