@@ -105,7 +105,12 @@ class ClusterPipeline:
         order, mzs = c.sort_by_precursor(pmz)
         rts = c.gather_f32(ds.retention_time, order) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
-        return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list_rule(np.diff(splits), p.n_probe))
+        n_list = n_list_rule(np.diff(splits), p.n_probe)
+        if p.dtype == "f16":
+            # float16 vectors (BASELINE config 5): no float32 rows to train an index on, and the f16 matrix cores
+            # scan a whole bucket faster than the fp32 path runs k-means on it -- every bucket is searched exhaustively
+            n_list[:] = 1
+        return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list)
 
     def _search(self, ds, st, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, p, keep_intermediates):
         """a2/a3 vectorise, a6 index, a7 search, a8 filter (+ f4 re-scoring): fills st["nb_idx"], st["nb_dist"]."""
@@ -117,9 +122,6 @@ class ClusterPipeline:
                                      p.hash_seed, True, dt)
         X = X16 = None
         if p.dtype == "f16":
-            if not all_flat:
-                raise _device.FalconHipError("dtype='f16' supports flat buckets only in this build "
-                                             "(a bucket needs an IVF index: lower batch_size / mz_interval)")
             X16 = vec("f16")
         elif p.scan == "f16x3":
             X16 = vec("split16")

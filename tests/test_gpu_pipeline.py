@@ -312,3 +312,26 @@ def test_refine_small_and_large_clusters_match_oracle(ctx, rt_tol):
                                      ctx.to_dev(rt, torch.float32), 20.0, "ppm", rt_tol)
     assert n_out == total and total > 10
     assert np.array_equal(out.cpu().numpy(), exp)
+
+
+def test_pipeline_f16_large_bucket_is_searched_exhaustively(ctx):
+    """dtype="f16" (config 5) with a bucket far beyond the flat limit (5,000 spectra in one precursor window, where the
+    float32 path would train a 64-list index): the float16 path scans it exhaustively -- same clustering as the
+    float32 path told to probe every list."""
+    import warnings
+    from sklearn.metrics import adjusted_rand_score
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset, n_list_rule
+    d = synth.select_charge(synth.generate(12000, seed=31), 2)
+    pm = (600.0 + (d["precursor_mz"] - d["precursor_mz"].min()) / np.ptp(d["precursor_mz"]) * 0.9).astype(np.float32)
+    ds = SpectrumDataset(pm, d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+    assert n_list_rule(np.array([len(ds)]), 16)[0] > 16                       # the float32 rule wants an IVF index here
+    pipe = ClusterPipeline(ctx)
+    args = (2000.0, "ppm", None, 0.05, 2 ** 15)                               # wide tolerance: one bucket, everything comparable
+    lab16, med16 = pipe.run(ds, *args, AnnParams(eps=0.3, dtype="f16", low_dim=400))
+    lab32, _ = pipe.run(ds, *args, AnnParams(eps=0.3, low_dim=400, n_probe=128))   # n_list <= n_probe: exhaustive fp32
+    lab16, lab32, med16 = lab16.cpu().numpy(), lab32.cpu().numpy(), med16.cpu().numpy()
+    assert np.array_equal(np.unique(lab16), np.arange(len(med16)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert adjusted_rand_score(lab32, lab16) >= 0.99          # same vectors up to float16 rounding
