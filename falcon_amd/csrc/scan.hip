@@ -317,31 +317,99 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
 }
 
 // MODE_IVF: survivors kept as flagged stream positions -> real ids (k / 64 gathers per lane, all in flight together)
+template <int E = FAL_MAX_K_ANN / 64>
 __device__ __forceinline__ void resolve_ids(const SelectArgs& a, const SelQuery& qy, int carry, int lane, uint32_t* sel_id,
                                             const int64_t* seg_off, const int64_t* seg_src) {
-    constexpr int E = FAL_MAX_K_ANN / 64;
     uint32_t v[E];
     int64_t at[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const int e = j * 64 + lane;
-        v[j] = e < carry ? sel_id[e] : 0u;
-        const int64_t pp = min<int64_t>((int64_t)(v[j] & 0x7FFFFFFFu), qy.nc - 1);
-        int lo = 0, hi = a.n_probe - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
+        v[j] = 0u;
+        at[j] = 0;
+        if (j * 64 < carry) {                            // wave-uniform: registers beyond the set cost nothing
+            const int e = j * 64 + lane;
+            v[j] = e < carry ? sel_id[e] : 0u;
+            const int64_t pp = min<int64_t>((int64_t)(v[j] & 0x7FFFFFFFu), qy.nc - 1);
+            int lo = 0, hi = a.n_probe - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
+            }
+            at[j] = seg_src[lo] + (pp - seg_off[lo]);
         }
-        at[j] = seg_src[lo] + (pp - seg_off[lo]);
     }
     uint32_t g[E];
 #pragma unroll
-    for (int j = 0; j < E; ++j) g[j] = (uint32_t)a.perm[at[j]];
+    for (int j = 0; j < E; ++j) g[j] = (j * 64 < carry) ? (uint32_t)a.perm[at[j]] : 0u;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int e = j * 64 + lane;
         if (e < carry && (v[j] & 0x80000000u)) sel_id[e] = g[j];
     }
+}
+
+// entries the selected set may hold in LDS while a long row streams by (k survivors + one 512-key chunk + slack)
+constexpr int kSelBuf = FAL_MAX_K_ANN + 512;
+
+// cut the set in LDS (cnt > k entries with explicit ids) back to its k best; *T = the k-th best key
+template <int EC>
+__device__ __forceinline__ int reselect(uint32_t* sel_u, uint32_t* sel_id, int cnt, int k, int lane, uint32_t* T_out) {
+    uint32_t u[EC], id[EC];
+#pragma unroll
+    for (int j = 0; j < EC; ++j) {
+        const int e = j * 64 + lane;
+        u[j] = e < cnt ? sel_u[e] : 0u;
+        id[j] = sel_id[e];
+    }
+    __syncthreads();                 // all reads done before the set is rewritten
+    uint32_t T = 0, I = 0xFFFFFFFFu;
+    bool exact = false;
+    for (int bit = 31; bit >= 0; --bit) {                  // largest T with count(key >= T) >= k
+        const uint32_t c = T | (1u << bit);
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < EC; ++j) n += wave_count(u[j] >= c);
+        if (n >= k) T = c;
+        if (n == k) {
+            exact = true;
+            break;
+        }
+    }
+    if (!exact) {
+        int gt = 0, eq = 0;
+#pragma unroll
+        for (int j = 0; j < EC; ++j) {
+            gt += wave_count(u[j] > T);
+            eq += wave_count(u[j] == T);
+        }
+        const int need = k - gt;
+        if (eq > need) {
+            uint32_t lo = 0;          // largest value with count(key == T && id < lo) < need
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t c = lo | (1u << bit);
+                int n = 0;
+#pragma unroll
+                for (int j = 0; j < EC; ++j) n += wave_count(u[j] == T && id[j] < c);
+                if (n < need) lo = c;
+            }
+            I = lo;
+        }
+    }
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < EC; ++j) {
+        const bool keep = u[j] != 0 && ((u[j] > T) || (u[j] == T && id[j] <= I));
+        const uint64_t mask = __ballot(keep);
+        if (keep) {
+            const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
+            sel_u[w] = u[j];
+            sel_id[w] = id[j];
+        }
+        base += __popcll(mask);
+    }
+    __syncthreads();
+    *T_out = T;
+    return base;
 }
 
 template <int MODE, int R>
@@ -355,16 +423,51 @@ __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery
         resolve_ids(a, qy, carry, lane, sel_id, seg_off, seg_src);
         __syncthreads();
     }
-    if constexpr (R == 16) {         // more than 1024 candidates: further rounds carry the survivors along
-        constexpr int RC = 8;        // (fewer fresh keys per round: the carried keys' registers come on top)
-        for (int64_t pos = fresh; pos < qy.nc; pos += fresh) {
-            fresh = (int)min<int64_t>(qy.nc - pos, 64 * RC);
-            carry = select_round<MODE, RC, true>(a, qy, k, lane, pos, fresh, carry, sel_u, sel_id, seg_off, seg_src);
-            __syncthreads();
-            if (MODE != MODE_DENSE) {
-                resolve_ids(a, qy, carry, lane, sel_id, seg_off, seg_src);
+    if constexpr (R == 16) {
+        // More than 1,024 candidates: stream the rest.  After the first round the k-th best value T is known; a later
+        // key can only matter if it beats T, and with candidates in no particular order ever fewer do (~k ln(nc/1024)
+        // in total).  So a chunk costs its loads, one compare per key and a ballot per register; only survivors are
+        // appended to the set in LDS, and the set is cut back to k (tightening T) when it outgrows its buffer.
+        constexpr int RS = 8;                              // keys per lane per chunk (512 per chunk)
+        if (qy.nc > 64 * R) {
+            uint32_t T = 0xFFFFFFFFu;                      // the smallest kept key = k-th best so far (carry == k here)
+            for (int e = lane; e < carry; e += 64) T = min(T, sel_u[e]);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) T = min(T, (uint32_t)__shfl_xor((int)T, off, 64));
+            int cnt = carry;
+            for (int64_t pos = fresh; pos < qy.nc; pos += 64 * RS) {
+                const int nf = (int)min<int64_t>(qy.nc - pos, 64 * RS);
+                const float* rl = qy.row + pos + lane;
+                float fv[RS];
+#pragma unroll
+                for (int i = 0; i < RS; ++i) fv[i] = rl[i * 64];
+#pragma unroll
+                for (int i = 0; i < RS; ++i) {
+                    const uint32_t u = (i * 64 + lane < nf) ? max(f32_sortable(fv[i]), 1u) : 0u;
+                    // MODE_DENSE: ids grow with the position, an equal key further on loses the tie.  MODE_IVF: ids are
+                    // arbitrary, equal keys stay in the race until ids are resolved.
+                    const bool in = MODE == MODE_DENSE ? u > T : u >= T;
+                    const uint64_t mask = __ballot(in);
+                    if (mask) {                            // wave-uniform
+                        if (in) {
+                            const int wpos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+                            sel_u[wpos] = u;
+                            sel_id[wpos] = MODE == MODE_DENSE ? (uint32_t)(qy.id0 + pos + i * 64 + lane)
+                                                              : (0x80000000u | (uint32_t)(pos + i * 64 + lane));
+                        }
+                        cnt += __popcll(mask);
+                    }
+                }
                 __syncthreads();
+                if (cnt > kSelBuf - 64 * RS || pos + 64 * RS >= qy.nc) {      // no room for another chunk, or the end
+                    if (MODE != MODE_DENSE) {
+                        resolve_ids<kSelBuf / 64>(a, qy, cnt, lane, sel_id, seg_off, seg_src);
+                        __syncthreads();
+                    }
+                    if (cnt > k) cnt = reselect<kSelBuf / 64>(sel_u, sel_id, cnt, k, lane, &T);
+                }
             }
+            carry = cnt;
         }
     }
     return carry;
@@ -540,8 +643,8 @@ __device__ __forceinline__ void filter_sort_store(const SelectArgs& a, const uin
 
 template <int MODE, bool FUSE>
 __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
-    __shared__ uint32_t sel_u[FAL_MAX_K_ANN];
-    __shared__ uint32_t sel_id[FAL_MAX_K_ANN];
+    __shared__ uint32_t sel_u[kSelBuf];       // the selected set (+ room for one streamed chunk of a long row)
+    __shared__ uint32_t sel_id[kSelBuf];
     __shared__ int64_t seg_off[FAL_MAX_N_PROBE + 1];   // MODE_IVF: stream offset of each probed list
     __shared__ int64_t seg_src[FAL_MAX_N_PROBE];       // MODE_IVF: perm position of each probed list
     const int lane = threadIdx.x;
@@ -595,9 +698,8 @@ __global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
     else carry = select_rounds<MODE, 16>(a, qy, k, lane, sel_u, sel_id, seg_off, seg_src);
 
     if constexpr (FUSE) {
-        __shared__ uint32_t f_u[FAL_MAX_K_ANN];
-        __shared__ uint32_t f_lo[FAL_MAX_K_ANN];
-        filter_sort_store(a, sel_u, sel_id, f_u, f_lo, carry, out_row, lane);
+        // the survivors of the filter go to the tail of the set's buffers (free once the selection is done)
+        filter_sort_store(a, sel_u, sel_id, sel_u + FAL_MAX_K_ANN, sel_id + FAL_MAX_K_ANN, carry, out_row, lane);
     } else {
         float* osim = a.out_sim + out_row * k;
         int32_t* oidx = a.out_idx + out_row * k;
