@@ -91,8 +91,8 @@ def pmc_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spectra", type=int, default=1_000_000, help="spectra per GPU")
     ap.add_argument("--low_dim", type=int, default=400)
     ap.add_argument("--n_probe", type=int, default=16)
