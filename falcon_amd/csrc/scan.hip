@@ -348,8 +348,9 @@ __device__ __forceinline__ void resolve_ids(const SelectArgs& a, const SelQuery&
     }
 }
 
-// entries the selected set may hold in LDS while a long row streams by (k survivors + one 512-key chunk + slack)
-constexpr int kSelBuf = FAL_MAX_K_ANN + 512;
+// entries the selected set may hold in LDS while a long row streams by (k survivors + one 256-key chunk); kept small:
+// the kernel is latency-bound and LDS is what limits the waves per CU
+constexpr int kSelBuf = FAL_MAX_K_ANN + 256;
 
 // cut the set in LDS (cnt > k entries with explicit ids) back to its k best; *T = the k-th best key
 template <int EC>
@@ -428,7 +429,7 @@ __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery
         // key can only matter if it beats T, and with candidates in no particular order ever fewer do (~k ln(nc/1024)
         // in total).  So a chunk costs its loads, one compare per key and a ballot per register; only survivors are
         // appended to the set in LDS, and the set is cut back to k (tightening T) when it outgrows its buffer.
-        constexpr int RS = 8;                              // keys per lane per chunk (512 per chunk)
+        constexpr int RS = 4;                              // keys per lane per chunk (256 per chunk)
         if (qy.nc > 64 * R) {
             uint32_t T = 0xFFFFFFFFu;                      // the smallest kept key = k-th best so far (carry == k here)
             for (int e = lane; e < carry; e += 64) T = min(T, sel_u[e]);
@@ -642,7 +643,7 @@ __device__ __forceinline__ void filter_sort_store(const SelectArgs& a, const uin
 }
 
 template <int MODE, bool FUSE>
-__global__ __launch_bounds__(64) void select_kernel(SelectArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DENSE ? 8 : 3, 8))) void select_kernel(SelectArgs a) {
     __shared__ uint32_t sel_u[kSelBuf];       // the selected set (+ room for one streamed chunk of a long row)
     __shared__ uint32_t sel_id[kSelBuf];
     __shared__ int64_t seg_off[FAL_MAX_N_PROBE + 1];   // MODE_IVF: stream offset of each probed list

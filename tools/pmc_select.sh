@@ -2,13 +2,13 @@
 # PMC counters for the select kernel (separate passes), summarised per kernel
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM"; do
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM"; do
   tag=$(echo $set | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_sel_$tag -o r -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_sel_$tag -o r -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
 done
 python3 - <<PY
 import sqlite3, glob, collections
-for db in sorted(glob.glob("$R/gpurun_out/pmc_sel_*/r_results.db")):
+for db in sorted(glob.glob("/tmp/pmc_sel_*/r_results.db")):
     c = sqlite3.connect(db)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for name, cn, v in c.execute("select kernel_name, counter_name, value from counters_collection"):
