@@ -93,3 +93,30 @@ def test_main_preprocesses_raw_spectra_on_the_device(tmp_path):
             np.testing.assert_allclose(part["intensity"][a:b], e["intensity"], rtol=3e-6)
             seen += 1
     assert seen == len(expected) and 50 < seen < len(specs)
+
+
+def test_main_with_rescore_option(tmp_path):
+    """`--rescore`: the neighbours are re-scored with the matched-peak cosine (similarity.py:17-80) using
+    --fragment_tol / --min_matched_peaks before DBSCAN; main() runs through and records the option."""
+    from falcon_amd import synth
+    from falcon_amd.falcon import main
+    from falcon_amd.ms_io import ms_io
+    d = synth.generate(1500, seed=4)
+    specs = [{"identifier": f"scan={i}", "precursor_mz": float(d["precursor_mz"][i]),
+              "precursor_charge": int(d["precursor_charge"][i]), "retention_time": float(d["retention_time"][i]),
+              "mz": d["mz"][d["indptr"][i]:d["indptr"][i + 1]].astype(np.float64),
+              "intensity": d["intensity"][d["indptr"][i]:d["indptr"][i + 1]]} for i in range(1500)]
+    mgf = str(tmp_path / "in.mgf")
+    ms_io.write_spectra(mgf, specs)
+    outs = {}
+    for name, extra in (("plain", []), ("rescored", ["--rescore", "--min_matched_peaks", "4"])):
+        out = str(tmp_path / name)
+        assert main([mgf, out, "--eps", "0.3", "--remove_precursor_tol", "0.0", "--min_intensity", "0.0",
+                     "--work_dir", str(tmp_path / ("w_" + name))] + extra) == 0
+        lines = open(out + ".csv").read().splitlines()
+        assert f"# rescore = {name == 'rescored'}" in lines
+        body = [l for l in lines if not l.startswith("#")][1:]
+        outs[name] = np.array([int(l.split(",")[5]) for l in body])
+    for lab in outs.values():
+        assert len(lab) == 1500 and np.array_equal(np.unique(lab), np.arange(lab.max() + 1))
+    assert len(np.unique(outs["rescored"])) != len(np.unique(outs["plain"])) or not np.array_equal(outs["rescored"], outs["plain"])
