@@ -32,7 +32,8 @@ for case in range(n_cases):
     ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"],
                                      precursor_tol=tol, rt_tol=rt_tol, **opts)
     t_or = time.time() - t
-    p = AnnParams(**opts)
+    scan = str(rng.choice(["f32", "f32", "f16x3"])) if opts["low_dim"] in (64, 128, 256, 400) else "f32"
+    p = AnnParams(scan=scan, **opts)
     lab, med = pipe.run(ds, tol[0], tol[1], rt_tol, 0.05, 2 ** 15, p)
     lab, med = lab.cpu().numpy(), med.cpu().numpy()
     same_lab, same_med = np.array_equal(lab, ref), np.array_equal(med, rmed)
@@ -47,7 +48,7 @@ for case in range(n_cases):
     same_many = np.array_equal(many[0].cpu().numpy(), lab)
     flag = "OK " if (same or ari >= 0.99) and same_many and med_ok else "BAD"
     bad += flag == "BAD"
-    print(f"{flag} case {case}: n={len(ds)} {opts} tol={tol} rt={rt_tol} labels_identical={same_lab} medoids_identical={same_med} (differing: {int((med != rmed).sum()) if len(med) == len(rmed) else -1}) ari={ari:.5f} clusters={len(med)} "
+    print(f"{flag} case {case}: n={len(ds)} scan={scan} {opts} tol={tol} rt={rt_tol} labels_identical={same_lab} medoids_identical={same_med} (differing: {int((med != rmed).sum()) if len(med) == len(rmed) else -1}) ari={ari:.5f} clusters={len(med)} "
           f"run_many_same={same_many} oracle {t_or:.1f}s", flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)
