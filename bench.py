@@ -8,11 +8,15 @@ medoids/labels) on synthetic peak lists, plus the cosine kernel's roofline fract
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over this rank's shard (default 1,000,000 synthetic
-spectra = BASELINE.json configs[1]; both charge partitions, like falcon.py:151-193).
+spectra = BASELINE.json configs[1]; both charge partitions, like falcon.py:151-193, software-pipelined
+on the one GPU by `ClusterPipeline.run_many`; `--serial` runs them strictly one after the other).
 Inputs are resident in HBM before the timed region; the step ends with the labels on the
-host.  Weak scaling: every rank owns an independent shard (its own 1M-spectrum block of
+host.  Before the W warmup steps three untimed passes bring the scratch pool / caching
+allocator to their steady-state sizes (setup, like the data generation).
+Weak scaling: every rank owns an independent shard (its own 1M-spectrum block of
 the generator = its own (charge, bucket) units); the only collective is the result
-all-gatherv (neighbour lists by default, `--exchange labels` for labels only).
+all-gatherv (CSR neighbour lists + labels by default, asynchronous: it travels while the next step
+computes; `--exchange labels|none` for the cheaper exchanges).
 
 Prints ONE JSON line on rank 0.
 """
