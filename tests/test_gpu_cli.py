@@ -1,5 +1,5 @@
 """`falcon.main()` end to end on the HIP path: MGF in, CSV (+ representatives MGF) out
-(reference falcon.py:33-244 contract; BASELINE config 1 driven through the GPU)."""
+(reference falcon.py:33-244 contract; BASELINE configs[0] -- 10k synthetic MGF spectra, low_dim 400 -- driven through the GPU)."""
 import os
 
 import numpy as np
@@ -14,9 +14,9 @@ def test_main_mgf_to_csv(tmp_path):
     from falcon_amd import synth
     from falcon_amd.falcon import main
     from falcon_amd.ms_io import ms_io
-    d = synth.generate(3000, seed=21)
+    d = synth.generate(10000, seed=21)
     specs = []
-    for i in range(3000):
+    for i in range(10000):
         a, b = d["indptr"][i], d["indptr"][i + 1]
         specs.append({"identifier": f"scan={i}", "precursor_mz": float(d["precursor_mz"][i]),
                       "precursor_charge": int(d["precursor_charge"][i]), "retention_time": float(d["retention_time"][i]),
@@ -33,7 +33,7 @@ def test_main_mgf_to_csv(tmp_path):
     body = lines[len(head):]
     assert body[0] == "filename,spectrum_id,precursor_charge,precursor_mz,retention_time,cluster"
     rows = [l.split(",") for l in body[1:]]
-    assert len(rows) == 3000
+    assert len(rows) == 10000
     ids = [r[1] for r in rows]
     assert ids[:3] == ["scan=0", "scan=1", "scan=2"] and ids[10] == "scan=10"      # natural sort
     lab = np.array([int(r[5]) for r in rows])
