@@ -318,11 +318,17 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         std::vector<AssignJob> ajobs;
         std::vector<DenseJob> djobs;
         int64_t dtiles = 0;
+        // rows per job: long segments amortise the resident centroid tiles, but with only a few indexed buckets long
+        // segments leave most CUs idle -- aim for >= 4 workgroups per CU, between 256 and kAssignSeg rows
+        int64_t work_rows = 0;
+        for (const BucketDev& b : bk)
+            if (!row_major && b.n_list <= kAssignMaxLists) work_rows += (int64_t)b.n * ceil_div(b.n_list, kAssignGroup);
+        const int64_t seg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(work_rows, (int64_t)ctx->num_cus * 4 * 32) * 32));
         for (const BucketDev& b : bk) {
             if (!row_major && b.n_list <= kAssignMaxLists) {
-                for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg)
+                for (int64_t s0 = 0; s0 < b.n; s0 += seg)
                     for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)
-                        ajobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0),
+                        ajobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(seg, b.n - s0),
                                          std::min(kAssignGroup, b.n_list - t0), t0, 0});
             } else {
                 djobs.push_back({b.row0, b.list0, 0, dtiles, b.n, b.n_list, 0});
