@@ -131,6 +131,58 @@ __global__ __launch_bounds__(256, 1) void assign_kernel(const float* __restrict_
     if (active) epilogue();
 }
 
+// Buckets with one or two centroid tiles (n_list <= 64): a 4-wave workgroup would idle two or three of its waves.
+// One wave per (row segment, 32-centroid tile) instead, rows streamed row-per-lane straight from L2 / HBM with the
+// pinned load ring of simtile.h -- with so few tiles the rows are re-read at most twice.
+template <int DH4>
+__global__ __launch_bounds__(64, 1) void assign_wave_kernel(const float* __restrict__ X, const float* __restrict__ Cn, int d,
+                                                            const AssignJob* __restrict__ jobs, int64_t n_jobs,
+                                                            unsigned long long* __restrict__ keys) {
+    const int64_t per_xcd = (n_jobs + 7) / 8;
+    const int64_t ji = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || ji >= n_jobs) return;
+    const AssignJob job = jobs[ji];
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int dh = d >> 1, dh4 = dh >> 2;
+    const int nr = job.nrows;
+    float q[DH4 * 4];            // this lane's k-half of centroid min(r, ncent - 1) of the tile
+    load_half_row<DH4>(q, Cn + (job.cent0 + min(r, job.ncent - 1)) * d + (int64_t)h * dh, dh4);
+    CandStream<DH4> cs;
+    const float* cur = X + (job.row0 + min(r, nr - 1)) * d + (int64_t)h * dh;
+    cs.prime(cur, dh4);
+    f32x16 prev;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) prev[i] = -INFINITY;
+    int prev_c0 = 0;
+    auto epilogue = [&]() {      // as in assign_kernel; every lane issues the atomic (both halves hold the same key)
+        float best = -INFINITY;
+        int bid = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = mfma32_row(i, h);
+            const float s = c < job.ncent ? prev[i] : -INFINITY;
+            const bool up = s > best;
+            best = up ? s : best;
+            bid = up ? c : bid;
+        }
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oc = __shfl_xor(bid, 32, 64);
+        const bool take = ob > best || (ob == best && oc < bid);
+        best = take ? ob : best;
+        bid = take ? oc : bid;
+        const unsigned long long key = ((unsigned long long)f32_sortable(best) << 32) | (uint32_t)~(uint32_t)(job.id_base + bid);
+        atomicMax(keys + job.row0 + min(prev_c0 + r, nr - 1), key);
+    };
+    for (int c0 = 0; c0 < nr; c0 += 32) {
+        const float* nxt = X + (job.row0 + min(c0 + 32 + r, nr - 1)) * d + (int64_t)h * dh;
+        const f32x16 acc = cs.template dot<true>(q, cur, nxt, dh4, epilogue);
+        prev = acc;
+        prev_c0 = c0;
+        cur = nxt;
+    }
+    epilogue();
+}
+
 __global__ void assign_unpack_kernel(const unsigned long long* __restrict__ keys, int64_t n, int32_t* __restrict__ assign) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned long long k = keys[i];
@@ -139,16 +191,24 @@ __global__ void assign_unpack_kernel(const unsigned long long* __restrict__ keys
 }
 
 int launch_assign(fal_ctx* ctx, int stage, const float* X, const float* centroids, int d, const AssignJob* jobs, int64_t n_jobs,
-                  int64_t n, unsigned long long* keys, int32_t* assign) {
-    if (n_jobs <= 0 || n <= 0) return FAL_OK;
+                  int64_t n_wave_jobs, int64_t n, unsigned long long* keys, int32_t* assign) {
+    // jobs[0, n_jobs): 4-wave shared-stream jobs; jobs[n_jobs, n_jobs + n_wave_jobs): one-wave jobs (one centroid tile each)
+    if (n_jobs + n_wave_jobs <= 0 || n <= 0) return FAL_OK;
     const int dh4 = d / 8;
-    const int64_t per_xcd = (n_jobs + 7) / 8;
-    FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many assignment jobs in one launch");
+    const int64_t per_xcd = (n_jobs + 7) / 8, per_xcd_w = (n_wave_jobs + 7) / 8;
+    FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX && per_xcd_w * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED,
+                "too many assignment jobs in one launch");
     StageScope ts(ctx, stage);
     FAL_CHECK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)n, ctx->stream));
-    dim3 grid((unsigned)(per_xcd * 8)), block(256);
-#define FAL_LAUNCH_ASSIGN(DH4) \
-    hipLaunchKernelGGL((assign_kernel<DH4>), grid, block, 0, ctx->stream, X, centroids, d, jobs, n_jobs, keys)
+    dim3 grid((unsigned)(per_xcd * 8)), block(256), grid_w((unsigned)(per_xcd_w * 8)), block_w(64);
+#define FAL_LAUNCH_ASSIGN(DH4)                                                                                          \
+    do {                                                                                                                \
+        if (n_jobs > 0)                                                                                                 \
+            hipLaunchKernelGGL((assign_kernel<DH4>), grid, block, 0, ctx->stream, X, centroids, d, jobs, n_jobs, keys); \
+        if (n_wave_jobs > 0)                                                                                            \
+            hipLaunchKernelGGL((assign_wave_kernel<DH4>), grid_w, block_w, 0, ctx->stream, X, centroids, d, jobs + n_jobs, \
+                               n_wave_jobs, keys);                                                                      \
+    } while (0)
     if (dh4 <= 8) FAL_LAUNCH_ASSIGN(8);
     else if (dh4 <= 16) FAL_LAUNCH_ASSIGN(16);
     else if (dh4 <= 32) FAL_LAUNCH_ASSIGN(32);

@@ -322,10 +322,21 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         // segments leave most CUs idle -- aim for >= 4 workgroups per CU, between 256 and kAssignSeg rows
         int64_t work_rows = 0;
         for (const BucketDev& b : bk)
-            if (!row_major && b.n_list <= kAssignMaxLists) work_rows += (int64_t)b.n * ceil_div(b.n_list, kAssignGroup);
+            if (!row_major && b.n_list > 64 && b.n_list <= kAssignMaxLists) work_rows += (int64_t)b.n * ceil_div(b.n_list, kAssignGroup);
         const int64_t seg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(work_rows, (int64_t)ctx->num_cus * 4 * 32) * 32));
+        // buckets with one or two centroid tiles take one-wave jobs (a 4-wave workgroup would idle most of its waves)
+        std::vector<AssignJob> wjobs;
+        int64_t wave_rows = 0;
+        for (const BucketDev& b : bk)
+            if (!row_major && b.n_list <= 64) wave_rows += (int64_t)b.n * ceil_div(b.n_list, 32);
+        const int64_t wseg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(wave_rows, (int64_t)ctx->num_cus * 16 * 32) * 32));
         for (const BucketDev& b : bk) {
-            if (!row_major && b.n_list <= kAssignMaxLists) {
+            if (!row_major && b.n_list <= 64) {
+                for (int64_t s0 = 0; s0 < b.n; s0 += wseg)
+                    for (int t0 = 0; t0 < b.n_list; t0 += 32)
+                        wjobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(wseg, b.n - s0),
+                                         std::min(32, b.n_list - t0), t0, 0});
+            } else if (!row_major && b.n_list <= kAssignMaxLists) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += seg)
                     for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)
                         ajobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(seg, b.n - s0),
@@ -338,6 +349,8 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         AssignJob* ajobs_dev = nullptr;
         DenseJob* djobs_dev = nullptr;
         unsigned long long* keys = nullptr;
+        const int64_t n_wide = (int64_t)ajobs.size(), n_wave = (int64_t)wjobs.size();
+        ajobs.insert(ajobs.end(), wjobs.begin(), wjobs.end());
         if (!ajobs.empty()) {
             B_TRY(ctx->reserve(SLOT_JOBS2, sizeof(AssignJob) * ajobs.size(), (void**)&ajobs_dev));
             B_TRY(ctx->upload(ajobs_dev, ajobs.data(), sizeof(AssignJob) * ajobs.size()));
@@ -351,8 +364,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,
                                    dtiles, nullptr, 0, ivf->assign));
-            B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, (int64_t)ajobs.size(), n, keys,
-                                ivf->assign));
+            B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, n_wide, n_wave, n, keys, ivf->assign));
             if (it == kmeans_iters) break;   // final assignment against the final centroids
             StageScope ts(ctx, ST_BUILD);
             hipLaunchKernelGGL(list_walk_kernel<0>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign,

@@ -61,8 +61,9 @@ struct AssignJob {
     int32_t pad;
 };
 // keys: u64[n] scratch (cleared here); assign[i] is written for every row a job covers
+// jobs[0, n_jobs): 4-wave jobs (<= 128 centroids each); jobs[n_jobs, n_jobs + n_wave_jobs): one-wave jobs (<= 32 centroids)
 int launch_assign(fal_ctx* ctx, int stage, const float* X, const float* centroids, int d, const AssignJob* jobs, int64_t n_jobs,
-                  int64_t n, unsigned long long* keys, int32_t* assign);
+                  int64_t n_wave_jobs, int64_t n, unsigned long long* keys, int32_t* assign);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order

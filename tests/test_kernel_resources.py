@@ -37,6 +37,7 @@ def _kernel_scratch(src, tmp_path):
     ("ivf_fine.hip", "ivf_list_kernel", 5),
     ("ivf_fine.hip", "ivf_list4_kernel", 5),
     ("assign.hip", "assign_kernel", 5),
+    ("assign.hip", "assign_wave_kernel", 5),
 ])
 def test_scan_kernels_use_no_scratch(tmp_path, src, pattern, expected):
     res = {k: v for k, v in _kernel_scratch(os.path.join(CSRC, src), tmp_path).items() if pattern in k}
