@@ -59,6 +59,8 @@ _SIGNATURES = {
                                c_int], c_int),
     "fal_neighbors_to_csr": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
                              c_int),
+    "fal_neighbors_to_csr_mapped": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int64, c_void_p,
+                                     c_void_p, c_void_p], c_int),
     "fal_dbscan": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, P(c_int64)], c_int),
     "fal_refine_clusters": ([c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_double, c_int, c_double,
                              P(c_int64)], c_int),

@@ -43,6 +43,9 @@ class AnnParams:
     rescore: bool = False         # re-score the ANN neighbours with the reference's matched-peak cosine
                                   # (similarity.py:17-80) before DBSCAN; uses fragment_tol and min_matches
     min_matches: int = 0          # (set from generate_clusters' `min_matches` when rescore is on)
+    clustering: str = "dbscan"    # "dbscan" (README.md:143-146) or "hierarchical": the snapshot's linkage + fcluster at
+                                  # the distance threshold (cluster.py:283-290) on the re-scored neighbour graph
+    linkage: str = "complete"     # (set from generate_clusters' `linkage` when clustering == "hierarchical")
 
 
 def n_list_rule(sizes: np.ndarray, n_probe: int) -> np.ndarray:
@@ -112,6 +115,25 @@ class ClusterPipeline:
             n_list[:] = 1
         return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list)
 
+    def _restrict(self, c, st, p, shard):
+        """One dataset on several GPUs (reference analogue: blocks are clustered independently and only
+        their labels are offset afterwards, cluster.py:115-155).  Every rank derived the SAME buckets in `_front`;
+        buckets are dealt to ranks by longest-processing-time on `distributed.bucket_costs`, and this rank keeps the
+        rows of its own buckets: st becomes the state of that subset (buckets whole and in order), plus
+        `rows` (i64, device: dataset rows of the subset in sorted order) and `n_total`."""
+        import torch
+        from .. import distributed as fdist
+        rank, world = shard
+        splits = np.asarray(st["splits"], np.int64)
+        owner = fdist.shard_units(fdist.bucket_costs(np.diff(splits), st["n_list"], p.n_probe), world)
+        pos, sub_splits, mine = fdist.shard_rows(splits, owner, rank)
+        pos_d = c.to_dev(pos, torch.int64)
+        order_sub = st["order"][pos_d] if len(pos) else st["order"][:0]
+        return dict(order=order_sub, mzs=st["mzs"][pos_d] if len(pos) else st["mzs"][:0],
+                    rts=None if st["rts"] is None else st["rts"][pos_d], splits=sub_splits,
+                    n_list=np.asarray(st["n_list"])[mine], rows=order_sub, n_total=int(st["order"].numel()),
+                    buckets=mine)
+
     def _search(self, ds, st, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, p, keep_intermediates):
         """a2/a3 vectorise, a6 index, a7 search, a8 filter (+ f4 re-scoring): fills st["nb_idx"], st["nb_dist"]."""
         c = self.ctx
@@ -180,11 +202,16 @@ class ClusterPipeline:
         return labels, medoids
 
     def run_many(self, datasets, precursor_tol_mass: float, precursor_tol_mode: str, rt_tol: Optional[float],
-                 fragment_tol: float, batch_size: int, p: AnnParams):
+                 fragment_tol: float, batch_size: int, p: AnnParams, shard: Optional[Tuple[int, int]] = None):
         """Several independent partitions, software-pipelined on one GPU: the light front end of partition i + 1
         (sort + bucket boundaries, on a second stream / context) and its host planning run while the scan of
         partition i occupies the matrix cores; all heavy kernels stay on the pipeline's own stream, in order.
-        Same results as `run` per partition.  -> [(labels, medoids), ...]; `self.lasts` holds every `last`."""
+        Same results as `run` per partition.  -> [(labels, medoids), ...]; `self.lasts` holds every `last`.
+
+        `shard = (rank, world)`: every partition is ONE dataset shared by `world` GPUs; this rank runs the path on
+        its own precursor buckets only (`_restrict`).  Labels / medoids then refer to the rank's rows in sorted
+        order (labels[i] belongs to dataset row lasts[j]["rows"][i]; medoids index the same rows) and
+        lasts[j]["rows"] (i64, device) maps them back -- the exchange step assembles the global result."""
         import torch
         c = self.ctx
         args = (precursor_tol_mass, precursor_tol_mode, rt_tol)
@@ -194,26 +221,43 @@ class ClusterPipeline:
                 self._front_ctx = _device.Context(c.device)               # bound to the front stream
         live = [i for i, ds in enumerate(datasets) if len(ds) > 0]
         states = {}
+        sharded = shard is not None and shard[1] > 1
 
         def front(i):
             with torch.cuda.stream(self._front_stream):
-                states[i] = self._front(self._front_ctx, datasets[i], *args, batch_size, p)
+                st = self._front(self._front_ctx, datasets[i], *args, batch_size, p)
+                if sharded:
+                    st = self._restrict(self._front_ctx, st, p, shard)
+                    # labels refer to the subset's own rows; `rows` maps them to dataset rows
+                    st["order"] = torch.arange(st["rows"].numel(), dtype=torch.int64, device=c.tdev)
+                states[i] = st
 
         if live:
             # inputs may have been produced on the caller's stream
             self._front_stream.wait_stream(torch.cuda.current_stream(c.tdev))
             front(live[0])
         for pos, i in enumerate(live):
-            self._search(datasets[i], states[i], *args, fragment_tol, p, False)   # enqueue only
+            if states[i]["order"].numel() > 0:
+                if sharded:
+                    # the subset's rows in sorted order = dataset rows `rows`: vectorise gathers them from the CSR
+                    st = dict(states[i], order=states[i]["rows"])
+                    torch.cuda.current_stream(c.tdev).wait_stream(self._front_stream)
+                    self._search(datasets[i], st, *args, fragment_tol, p, False)
+                    st["order"] = states[i]["order"]
+                    states[i] = st
+                else:
+                    self._search(datasets[i], states[i], *args, fragment_tol, p, False)   # enqueue only
             if pos + 1 < len(live):
                 front(live[pos + 1])                                               # overlaps the scan just enqueued
         outs, self.lasts = [], []
         for i, ds in enumerate(datasets):
-            if len(ds) == 0:
+            if len(ds) == 0 or states[i]["order"].numel() == 0:
                 outs.append((c.empty((0,), torch.int32), c.empty((0,), torch.int32)))
-                self.lasts.append({})
+                self.lasts.append({"rows": c.empty((0,), torch.int64)} if sharded else {})
                 continue
             labels, medoids, last = self._graph(states[i], *args, p, False)
+            if sharded:
+                last["rows"] = states[i]["rows"]
             outs.append((labels, medoids))
             self.lasts.append(last)
         if self.lasts:
@@ -279,7 +323,9 @@ def generate_clusters(dataset, linkage: str, distance_threshold: float, min_matc
     """Same call as the reference (cluster.py:24-34).  `distance_threshold` is the cosine
     distance threshold and plays the role of DBSCAN's eps (README.md:73-79); `linkage` and
     `min_matches` belong to the snapshot's exact-cosine path: `min_matches` is used when `ann.rescore` is on
-    (matched-peak re-scoring of the ANN neighbours, similarity.py:17-80), `linkage` is accepted but unused.
+    (matched-peak re-scoring of the ANN neighbours, similarity.py:17-80); `linkage` selects the hierarchical
+    clustering of those exact distances when `ann.clustering == "hierarchical"` and is an error otherwise unless
+    it is the reference default "complete".
 
     Returns (labels int32[N] by dataset row with noise renumbered as singletons --
     cluster.py:144-155 --, medoids int32[n_labels]: medoids[c] = dataset row representing
@@ -289,11 +335,24 @@ def generate_clusters(dataset, linkage: str, distance_threshold: float, min_matc
         dataset = SpectrumDataset.from_table(
             dataset.to_table(columns=["precursor_mz", "precursor_charge", "retention_time", "mz", "intensity"])
             if hasattr(dataset, "to_table") else dataset)
-    p = ann or AnnParams()
+    import dataclasses
+    if linkage not in ("complete", "single", "average"):
+        raise ValueError(f"unknown linkage {linkage!r} (choose complete, single or average; cluster.py:283-290)")
     if ann is None:
-        p.eps = distance_threshold
+        p = AnnParams(eps=float(distance_threshold))
+    else:
+        if abs(float(ann.eps) - float(distance_threshold)) > 1e-12:
+            raise ValueError(f"distance_threshold ({distance_threshold}) and ann.eps ({ann.eps}) differ: they name the same "
+                             "cosine-distance threshold (README.md:73-79, config.py:104-111)")
+        p = dataclasses.replace(ann)                 # never mutate the caller's parameters
     if p.rescore:
         p.min_matches = int(min_matches)
+    if p.clustering == "hierarchical":
+        p.linkage = linkage
+    elif linkage != "complete":
+        raise ValueError(f"linkage={linkage!r} only applies to the hierarchical clustering of the exact distances "
+                         "(AnnParams(clustering=\"hierarchical\", rescore=True) / --clustering hierarchical); the default "
+                         "nearest-neighbour path clusters with DBSCAN and would ignore it")
     pipe = pipeline or _default_pipeline
     if pipe is None:
         pipe = _default_pipeline = ClusterPipeline()

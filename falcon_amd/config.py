@@ -40,8 +40,13 @@ class Config:
                        help='Precursor tolerance mass and mode (default: 20 ppm). Mode is "ppm" or "Da".')
         p.add_argument("--rt_tol", type=float, default=None, help="Retention time tolerance (default: none).")
         p.add_argument("--fragment_tol", type=float, default=0.05, help="Fragment mass tolerance in m/z.")
-        p.add_argument("--linkage", type=str, default="complete",
-                       help="(snapshot option, accepted; unused by the nearest-neighbour path)")
+        p.add_argument("--linkage", type=str, default="complete", choices=["complete", "single", "average"],
+                       help="Linkage of the hierarchical clustering (--clustering hierarchical; default: complete). "
+                            "Any other value is an error with the default DBSCAN clustering, which has no linkage.")
+        p.add_argument("--clustering", type=str, default="dbscan", choices=["dbscan", "hierarchical"],
+                       help="dbscan (README: density clustering of the neighbour graph, default) or hierarchical "
+                            "(the snapshot's linkage + cut at the distance threshold, on the re-scored neighbour graph; "
+                            "implies --rescore).")
         p.add_argument("--distance_threshold", type=float, default=0.1,
                        help="Cosine distance threshold; alias of --eps (default: 0.1).")
         p.add_argument("--eps", type=float, default=None,
@@ -70,6 +75,7 @@ class Config:
         p.add_argument("--max_peaks_used", default=50, type=int)
         p.add_argument("--scaling", default="off", type=str, choices=["off", "root", "log", "rank"])
         self._parser = p
+        self._base_defaults = {a.dest: a.default for a in p._actions if a.dest != "help"}
         self._namespace = None
 
     # ------------------------------------------------------------------------------------------
@@ -114,6 +120,9 @@ class Config:
         pre.add_argument("-c", "--config", default=None)
         known, _ = pre.parse_known_args(args_str)
         defaults = self._ini_defaults(known.config)
+        # INI values are defaults of THIS call only: start from the built-in defaults every time (a parser keeps
+        # what set_defaults gave it, and main() / parse() are called repeatedly in one process)
+        self._parser.set_defaults(**self._base_defaults)
         if defaults:
             self._parser.set_defaults(**defaults)
         ns = vars(self._parser.parse_args(args_str))
@@ -124,6 +133,8 @@ class Config:
             ns["eps"] = ns["distance_threshold"]
         else:
             ns["distance_threshold"] = ns["eps"]
+        if ns["clustering"] == "hierarchical":
+            ns["rescore"] = True
         if ns["n_neighbors_ann"] < ns["n_neighbors"]:
             raise ValueError("n_neighbors_ann should be equal or greater than n_neighbors (README.md:110-113)")
         self._namespace = ns

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void nb_count_kernel(const int32_t* __restrict
 // rows known to be front-packed with indptr[row + 1] - indptr[row] entries: only that prefix is read
 __global__ __launch_bounds__(256) void nb_pack_prefix_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
                                                              int64_t n, int k, int64_t id_offset,
+                                                             const int64_t* __restrict__ id_map,
                                                              const int64_t* __restrict__ indptr, int32_t* __restrict__ out_idx,
                                                              float* __restrict__ out_dist) {
     const int lane = threadIdx.x & 63;
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(256) void nb_pack_prefix_kernel(const int32_t* __re
         const int64_t base = indptr[row];
         const int cnt = (int)(indptr[row + 1] - base);
         for (int j = lane; j < cnt; j += 64) {
-            out_idx[base + j] = (int32_t)(nb_idx[row * k + j] + id_offset);
+            const int32_t id = nb_idx[row * k + j];
+            out_idx[base + j] = (int32_t)((id_map ? id_map[id] : (int64_t)id) + id_offset);
             out_dist[base + j] = nb_dist[row * k + j];
         }
     }
@@ -190,6 +192,7 @@ __global__ void nb_chain_kernel(const int64_t* __restrict__ local, int64_t n, in
 
 __global__ __launch_bounds__(256) void nb_pack_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
                                                       int64_t n, int k, int64_t id_offset,
+                                                      const int64_t* __restrict__ id_map,
                                                       const int64_t* __restrict__ indptr, int32_t* __restrict__ out_idx,
                                                       float* __restrict__ out_dist) {
     const int lane = threadIdx.x & 63;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void nb_pack_kernel(const int32_t* __restrict_
             const unsigned long long m = __ballot(valid);
             if (valid) {
                 const int64_t o = base + __popcll(m & ((1ull << lane) - 1ull));
-                out_idx[o] = (int32_t)(id + id_offset);
+                out_idx[o] = (int32_t)((id_map ? id_map[id] : (int64_t)id) + id_offset);
                 out_dist[o] = nb_dist[row * k + j];
             }
             base += __popcll(m);
@@ -233,6 +236,13 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
 
 int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, const int32_t* nb_count, int64_t n, int k,
                          int64_t id_offset, int64_t row0, int64_t* indptr_out, int32_t* idx_out, float* dist_out) {
+    return fal_neighbors_to_csr_mapped(ctx, nb_idx, nb_dist, nb_count, n, k, nullptr, id_offset, row0, indptr_out, idx_out,
+                                       dist_out);
+}
+
+int fal_neighbors_to_csr_mapped(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, const int32_t* nb_count, int64_t n,
+                                int k, const int64_t* id_map, int64_t id_offset, int64_t row0, int64_t* indptr_out,
+                                int32_t* idx_out, float* dist_out) {
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && row0 >= 0, FAL_EINVAL, "fal_neighbors_to_csr: bad argument");
     FAL_REQUIRE(indptr_out, FAL_EINVAL, "fal_neighbors_to_csr: NULL indptr");
     if (row0 == 0) FAL_CHECK_HIP(hipMemsetAsync(indptr_out, 0, sizeof(int64_t), ctx->stream));
@@ -254,10 +264,10 @@ int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_di
                        local, n, indptr_out + row0);
     if (nb_count)
         hipLaunchKernelGGL(nb_pack_prefix_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, id_offset,
-                           indptr_out + row0, idx_out, dist_out);
+                           id_map, indptr_out + row0, idx_out, dist_out);
     else
         hipLaunchKernelGGL(nb_pack_kernel, dim3(grid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, id_offset,
-                           indptr_out + row0, idx_out, dist_out);
+                           id_map, indptr_out + row0, idx_out, dist_out);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

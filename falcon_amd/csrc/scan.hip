@@ -172,9 +172,9 @@ int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* 
 // ---------------------------------------------------------------------------------------------
 // wavefront top-k select: one wave per query over that query's row of sims
 // ---------------------------------------------------------------------------------------------
-// Keys are (sortable sim, id); order = sim descending, then id ascending.  A round holds up to
-// 64*R keys in registers (R per lane; R = 4, 8 or 16 chosen per query from its candidate count):
-// the survivors of earlier rounds plus new candidates.  The k-th largest sim is found by a bitwise
+// Keys are (sortable sim, id); order = sim descending, then id ascending.  The first round holds up to
+// 64*R keys in registers (R per lane; R = 2 ... 16 chosen per query from its candidate count); longer rows
+// stream the rest against the running k-th best value (select_rounds).  The k-th largest sim is found by a bitwise
 // binary search whose counts are wave ballots (v_cmp + s_bcnt1, no LDS) and which stops as soon as
 // a threshold splits off exactly k keys; boundary ties are resolved by a second search over ids.
 // Survivors are compacted into LDS by ballot-prefix ranks; the final <= k keys are sorted by an
@@ -187,27 +187,25 @@ struct SelQuery {
     int64_t id0;          // MODE_DENSE: id = id0 + position
 };
 
-// One round of the selection: R*64 fresh keys from the query's sims row (slot s = i*64 + lane) plus, in
-// later rounds (CARRY), the survivors of the previous round.  Keep the k best: threshold by bitwise
-// search with ballot counts (early exit when a threshold isolates exactly k keys), ties at the
-// threshold by id, survivors compacted into LDS.  Returns how many were kept.
+// The first round of the selection: up to R*64 keys from the query's sims row (slot s = i*64 + lane).  Keep the k
+// best: threshold by bitwise search with ballot counts (early exit when a threshold isolates exactly k keys),
+// ties at the threshold by id, survivors compacted into LDS.  Returns how many were kept.
 //  * loads are unconditional and unclamped (the sims buffer has kSimsSlack floats of slack), so the R
 //    loads of a round are in flight together with immediate offsets;
 //  * MODE_DENSE ids are implicit (id0 + stream position): no id registers, none written until compaction.
-template <int MODE, int R, bool CARRY>
-__device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery& qy, int k, int lane, int64_t pos,
-                                            int fresh, int carry, uint32_t* sel_u, uint32_t* sel_id,
-                                            const int64_t* seg_off, const int64_t* seg_src) {
-    constexpr int E = FAL_MAX_K_ANN / 64;          // carried keys per lane
-    uint32_t u[R], cu[E], cid[E];
-    const float* rl = qy.row + pos + lane;
+template <int MODE, int R>
+__device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery& qy, int k, int lane, int fresh,
+                                            uint32_t* sel_u, uint32_t* sel_id, const int64_t* seg_off,
+                                            const int64_t* seg_src) {
+    uint32_t u[R];
+    const float* rl = qy.row + lane;
     float fv[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) fv[i] = rl[i * 64];
     // ids.  MODE_DENSE: implicit (id0 + stream position).  MODE_IVF: the id of stream position pp is
     // perm[list-order position of pp] -- a segment search plus a gather -- so it is resolved LAZILY: only for
     // the k survivors after the rounds (select_rounds), and here only in the rare tie-at-the-threshold path.
-    const uint32_t id_lane = (uint32_t)(qy.id0 + pos + lane);
+    const uint32_t id_lane = (uint32_t)(qy.id0 + lane);
     auto real_id = [&](int64_t pp) -> uint32_t {
         pp = min<int64_t>(pp, qy.nc - 1);
         int lo = 0, hi = a.n_probe - 1;              // last segment with seg_off <= pp
@@ -218,20 +216,11 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
         return (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])];
     };
     auto id_of = [&](int i) -> uint32_t {
-        return MODE == MODE_DENSE ? id_lane + (uint32_t)(i * 64) : real_id(pos + i * 64 + lane);
+        return MODE == MODE_DENSE ? id_lane + (uint32_t)(i * 64) : real_id(i * 64 + lane);
     };
 #pragma unroll
     for (int i = 0; i < R; ++i) u[i] = (i * 64 + lane < fresh) ? max(f32_sortable(fv[i]), 1u) : 0u;
-    if (CARRY) {
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const int e = j * 64 + lane;
-            cu[j] = e < carry ? sel_u[e] : 0u;
-            cid[j] = sel_id[e];
-        }
-        __syncthreads();             // all reads of sel_* done before they are rewritten
-    }
-    const int m = carry + fresh;
+    const int m = fresh;
 
     uint32_t T = 1, I = 0xFFFFFFFFu;
     if (m > k) {
@@ -243,10 +232,6 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
             int cnt = 0;
 #pragma unroll
             for (int i = 0; i < R; ++i) cnt += wave_count(u[i] >= c);
-            if (CARRY) {
-#pragma unroll
-                for (int j = 0; j < E; ++j) cnt += wave_count(cu[j] >= c);
-            }
             if (cnt >= k) T = c;
             if (cnt == k) {
                 exact = true;
@@ -260,13 +245,6 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
                 gt += wave_count(u[i] > T);
                 eq += wave_count(u[i] == T);
             }
-            if (CARRY) {
-#pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    gt += wave_count(cu[j] > T);
-                    eq += wave_count(cu[j] == T);
-                }
-            }
             const int need = k - gt;
             if (eq > need) {
                 uint32_t lo = 0;      // largest value with count(key == T && id < lo) < need
@@ -275,10 +253,6 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
                     int cnt = 0;
 #pragma unroll
                     for (int i = 0; i < R; ++i) cnt += wave_count(u[i] == T && id_of(i) < c);
-                    if (CARRY) {
-#pragma unroll
-                        for (int j = 0; j < E; ++j) cnt += wave_count(cu[j] == T && cid[j] < c);
-                    }
                     if (cnt < need) lo = c;
                 }
                 I = lo;
@@ -287,19 +261,6 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
     }
     // ---- compact survivors into LDS ------------------------------------------------------
     int base = 0;
-    if (CARRY) {
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const bool keep = cu[j] != 0 && ((cu[j] > T) || (cu[j] == T && cid[j] <= I));
-            const uint64_t mask = __ballot(keep);
-            if (keep) {
-                const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
-                sel_u[w] = cu[j];
-                sel_id[w] = cid[j];
-            }
-            base += __popcll(mask);
-        }
-    }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         // (I is wave-uniform; all-ones = no tie-break in force: ids need not be resolved)
@@ -309,7 +270,7 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
             const int w = base + __popcll(mask & ((1ull << lane) - 1ull));
             sel_u[w] = u[i];
             // MODE_IVF: the stream position, flagged; select_rounds turns the survivors' positions into ids
-            sel_id[w] = MODE == MODE_DENSE ? id_of(i) : (0x80000000u | (uint32_t)(pos + i * 64 + lane));
+            sel_id[w] = MODE == MODE_DENSE ? id_of(i) : (0x80000000u | (uint32_t)(i * 64 + lane));
         }
         base += __popcll(mask);
     }
@@ -418,7 +379,7 @@ __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery
                                              uint32_t* sel_u, uint32_t* sel_id, const int64_t* seg_off,
                                              const int64_t* seg_src) {
     int fresh = (int)min<int64_t>(qy.nc, 64 * R);
-    int carry = select_round<MODE, R, false>(a, qy, k, lane, 0, fresh, 0, sel_u, sel_id, seg_off, seg_src);
+    int carry = select_round<MODE, R>(a, qy, k, lane, fresh, sel_u, sel_id, seg_off, seg_src);
     __syncthreads();
     if (MODE != MODE_DENSE) {
         resolve_ids(a, qy, carry, lane, sel_id, seg_off, seg_src);

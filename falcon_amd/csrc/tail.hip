@@ -418,7 +418,9 @@ using namespace fal;
 int fal::refine_dev(fal_ctx* ctx, int32_t* labels, int64_t n, const float* mz, const float* rt, double tol, int is_da,
                     double rt_tol, const int64_t* d_count_in, int64_t** d_count_out) {
     hipStream_t st = ctx->stream;
-    const int64_t cmax = n / 2 + 1;           // a DBSCAN cluster has at least two members
+    // sized by n: a DBSCAN cluster of this library may hold ONE member (a core row whose only eps-neighbours are
+    // non-core borders that join a lower core), and the staged ABI accepts any cluster count <= n
+    const int64_t cmax = n + 1;
     int32_t *counts = nullptr, *rows = nullptr;
     int64_t *seg = nullptr, *base = nullptr;
     unsigned char* slab = nullptr;
@@ -461,7 +463,7 @@ int fal::finalize_dev(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, con
                       const int64_t* row_order, const int32_t* nb_idx, const float* nb_dist, int k,
                       int32_t* labels_out, int32_t* medoids_out, int64_t** d_noise_out) {
     hipStream_t st = ctx->stream;
-    const int64_t cmax = n / 2 + 1;
+    const int64_t cmax = n + 1;               // fal_finalize accepts any n_clusters <= n (single-member clusters included)
     int32_t *size = nullptr, *noise = nullptr;
     unsigned long long* best = nullptr;
     int64_t* rank = nullptr;

@@ -230,10 +230,11 @@ class Context:
               "fal_rescore_neighbors")
         return nb_dist
 
-    def neighbors_to_csr(self, nb_idx, nb_dist, id_offset: int = 0, out=None, row0: int = 0, nb_count=None):
+    def neighbors_to_csr(self, nb_idx, nb_dist, id_offset: int = 0, out=None, row0: int = 0, nb_count=None, id_map=None):
         """ELL neighbour lists -> CSR (indptr i64[rows+1], idx i32[cap], dist f32[cap]); entries beyond
         indptr[-1] are unspecified.  `out` = (indptr, idx, dist) buffers to fill; with `row0` > 0 the call
-        appends a further segment (rows row0.. of `out`, ids shifted by its own id_offset).  No sync."""
+        appends a further segment (rows row0.. of `out`, ids shifted by its own id_offset).  `id_map` (i64):
+        stored id -> id_map[id] + id_offset (a bucket shard's positions -> dataset rows).  No sync."""
         torch = _torch()
         n, k = nb_idx.shape
         if out is None:
@@ -242,9 +243,9 @@ class Context:
         indptr, idx, dist = out
         if indptr.numel() < row0 + n + 1:
             raise FalconHipError("neighbors_to_csr: indptr buffer too small")
-        check(self.lib.fal_neighbors_to_csr(self._h, self._p(nb_idx), self._p(nb_dist), self._p(nb_count), n, k, int(id_offset),
-                                            int(row0),
-                                            self._p(indptr), self._p(idx), self._p(dist)), "fal_neighbors_to_csr")
+        check(self.lib.fal_neighbors_to_csr_mapped(self._h, self._p(nb_idx), self._p(nb_dist), self._p(nb_count), n, k,
+                                                   self._p(id_map), int(id_offset), int(row0),
+                                                   self._p(indptr), self._p(idx), self._p(dist)), "fal_neighbors_to_csr")
         return indptr, idx, dist
 
     def dbscan(self, nb_idx, nb_dist, eps: float):

@@ -38,15 +38,21 @@ def world() -> Tuple[int, int]:
 
 def shard_units(costs: np.ndarray, world_size: int) -> np.ndarray:
     """Longest-processing-time assignment of independent units (buckets) to ranks
-    (SURVEY 8e): returns rank of every unit.  Deterministic."""
+    (SURVEY 8e): returns rank of every unit.  Deterministic (ties: lower rank, earlier unit)."""
+    import heapq
     costs = np.asarray(costs, np.float64)
+    if world_size <= 1 or len(costs) == 0:
+        return np.zeros(len(costs), np.int64)
     order = np.argsort(-costs, kind="stable")
-    load = np.zeros(world_size)
+    cl = costs[order].tolist()
+    heap = [(0.0, r) for r in range(world_size)]           # (load, rank): the least loaded rank, lowest rank on ties
+    seq = []
+    for cu in cl:
+        load, r = heap[0]
+        seq.append(r)
+        heapq.heapreplace(heap, (load + cu, r))
     owner = np.empty(len(costs), np.int64)
-    for u in order:
-        r = int(np.argmin(load))
-        owner[u] = r
-        load[r] += costs[u]
+    owner[order] = seq
     return owner
 
 
@@ -116,9 +122,11 @@ class SparseGraphExchange:
     def __init__(self, device):
         self.device = device
 
-    def start(self, indptr, idx, dist, labels, n_labels_local: int):
+    def start(self, indptr, idx, dist, labels, n_labels_local: int, rows=None):
         """indptr i64[n+1] / idx i32[>=nnz] / dist f32[>=nnz] from `Context.neighbors_to_csr` (ids already
-        global), labels i32[n] local labels in [0, n_labels_local)."""
+        global), labels i32[n] local labels in [0, n_labels_local).  `rows` (optional, i32/i64[n]): the global
+        row of every local row -- a rank that owns a bucket shard of ONE dataset sends them so that every
+        receiver can place its labels (`assemble_labels`)."""
         import torch
         d = _dist()
         rank, ws = world()
@@ -136,36 +144,52 @@ class SparseGraphExchange:
         sizes = sizes_t.cpu().numpy().reshape(ws, 3)                      # the one synchronisation
         n_max, nnz_max = int(sizes[:, 0].max()), max(int(sizes[:, 1].max()), 1)
         nnz = int(sizes[rank, 1])
-        # payload: one int32 block per rank  [counts n_max | labels n_max | idx nnz_max | dist bits nnz_max]
-        width = 2 * n_max + 2 * nnz_max
+        # payload: one int32 block per rank  [counts n_max | labels n_max | (rows n_max) | idx nnz_max | dist bits nnz_max]
+        nb = 3 if rows is not None else 2
+        width = nb * n_max + 2 * nnz_max
         send = torch.empty(width, dtype=torch.int32, device=indptr.device)
         send[:n] = (indptr[1:] - indptr[:-1]).to(torch.int32)
         send[n_max:n_max + n] = labels.to(torch.int32)
-        send[2 * n_max:2 * n_max + nnz] = idx[:nnz]
-        send[2 * n_max + nnz_max:2 * n_max + nnz_max + nnz] = dist[:nnz].view(torch.int32)
+        if rows is not None:
+            send[2 * n_max:2 * n_max + n] = rows.to(torch.int32)
+        send[nb * n_max:nb * n_max + nnz] = idx[:nnz]
+        send[nb * n_max + nnz_max:nb * n_max + nnz_max + nnz] = dist[:nnz].view(torch.int32)
         if ws > 1:
             recv = torch.empty(ws * width, dtype=torch.int32, device=indptr.device)
             work = d.all_gather_into_tensor(recv, send, async_op=True)   # ONE collective for the whole payload
         else:
             recv, work = send, None
-        return dict(work=work, recv=recv, send=send, sizes=sizes, n_max=n_max, nnz_max=nnz_max, width=width)
+        return dict(work=work, recv=recv, send=send, sizes=sizes, n_max=n_max, nnz_max=nnz_max, width=width, nb=nb)
 
     def finish(self, h):
         import torch
         rank, ws = world()
         if h["work"] is not None:
             h["work"].wait()
-        sizes, n_max, nnz_max, width = h["sizes"], h["n_max"], h["nnz_max"], h["width"]
+        sizes, n_max, nnz_max, width, nb = h["sizes"], h["n_max"], h["nnz_max"], h["width"], h["nb"]
         recv = h["recv"].view(ws, width)
         label_off = np.concatenate([[0], np.cumsum(sizes[:, 2])])
-        out = dict(counts=[], idx=[], dist=[], labels=[], sizes=sizes, n_labels=int(label_off[-1]))
+        out = dict(counts=[], idx=[], dist=[], labels=[], rows=[], sizes=sizes, n_labels=int(label_off[-1]))
         for r in range(ws):
             n_r, nnz_r = int(sizes[r, 0]), int(sizes[r, 1])
             blk = recv[r]
             out["counts"].append(blk[:n_r])
             out["labels"].append(blk[n_max:n_max + n_r] + int(label_off[r]))       # falcon.py:189-193 per rank
-            out["idx"].append(blk[2 * n_max:2 * n_max + nnz_r])
-            out["dist"].append(blk[2 * n_max + nnz_max:2 * n_max + nnz_max + nnz_r].view(torch.float32))
+            if nb == 3:
+                out["rows"].append(blk[2 * n_max:2 * n_max + n_r])
+            out["idx"].append(blk[nb * n_max:nb * n_max + nnz_r])
+            out["dist"].append(blk[nb * n_max + nnz_max:nb * n_max + nnz_max + nnz_r].view(torch.float32))
+        return out
+
+    @staticmethod
+    def assemble_labels(g, n_total: int):
+        """labels of the WHOLE dataset from the gathered shards (`rows` sent): labels[row] = that row's globally unique
+        label (rank-major offsets, the per-block offset of cluster.py:144-155).  Device tensor i32[n_total]."""
+        import torch
+        dev = g["labels"][0].device
+        out = torch.full((n_total,), -1, dtype=torch.int32, device=dev)
+        for rows, lab in zip(g["rows"], g["labels"]):
+            out[rows.long()] = lab
         return out
 
 
@@ -227,15 +251,10 @@ def run_sharded(pipe, ds, precursor_tol_mass: float, precursor_tol_mode: str, rt
     c = pipe.ctx
     n = len(ds)
     st = pipe._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p)
-    splits = np.asarray(st["splits"], np.int64)
-    owner = shard_units(bucket_costs(np.diff(splits), st["n_list"], p.n_probe), world_size)
-    rows, sub_splits, mine = shard_rows(splits, owner, rank)
-    n_sub = len(rows)
+    sub = pipe._restrict(c, st, p, (rank, world_size))
+    order_sub = sub["rows"]
+    n_sub = int(order_sub.numel())
     if n_sub:
-        rows_d = c.to_dev(rows, torch.int64)
-        order_sub = st["order"][rows_d]                       # dataset rows of my buckets, in sorted order
-        sub = dict(order=order_sub, mzs=st["mzs"][rows_d], rts=None if st["rts"] is None else st["rts"][rows_d],
-                   splits=sub_splits, n_list=np.asarray(st["n_list"])[mine])
         pipe._search(ds, sub, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, p, False)
         sub["order"] = torch.arange(n_sub, dtype=torch.int64, device=c.tdev)      # label the subset locally ...
         labels_sub, medoids_sub, _ = pipe._graph(sub, precursor_tol_mass, precursor_tol_mode, rt_tol, p, False)

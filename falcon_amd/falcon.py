@@ -17,6 +17,7 @@ import logging
 import os
 import re
 import shutil
+import random
 import sys
 import tempfile
 import threading
@@ -24,14 +25,15 @@ from typing import Dict, List, Union
 
 import numpy as np
 
-from . import __version__, seed
+from . import __version__
 from .cluster import cluster, spectrum
 from .config import config
 from .ms_io import ms_io
 
 logger = logging.getLogger("falcon")
 
-seed.set_seeds()                                                    # falcon.py:30
+random.seed(42)            # the reference seeds `random` and NumPy with 42 on import (falcon/seed.py, falcon.py:30);
+np.random.seed(42)         # the device path itself draws no random numbers
 
 
 def _natural_key(s: str):
@@ -69,7 +71,7 @@ def _option_lines() -> List[str]:
         # nearest-neighbour options (README.md:101-117)
         f"eps = {c.eps:.3f}", f"n_probe = {c.n_probe}", f"n_neighbors = {c.n_neighbors}",
         f"n_neighbors_ann = {c.n_neighbors_ann}", f"low_dim = {c.low_dim}", f"mz_interval = {c.mz_interval}",
-        f"rescore = {c.rescore}",
+        f"rescore = {c.rescore}", f"clustering = {c.clustering}",
     ]
 
 
@@ -120,10 +122,10 @@ def _run(args) -> int:
     ann = cluster.AnnParams(eps=config.eps, low_dim=config.low_dim, n_probe=config.n_probe,
                             n_neighbors=config.n_neighbors, n_neighbors_ann=config.n_neighbors_ann,
                             mz_interval=config.mz_interval, min_mz=config.min_mz, max_mz=config.max_mz,
-                            rescore=config.rescore)
+                            rescore=config.rescore, clustering=config.clustering)
     rows_all, current_label, representatives = [], 0, []
     for charge in charges:                                                                     # falcon.py:153
-        part = np.load(os.path.join(spectra_dir, f"spectra_charge_{charge}.npz"), allow_pickle=True)
+        part = np.load(os.path.join(spectra_dir, f"spectra_charge_{charge}.npz"))     # plain arrays: no pickle
         n = len(part["precursor_mz"])
         if n == 0:
             continue
@@ -135,8 +137,9 @@ def _run(args) -> int:
         labels = labels + current_label                                                        # falcon.py:189-193
         current_label = int(labels.max()) + 1
         for i in range(n):
+            # float32 columns keep their own (shortest round-trip) text form, as pandas' to_csv prints them
             rows_all.append((str(part["filename"][i]), str(part["identifier"][i]), charge,
-                             float(part["precursor_mz"][i]), float(part["retention_time"][i]), int(labels[i])))
+                             np.float32(part["precursor_mz"][i]), np.float32(part["retention_time"][i]), int(labels[i])))
         if config.export_representatives:                                                      # falcon.py:198-203
             ip = part["indptr"]
             for c, m in enumerate(medoids):
@@ -207,7 +210,7 @@ def _prepare_spectra(spectra_dir: str, min_mz: float, max_mz: float, ctx) -> Lis
             None if config.scaling == "off" else config.scaling)
         valid, oip, omz, oit = valid.cpu().numpy(), oip.cpu().numpy(), omz.cpu().numpy(), oit.cpu().numpy()
         low_quality += int((~valid).sum())
-        ident = np.array([s["identifier"] for s in specs], dtype=object)
+        ident = np.array([str(s["identifier"]) for s in specs], dtype=str)
         rt = np.array([s.get("retention_time", -1) for s in specs], np.float32)
         for z in np.unique(charge[valid]):
             rows = np.flatnonzero(valid & (charge == z))
@@ -216,7 +219,7 @@ def _prepare_spectra(spectra_dir: str, min_mz: float, max_mz: float, ctx) -> Lis
                                  dict(identifier=[], filename=[], precursor_mz=[], retention_time=[], mz=[], intensity=[],
                                       counts=[]))
             p["identifier"].append(ident[rows])
-            p["filename"].append(np.array([fn] * len(rows), dtype=object))
+            p["filename"].append(np.array([fn] * len(rows), dtype=str))
             p["precursor_mz"].append(pmz[rows].astype(np.float32))
             p["retention_time"].append(rt[rows])
             p["mz"].append(omz[pos])
@@ -239,16 +242,18 @@ def _prepare_spectra(spectra_dir: str, min_mz: float, max_mz: float, ctx) -> Lis
 
 
 def _write_cluster_info(rows) -> None:
-    """falcon.py:483-524: `#` header block with every option, then the CSV table."""
-    with open(f"{config.output_filename}.csv", "a") as f:
+    """falcon.py:483-524: `#` header block with every option, then the CSV table (pandas `to_csv` conventions:
+    minimal quoting with doubled quotes, float32 columns in their shortest round-trip form)."""
+    import csv
+    with open(f"{config.output_filename}.csv", "a", newline="") as f:
         f.write(f"# falcon version {__version__}\n")
         for line in _option_lines():
             f.write(f"# {line}\n")
         f.write("#\n")
-        f.write("filename,spectrum_id,precursor_charge,precursor_mz,retention_time,cluster\n")
+        w = csv.writer(f, quoting=csv.QUOTE_MINIMAL, lineterminator="\n")
+        w.writerow(["filename", "spectrum_id", "precursor_charge", "precursor_mz", "retention_time", "cluster"])
         for fn, sid, charge, pmz, rt, lab in rows:
-            sid_q = f'"{sid}"' if ("," in sid or '"' in sid) else sid
-            f.write(f"{fn},{sid_q},{charge},{pmz},{rt},{lab}\n")
+            w.writerow([fn, sid, charge, str(np.float32(pmz)), str(np.float32(rt)), lab])
 
 
 if __name__ == "__main__":

@@ -38,6 +38,8 @@ def get_spectra(source) -> Iterator[Dict]:
             elif line == "END IONS":
                 if inside:
                     try:
+                        if "__bad__" in params:          # a peak line that did not parse: the spectrum is skipped
+                            raise ValueError("malformed peak line")
                         yield {
                             "identifier": params["title"],
                             "precursor_mz": float(params["pepmass"].split()[0]),

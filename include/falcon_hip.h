@@ -181,6 +181,13 @@ int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_di
                          const int32_t* nb_count /*[n] lengths of front-packed rows, or NULL*/,
                          int64_t n, int k, int64_t id_offset, int64_t row0, int64_t* indptr_out,
                          int32_t* idx_out, float* dist_out);
+/*          Same with an id map: stored id -> id_map[id] + id_offset.  A rank that ran the path on a
+ *          SUBSET of a dataset's buckets (its share of one precursor-sorted dataset) maps
+ *          the subset positions back to dataset rows here (id_map = the subset's row order). -- [dev] */
+int fal_neighbors_to_csr_mapped(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
+                                const int32_t* nb_count, int64_t n, int k,
+                                const int64_t* id_map /*[ids] or NULL*/, int64_t id_offset, int64_t row0,
+                                int64_t* indptr_out, int32_t* idx_out, float* dist_out);
 
 /* ---- a9  DBSCAN(eps, min_samples = 2 as reference cluster.py:66) on the sparse
  *          neighbour graph; spec README.md:143-146.  Order-independent form:

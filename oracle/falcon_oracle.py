@@ -225,14 +225,74 @@ def n_list_for(n_b: int) -> int:
     return int(min(MAX_N_LIST, 2 ** int(math.floor(math.log2(n_b / MIN_PTS_PER_LIST)))))
 
 
+# ---- the kernels' summation order (oracle/kordered.c; built by __graft_entry__.build()) ----------
+_KLIB = None
+
+
+def _klib():
+    """ctypes handle of oracle/_build/libkordered.so, or None when it has not been built."""
+    global _KLIB
+    if _KLIB is None:
+        import ctypes as C
+        import os
+        fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libkordered.so")
+        if not os.path.isfile(fn):
+            _KLIB = False
+        else:
+            lib = C.CDLL(fn)
+            vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+            lib.fo_sims_kordered.argtypes = [vp, i64, vp, i64, i32, vp]
+            lib.fo_argmax_kordered.argtypes = [vp, i64, vp, i64, i32, vp]
+            lib.fo_ivf_search.argtypes = [vp, i64, i32, vp, i32, vp, vp, i32, i64, vp, vp]
+            lib.fo_topk_rows.argtypes = [vp, i64, i64, i32, vp, vp]
+            _KLIB = lib
+    return _KLIB or None
+
+
+def have_kordered() -> bool:
+    """True when the C helper is built: `sims_f32` is then BIT-IDENTICAL to the HIP kernels."""
+    return _klib() is not None
+
+
+def _ptr(a):
+    return a.ctypes.data
+
+
 def sims_f32(A: np.ndarray, B: np.ndarray) -> np.ndarray:
-    """Inner products in float32 (BLAS order; the HIP kernels use a k-ordered fmaf
-    chain -- results agree to ~1e-7, tests use the 1e-5 tolerance of north_star)."""
-    return (A.astype(f32) @ B.astype(f32).T).astype(f32)
+    """Inner products in float32, summed as the HIP kernels sum them (simtile.h): with dh = d/2,
+    acc = fma(a[dh+k], b[dh+k], fma(a[k], b[k], acc)) for k = 0..dh-1, one rounding per fma.
+    With oracle/_build/libkordered.so (gcc fmaf) the result equals the kernels bit for bit; without it
+    the fma is emulated in float64 (exact product, one extra rounding of the sum: differs from a true
+    fma only when the float64 sum lands exactly on a float32 rounding boundary)."""
+    A = np.ascontiguousarray(A, f32)
+    B = np.ascontiguousarray(B, f32)
+    na, d = A.shape
+    nb = B.shape[0]
+    out = np.empty((na, nb), f32)
+    lib = _klib()
+    if lib is not None and d % 2 == 0:
+        rc = lib.fo_sims_kordered(_ptr(A), na, _ptr(B), nb, d, _ptr(out))
+        assert rc == 0, rc
+        return out
+    dh = d // 2
+    acc = np.zeros((na, nb), f32)
+    A64, B64 = A.astype(f64), B.astype(f64)
+    for k in range(dh):
+        acc = (A64[:, k, None] * B64[None, :, k] + acc.astype(f64)).astype(f32)
+        acc = (A64[:, dh + k, None] * B64[None, :, dh + k] + acc.astype(f64)).astype(f32)
+    return acc
 
 
 def kmeans_assign(X: np.ndarray, C: np.ndarray) -> np.ndarray:
     """argmax inner product, ties -> lowest centroid id."""
+    lib = _klib()
+    X = np.ascontiguousarray(X, f32)
+    C = np.ascontiguousarray(C, f32)
+    if lib is not None and X.shape[1] % 2 == 0:
+        out = np.empty(len(X), np.int32)
+        rc = lib.fo_argmax_kordered(_ptr(X), len(X), _ptr(C), len(C), X.shape[1], _ptr(out))
+        assert rc == 0, rc
+        return out
     return np.argmax(sims_f32(X, C), axis=1).astype(np.int32)
 
 
@@ -278,15 +338,27 @@ def topk_desc(sim_row: np.ndarray, ids: np.ndarray, k: int):
     return sim_row[order], ids[order]
 
 
+def _topk_rows(S: np.ndarray, k: int):
+    """row-wise k best of a dense [n, m] matrix by (sim desc, column asc) -> sim [n,k] (pad -inf), idx [n,k] (pad -1)"""
+    S = np.ascontiguousarray(S, f32)
+    n, m = S.shape
+    sim = np.full((n, k), -np.inf, f32)
+    idx = np.full((n, k), -1, np.int32)
+    lib = _klib()
+    if lib is not None:
+        lib.fo_topk_rows(_ptr(S), n, m, k, _ptr(sim), _ptr(idx))
+        return sim, idx
+    ids = np.arange(m)
+    for i in range(n):
+        ss, ii = topk_desc(S[i], ids, k)
+        sim[i, :len(ss)] = ss
+        idx[i, :len(ii)] = ii
+    return sim, idx
+
+
 def coarse_probe(X: np.ndarray, C: np.ndarray, n_probe: int) -> np.ndarray:
     """top-n_probe centroids per query by (sim desc, list id asc)."""
-    S = sims_f32(X, C)
-    n_list = C.shape[0]
-    ids = np.arange(n_list)
-    out = np.empty((len(X), n_probe), np.int32)
-    for i in range(len(X)):
-        out[i] = topk_desc(S[i], ids, n_probe)[1]
-    return out
+    return _topk_rows(sims_f32(X, C), n_probe)[1]
 
 
 def ivf_search(X: np.ndarray, C: np.ndarray, assign: np.ndarray, perm: np.ndarray, off: np.ndarray,
@@ -301,10 +373,19 @@ def ivf_search(X: np.ndarray, C: np.ndarray, assign: np.ndarray, perm: np.ndarra
         probes = np.zeros((n, 1), np.int32)
     elif probes is None:
         probes = coarse_probe(X, C, min(n_probe, n_list))
-    Xf = X.astype(f32)
+    Xf = np.ascontiguousarray(X, f32)
+    lib = _klib()
+    if lib is not None and Xf.shape[1] % 2 == 0 and n > 0:
+        pr = np.ascontiguousarray(probes, np.int32)
+        pm = np.ascontiguousarray(perm, np.int64)
+        of = np.ascontiguousarray(off, np.int64)
+        rc = lib.fo_ivf_search(_ptr(Xf), n, Xf.shape[1], _ptr(pr), pr.shape[1], _ptr(pm), _ptr(of), k_ann, base,
+                               _ptr(sim), _ptr(idx))
+        assert rc == 0, rc
+        return sim, idx
     for i in range(n):
-        cand = np.concatenate([perm[off[l]:off[l + 1]] for l in probes[i]])
-        s = (Xf[cand] @ Xf[i]).astype(f32)
+        cand = np.concatenate([perm[off[l]:off[l + 1]] for l in probes[i] if l >= 0])
+        s = sims_f32(Xf[cand], Xf[i:i + 1])[:, 0]
         ss, ii = topk_desc(s, cand, k_ann)
         sim[i, :len(ss)] = ss
         idx[i, :len(ii)] = ii + base
@@ -312,17 +393,10 @@ def ivf_search(X: np.ndarray, C: np.ndarray, assign: np.ndarray, perm: np.ndarra
 
 
 def exhaustive_topk(X: np.ndarray, k: int, base: int = 0):
-    """Ground truth: brute-force cosine top-k inside one bucket."""
-    Xf = X.astype(f32)
-    S = (Xf @ Xf.T).astype(f32)
-    n = len(X)
-    sim = np.full((n, k), -np.inf, f32)
-    idx = np.full((n, k), -1, np.int32)
-    ids = np.arange(n)
-    for i in range(n):
-        ss, ii = topk_desc(S[i], ids, k)
-        sim[i, :len(ss)] = ss
-        idx[i, :len(ii)] = ii + base
+    """Ground truth: brute-force cosine top-k inside one bucket, in the kernels' summation order."""
+    Xf = np.ascontiguousarray(X, f32)
+    sim, idx = _topk_rows(sims_f32(Xf, Xf), k)
+    idx[idx >= 0] += base
     return sim, idx
 
 

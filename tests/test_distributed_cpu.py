@@ -154,3 +154,97 @@ def test_shard_rows_and_merge_shards():
         off += len(med)
     with pytest.raises(ValueError):
         fd.merge_shards(48, shards)
+
+
+# ---------------------------------------------------------------------------------------------
+# run_sharded (one dataset, buckets dealt to ranks by LPT, ONE all-gatherv) at world size 2 over gloo.
+# The HIP pipeline cannot run here, so the three phases are backed by the oracle (tests may use it);
+# the bucket assignment (`ClusterPipeline._restrict`), `run_sharded` and `_gather_shards` are the product's.
+# ---------------------------------------------------------------------------------------------
+class _OraclePipe:
+    def __init__(self, data):
+        import torch
+        from falcon_amd.cluster.cluster import ClusterPipeline
+        self.data = data
+
+        class Ctx:
+            tdev = torch.device("cpu")
+
+            @staticmethod
+            def to_dev(a, dtype=None):
+                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+                return t.to(dtype) if dtype is not None else t
+        self.ctx = Ctx()
+        self._restrict = lambda c, st, p, shard: ClusterPipeline._restrict(self, c, st, p, shard)
+
+    def _front(self, c, ds, tol, mode, rt_tol, batch_size, p):
+        import torch
+        from falcon_amd.cluster.cluster import n_list_rule
+        from oracle import falcon_oracle as fo
+        pmz = np.asarray(ds.precursor_mz, np.float32)
+        order = np.argsort(pmz, kind="stable")
+        splits = fo.bucket_splits(pmz[order], tol, mode, batch_size, p.mz_interval)
+        return dict(order=torch.from_numpy(order), mzs=torch.from_numpy(pmz[order]), rts=None, splits=splits,
+                    n_list=n_list_rule(np.diff(splits), p.n_probe))
+
+    def _search(self, ds, st, *a):
+        pass
+
+    def _graph(self, st, tol, mode, rt_tol, p, keep):
+        import torch
+        from oracle import falcon_oracle as fo
+        rows = st["rows"].numpy()                                  # dataset rows of my buckets, sorted order
+        d = self.data
+        cnt = np.diff(d["indptr"])[rows]
+        ip = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum(cnt, out=ip[1:])
+        src = np.repeat(d["indptr"][:-1][rows] - ip[:-1], cnt) + np.arange(ip[-1])
+        lab, med = fo.generate_clusters(d["mz"][src], d["intensity"][src], ip, d["precursor_mz"][rows], None,
+                                        precursor_tol=(tol, mode), eps=p.eps, n_probe=p.n_probe, mz_interval=p.mz_interval)
+        return torch.from_numpy(lab), torch.from_numpy(med), {}
+
+
+def _sharded_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from falcon_amd import distributed as fd, synth
+    from falcon_amd.cluster.cluster import AnnParams, SpectrumDataset
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = synth.select_charge(synth.generate(3000, seed=3, mz_lo=500.0, mz_hi=530.0), 2)
+        ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+        labels, medoids = fd.run_sharded(_OraclePipe(d), ds, 20.0, "ppm", None, 0.05, 2 ** 15, AnnParams())
+        q.put((rank, labels, medoids))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_sharded_world2_gloo_equals_one_rank():
+    """`run_sharded` through `_gather_shards` with world > 1 gives every rank the partition one rank
+    computes alone (labels up to the rank-major renumbering, the same medoid rows)."""
+    import torch.multiprocessing as mp
+    from oracle import falcon_oracle as fo
+    from falcon_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    d = synth.select_charge(synth.generate(3000, seed=3, mz_lo=500.0, mz_hi=530.0), 2)
+    ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], None)
+    (_, l0, m0), (_, l1, m1) = res
+    assert np.array_equal(l0, l1) and np.array_equal(m0, m1)                 # every rank holds the same result
+    assert l0.min() == 0 and np.array_equal(np.unique(l0), np.arange(len(m0)))
+    # same partition: the label pairs are in bijection
+    pairs = np.unique(np.stack([ref, l0]), axis=1)
+    assert pairs.shape[1] == len(rmed) == len(m0)
+    assert np.array_equal(np.sort(m0), np.sort(rmed))
+    assert np.array_equal(l0[m0], np.arange(len(m0)))
+    assert len(np.unique(ref)) > 50 and (np.bincount(ref) > 1).sum() > 20    # a non-trivial clustering

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import falcon_oracle as fo
-from tests.util import assert_topk_close
+from tests.util import assert_topk_close, assert_topk_exact
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +39,7 @@ def test_flat_exhaustive_topk(ctx, d, k):
     sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
     for a, b in zip(off[:-1], off[1:]):
         rs, ri = fo.exhaustive_topk(X[a:b], k, base=a)
-        assert_topk_close(sim[a:b], idx[a:b], rs, ri, X[a:b], base=a, what=f"bucket {a}:{b}")
+        assert_topk_exact(sim[a:b], idx[a:b], rs, ri, what=f"bucket {a}:{b}")
         # exact ties are broken by ascending id, bit for bit
     a = off[4]
     assert np.array_equal(idx[a, :5], np.arange(a, a + 5))
@@ -56,7 +56,7 @@ def test_flat_many_small_batches(ctx, monkeypatch):
     sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
     for a, b in zip(off[:-1], off[1:]):
         rs, ri = fo.exhaustive_topk(X[a:b], 32, base=a)
-        assert_topk_close(sim[a:b], idx[a:b], rs, ri, X[a:b], base=a)
+        assert_topk_exact(sim[a:b], idx[a:b], rs, ri)
 
 
 @pytest.mark.parametrize("sizes,nlists,d", [
@@ -78,14 +78,13 @@ def test_ivf_build_matches_oracle(ctx, sizes, nlists, d):
     assert np.array_equal(np.sort(perm), np.arange(off[-1]))
     for b, (a, e) in enumerate(zip(off[:-1], off[1:])):
         C, ra, rperm, roff = fo.ivf_build(X[a:e], nlists[b], 4)
-        assert np.array_equal(loff[lb[b]:lb[b + 1] + 1] - a, roff) or (asg[a:e] != ra).any()
-        agree = (asg[a:e] == ra).mean()
-        assert agree >= 0.999, (b, agree)
-        if agree == 1.0:
-            assert np.array_equal(perm[a:e] - a, rperm)
-            if nlists[b] > 1:
-                # ordered float32 sums + fixed-order norm: centroids are bit-identical
-                assert np.array_equal(cent[lb[b]:lb[b + 1]], C)
+        # the oracle sums in the kernels' k order (oracle/kordered.c): every assignment, list and centroid is identical
+        assert np.array_equal(asg[a:e], ra), (b, (asg[a:e] != ra).sum())
+        assert np.array_equal(loff[lb[b]:lb[b + 1] + 1] - a, roff)
+        assert np.array_equal(perm[a:e] - a, rperm)
+        if nlists[b] > 1:
+            # ordered float32 sums + fixed-order norm: centroids are bit-identical
+            assert np.array_equal(cent[lb[b]:lb[b + 1]], C)
 
 
 @pytest.mark.parametrize("n_probe,k", [(4, 32), (16, 128), (64, 64)])
@@ -99,17 +98,10 @@ def test_ivf_search_matches_oracle_on_same_index(ctx, n_probe, k):
     sim, idx = idxr.search(n_probe, k)
     sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
     lb = np.concatenate([[0], np.cumsum(nlists)])
-    bad_rows = 0
     for b, (a, e) in enumerate(zip(off[:-1], off[1:])):
         lo = loff[lb[b]:lb[b + 1] + 1] - a
         rs, ri = fo.ivf_search(X[a:e], cent[lb[b]:lb[b + 1]], asg[a:e], perm[a:e] - a, lo, n_probe, k, base=a)
-        try:
-            assert_topk_close(sim[a:e], idx[a:e], rs, ri, X[a:e], base=a, what=f"bucket {b}")
-        except AssertionError:
-            # a coarse-quantiser near-tie may swap one probed list for a query: count such rows
-            rows = [i for i in range(e - a) if not np.array_equal(idx[a + i], ri[i])]
-            bad_rows += len(rows)
-    assert bad_rows <= 0.002 * off[-1], bad_rows
+        assert_topk_exact(sim[a:e], idx[a:e], rs, ri, what=f"bucket {b}")
 
 
 def test_ivf_exhaustive_probe_equals_bruteforce(ctx):
@@ -123,7 +115,7 @@ def test_ivf_exhaustive_probe_equals_bruteforce(ctx):
     sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
     for a, b in zip(off[:-1], off[1:]):
         rs, ri = fo.exhaustive_topk(X[a:b], 64, base=a)
-        assert_topk_close(sim[a:b], idx[a:b], rs, ri, X[a:b], base=a)
+        assert_topk_exact(sim[a:b], idx[a:b], rs, ri)
 
 
 def _f16_planes(X):

@@ -167,3 +167,62 @@ def test_oracle_ivf_exhaustive_equals_bruteforce_and_dbscan_variants_agree():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert adjusted_rand_score(l_skl, l_comp) >= 0.99      # north_star gate, order-independent DBSCAN
+
+
+def test_config_ini_values_do_not_leak_into_the_next_parse(tmp_path):
+    """INI values were installed as parser defaults and survived into later parse() calls."""
+    from falcon_amd.config import Config
+    c = Config()
+    ini = tmp_path / "a.ini"
+    ini.write_text("eps = 0.3\nn_probe = 4\nscaling = root\n")
+    c.parse(f"-c {ini} in.mgf out")
+    assert (c.eps, c.n_probe, c.scaling) == (0.3, 4, "root")
+    c.parse("in.mgf out")
+    assert (c.eps, c.n_probe, c.scaling) == (0.1, 16, "off")
+    c.parse("in.mgf out --clustering hierarchical --linkage average")
+    assert c.rescore and c.linkage == "average"
+    with pytest.raises(SystemExit):
+        c.parse("in.mgf out --linkage ward")
+
+
+def test_generate_clusters_argument_errors():
+    """linkage / threshold arguments are validated before any device work (no silent ignoring)."""
+    from falcon_amd.cluster.cluster import AnnParams, SpectrumDataset, generate_clusters
+    ds = SpectrumDataset(np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32),
+                         np.zeros(3, np.float32), np.arange(4, dtype=np.int64))
+    with pytest.raises(ValueError, match="only applies to the hierarchical"):
+        generate_clusters(ds, "average", 0.1, 0, 20.0, "ppm", None, 0.05, 2 ** 15)
+    with pytest.raises(ValueError, match="unknown linkage"):
+        generate_clusters(ds, "ward", 0.1, 0, 20.0, "ppm", None, 0.05, 2 ** 15)
+    ann = AnnParams(eps=0.2)
+    with pytest.raises(ValueError, match="differ"):
+        generate_clusters(ds, "complete", 0.1, 0, 20.0, "ppm", None, 0.05, 2 ** 15, ann=ann)
+    assert ann.min_matches == 0 and ann.eps == 0.2            # the caller's parameters are never touched
+
+
+def test_mgf_corrupt_peak_line_skips_the_spectrum():
+    """a peak line that does not parse drops the whole spectrum (pyteomics raises and the reference's
+    try/except in get_spectra yields nothing, mgf_io.py:27-30)."""
+    import io
+    from falcon_amd.ms_io import mgf_io
+    txt = ("BEGIN IONS\nTITLE=a\nPEPMASS=500.1\nCHARGE=2+\n100.0 1.0\n2x0.0 5\n300 2\nEND IONS\n"
+           "BEGIN IONS\nTITLE=b\nPEPMASS=600.1\n100.0 1.0\n200.0 5\nEND IONS\n")
+    got = list(mgf_io.get_spectra(io.StringIO(txt)))
+    assert [g["identifier"] for g in got] == ["b"]
+
+
+def test_csv_writer_quotes_like_pandas(tmp_path):
+    """minimal quoting with doubled quotes for every text column, float32 values in their own repr."""
+    import csv
+    from falcon_amd import falcon as fmain
+    from falcon_amd.config import config
+    config.parse(f"in.mgf {tmp_path / 'out'}")
+    rows = [("/d/a,b.mgf", 'id "x", 1', "2", np.float32(500.23), np.float32(12.5), 3),
+            ("/d/c.mgf", "plain", "None", np.float32(1199.9999), np.float32(-1), 4)]
+    fmain._write_cluster_info(rows)
+    lines = [l for l in open(f"{tmp_path / 'out'}.csv") if not l.startswith("#")]
+    back = list(csv.reader(lines))
+    assert back[0] == ["filename", "spectrum_id", "precursor_charge", "precursor_mz", "retention_time", "cluster"]
+    assert back[1] == ["/d/a,b.mgf", 'id "x", 1', "2", "500.23", "12.5", "3"]
+    assert back[2] == ["/d/c.mgf", "plain", "None", "1199.9999", "-1.0", "4"]
+    assert '"id ""x"", 1"' in lines[1]

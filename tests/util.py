@@ -29,3 +29,12 @@ def assert_topk_close(sim, idx, ref_sim, ref_idx, X=None, base=0, tol=1e-5, what
                 js = np.isin(idx[i], extra)
                 assert np.all(np.abs(sim[i][js] - kth) <= tol), f"{what}: row {i} differs beyond ties"
     return int(diff.sum())
+
+
+def assert_topk_exact(sim, idx, ref_sim, ref_idx, what=""):
+    """Bit-exact form: the oracle sums in the kernels' own k order (oracle/kordered.c), so similarities,
+    ids, tie order and padding must all be identical."""
+    from oracle import falcon_oracle as fo
+    assert fo.have_kordered(), "oracle/_build/libkordered.so is missing: run __graft_entry__.build()"
+    assert np.array_equal(idx, ref_idx), f"{what}: ids differ in {(idx != ref_idx).any(1).sum()} rows"
+    assert np.array_equal(sim, ref_sim), f"{what}: sims differ, max {np.nanmax(np.abs(np.where(np.isfinite(ref_sim), sim - ref_sim, 0)))}"

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export PYTHONPATH=$R
-rocprofv3 --kernel-trace --stats -d /tmp/p10 -o r -- python3 $R/tools/scale_test.py ${1:-10000000} > /tmp/o.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/p10 -o r -- python3 $R/tools/scale_run.py ${1:-10000000} > /tmp/o.txt 2>&1
 tail -2 /tmp/o.txt
 python3 $R/profiles/summarize.py stats /tmp/p10/r_results.db /tmp/k.csv
 python3 - <<PY
