@@ -107,3 +107,101 @@ def select_charge(data: dict, charge: int) -> dict:
     out = {k: data[k][sel] for k in ("precursor_mz", "retention_time", "precursor_charge", "truth")}
     out.update(mz=data["mz"][src], intensity=data["intensity"][src], indptr=indptr, rows=sel)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# The same recipe on the GPU (torch, plumbing only): bench.py generates its workloads here because the
+# numpy generator needs ~20 s of host time per million spectra.  Same distributions, parameters and
+# layout as `_block` / `generate` / `select_charge`; a different random stream (torch's Philox), so the
+# spectra are statistically -- not bitwise -- the numpy ones.  Parity tests keep the numpy generator
+# (the oracle runs on its output); tests/test_gpu_synth.py compares the statistics of the two.
+# ---------------------------------------------------------------------------------------------
+def _block_device(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, dev):
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed) * 1_000_003 + int(block))
+    f32 = torch.float32
+
+    def uni(lo, hi, shape):
+        return torch.rand(shape, generator=g, device=dev, dtype=torch.float64) * (hi - lo) + lo
+
+    def randn(shape, dtype=f32):
+        return torch.randn(shape, generator=g, device=dev, dtype=dtype)
+
+    n_single = int(round(0.2 * n))
+    m = max(16, int((n - n_single) / 7.5) + 64)
+    sizes = 1 + torch.poisson(torch.full((m,), 7.0, device=dev), generator=g).long()
+    cs = torch.cumsum(sizes, 0)
+    n_cl = int(torch.searchsorted(cs, torch.tensor([n - n_single], device=dev)).item()) + 1
+    sizes = sizes[:n_cl].clone()
+    sizes[-1] -= cs[n_cl - 1] - (n - n_single)
+    if int(sizes[-1].item()) <= 0:
+        sizes = sizes[:-1]
+    sizes = torch.cat([sizes, torch.ones(n - int(sizes.sum().item()), dtype=torch.long, device=dev)])
+    n_t = sizes.numel()
+    tmpl = torch.repeat_interleave(torch.arange(n_t, device=dev), sizes)
+    t_pmz = uni(mz_lo, mz_hi, (n_t,)).to(f32)
+    t_charge = torch.where(torch.rand(n_t, generator=g, device=dev) < 0.7, 2, 3).to(torch.int8)
+    t_mz = torch.sort(uni(101.0, 1500.0, (n_t, N_TEMPLATE_PEAKS)), dim=1).values.to(f32)
+    t_int = torch.exp(randn((n_t, N_TEMPLATE_PEAKS)))                                  # LogNormal(0, 1)
+    P, T = N_TEMPLATE_PEAKS + N_NOISE_PEAKS, N_TEMPLATE_PEAKS
+    mz = torch.empty((n, P), dtype=f32, device=dev)
+    it = torch.empty((n, P), dtype=f32, device=dev)
+    mz[:, :T] = t_mz[tmpl] + randn((n, T)) * 0.005
+    it[:, :T] = t_int[tmpl] * torch.exp(randn((n, T)) * 0.2)
+    keep = torch.rand((n, P), generator=g, device=dev) >= 0.10                         # 10 % peak dropout
+    keep[:, T:] = True
+    base = torch.where(keep[:, :T], it[:, :T], torch.zeros((), device=dev)).amax(1, keepdim=True).clamp_min(1e-6)
+    mz[:, T:] = uni(101.0, 1500.0, (n, N_NOISE_PEAKS)).to(f32)
+    it[:, T:] = (uni(0.0, 0.05, (n, N_NOISE_PEAKS)) * base.double()).to(f32)
+    keep &= (mz >= 101.0) & (mz <= 1500.0)
+    it_k = torch.where(keep, it, torch.full((), -1.0, device=dev))
+    kth = torch.kthvalue(it_k, P - MAX_PEAKS + 1, dim=1, keepdim=True).values         # keep the MAX_PEAKS most intense
+    keep &= it_k >= kth
+    key = torch.where(keep, mz, torch.full((), float("inf"), device=dev))
+    o = torch.argsort(key, dim=1, stable=True)
+    mz, it, keep = torch.gather(mz, 1, o), torch.gather(it, 1, o), torch.gather(keep, 1, o)
+    it = torch.where(keep, it, torch.zeros((), device=dev))
+    nrm = torch.sqrt((it.double() ** 2).sum(1, keepdim=True)).clamp_min(1e-30)
+    it = (it.double() / nrm).to(f32)
+    counts = keep.sum(1)
+    pmz = (t_pmz[tmpl].double() * (1.0 + randn((n,), torch.float64) * 3e-6)).to(f32)
+    rt = uni(0.0, 7200.0, (n,)).to(f32)
+    charge = t_charge[tmpl]
+    perm = torch.randperm(n, generator=g, device=dev)
+    keep, mz, it, counts = keep[perm], mz[perm], it[perm], counts[perm]
+    return dict(mz=mz[keep], intensity=it[keep], counts=counts.long(), precursor_mz=pmz[perm], retention_time=rt[perm],
+                precursor_charge=charge[perm], truth=tmpl[perm].long())
+
+
+def generate_device(n: int, device, seed: int = 42, first_block: int = 0, mz_lo: float = 400.0, mz_hi: float = 1200.0):
+    """`generate` on a torch device -> the same dict with device tensors (indptr i64[n+1])."""
+    import torch
+    parts, done, b, t_off = [], 0, first_block, 0
+    while done < n:
+        m = min(BLOCK, n - done)
+        p = _block_device(m, b, seed, mz_lo, mz_hi, device)
+        p["truth"] = p["truth"] + t_off
+        t_off = int(p["truth"].max().item()) + 1
+        parts.append(p)
+        done += m
+        b += 1
+    cat = lambda k: torch.cat([p[k] for p in parts])
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    torch.cumsum(cat("counts"), 0, out=indptr[1:])
+    return dict(mz=cat("mz"), intensity=cat("intensity"), indptr=indptr, precursor_mz=cat("precursor_mz"),
+                retention_time=cat("retention_time"), precursor_charge=cat("precursor_charge"), truth=cat("truth"))
+
+
+def select_charge_device(data: dict, charge: int) -> dict:
+    """`select_charge` for the device form."""
+    import torch
+    sel = torch.nonzero(data["precursor_charge"] == charge).flatten()
+    ip = data["indptr"]
+    counts = (ip[1:] - ip[:-1])[sel]
+    indptr = torch.zeros(sel.numel() + 1, dtype=torch.int64, device=ip.device)
+    torch.cumsum(counts, 0, out=indptr[1:])
+    src = torch.repeat_interleave(ip[:-1][sel] - indptr[:-1], counts) + torch.arange(int(indptr[-1].item()), device=ip.device)
+    out = {k: data[k][sel] for k in ("precursor_mz", "retention_time", "precursor_charge", "truth")}
+    out.update(mz=data["mz"][src], intensity=data["intensity"][src], indptr=indptr, rows=sel)
+    return out

@@ -245,6 +245,7 @@ def _klib():
             lib.fo_argmax_kordered.argtypes = [vp, i64, vp, i64, i32, vp]
             lib.fo_ivf_search.argtypes = [vp, i64, i32, vp, i32, vp, vp, i32, i64, vp, vp]
             lib.fo_topk_rows.argtypes = [vp, i64, i64, i32, vp, vp]
+            lib.fo_set_threads.argtypes = [i32]
             _KLIB = lib
     return _KLIB or None
 
@@ -705,7 +706,7 @@ def generate_clusters(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
                       rt_tol=None, batch_size=2 ** 15, low_dim=400, n_probe=16, n_neighbors=64,
                       n_neighbors_ann=128, min_mz=101.0, max_mz=1500.0, fragment_tol=0.05,
                       mz_interval=1.0, kmeans_iters=10, hash_seed=0, dbscan="components",
-                      dtype=np.float32, return_intermediates=False):
+                      dtype=np.float32, return_intermediates=False, n_jobs=1):
     """Whole hot path for ONE charge partition -> (labels int32[N] by dataset row,
     no -1 left; medoids int32[n_labels]: medoids[c] = dataset row representing
     cluster c).  Mirrors cluster.generate_clusters (cluster.py:24-156) with the
@@ -722,12 +723,27 @@ def generate_clusters(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
     splits = bucket_splits(mzs, tol, mode, batch_size, mz_interval)
     sim = np.full((N, n_neighbors_ann), -np.inf, f32)
     idx = np.full((N, n_neighbors_ann), -1, np.int32)
-    for a, b in zip(splits[:-1], splits[1:]):
-        a, b = int(a), int(b)
+    def one_bucket(ab):
+        a, b = int(ab[0]), int(ab[1])
         Xb = X[a:b].astype(f32)
         nl = n_list_for(b - a)
         C, asg, perm, off = ivf_build(Xb, nl, kmeans_iters)
         sim[a:b], idx[a:b] = ivf_search(Xb, C, asg, perm, off, n_probe, n_neighbors_ann, base=a)
+
+    buckets = list(zip(splits[:-1], splits[1:]))
+    if n_jobs > 1 and _klib() is not None:
+        # buckets on a thread pool, like the reference's joblib threading backend over its blocks (cluster.py:115-136);
+        # the C helper then runs one thread per call (ctypes releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        _klib().fo_set_threads(1)
+        try:
+            with ThreadPoolExecutor(max_workers=n_jobs) as pool:
+                list(pool.map(one_bucket, buckets))
+        finally:
+            _klib().fo_set_threads(0)
+    else:
+        for ab in buckets:
+            one_bucket(ab)
     nb_idx, nb_dist = filter_neighbors(sim, idx, mzs, rts, tol, mode, rt_tol, n_neighbors)
     if dbscan == "sklearn":
         db = dbscan_sklearn_order(nb_idx, nb_dist, eps)

@@ -23,7 +23,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <omp.h>
+
 #define JT 64 /* outputs per register tile: independent chains hide the fma latency */
+
+/* threads per call: 0 = all (OpenMP default); the all-cores CPU baseline of bench.py runs one bucket per pool
+ * thread and sets this to 1 */
+static int g_threads = 0;
+void fo_set_threads(int n) { g_threads = n; }
+static int nthreads(void) { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
 
 /* out[i * nb + j] = <A[i], B[j]> in the kernel's k order.  A: [na, d], B: [nb, d], row-major. */
 int fo_sims_kordered(const float* A, int64_t na, const float* B, int64_t nb, int d, float* out) {
@@ -34,7 +42,7 @@ int fo_sims_kordered(const float* A, int64_t na, const float* B, int64_t nb, int
     if (!Bt) return -2;
     for (int64_t j = 0; j < nb; ++j)
         for (int k = 0; k < d; ++k) Bt[(size_t)k * nbp + j] = B[(size_t)j * d + k];
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads())
     for (int64_t i = 0; i < na; ++i) {
         const float* a = A + (size_t)i * d;
         for (int64_t j0 = 0; j0 < nbp; j0 += JT) {
@@ -64,7 +72,7 @@ int fo_argmax_kordered(const float* A, int64_t na, const float* B, int64_t nb, i
     if (!Bt) return -2;
     for (int64_t j = 0; j < nb; ++j)
         for (int k = 0; k < d; ++k) Bt[(size_t)k * nbp + j] = B[(size_t)j * d + k];
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads())
     for (int64_t i = 0; i < na; ++i) {
         const float* a = A + (size_t)i * d;
         float best = -INFINITY;
@@ -123,7 +131,7 @@ int fo_ivf_search(const float* X, int64_t n, int d, const int32_t* probes, int n
     if (d <= 0 || (d & 1)) return -1;
     const int dh = d / 2;
     int rc = 0;
-#pragma omp parallel
+#pragma omp parallel num_threads(nthreads())
     {
         int64_t cap = 1024;
         float* s = (float*)malloc(sizeof(float) * cap);
@@ -168,7 +176,7 @@ int fo_ivf_search(const float* X, int64_t n, int d, const int32_t* probes, int n
 
 /* row-wise top-k of a dense [n, m] similarity matrix, ids = column (coarse quantiser, exhaustive search) */
 int fo_topk_rows(const float* S, int64_t n, int64_t m, int k, float* sim, int32_t* idx) {
-#pragma omp parallel
+#pragma omp parallel num_threads(nthreads())
     {
         float* os = (float*)malloc(sizeof(float) * k);
         int64_t* oi = (int64_t*)malloc(sizeof(int64_t) * k);
@@ -195,7 +203,7 @@ int fo_topk_rows(const float* S, int64_t n, int64_t m, int k, float* sim, int32_
  */
 int fo_sims_mode(const float* A, int64_t na, const float* B, int64_t nb, int d, int mode, float* out) {
     const int dh = d / 2;
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads())
     for (int64_t i = 0; i < na; ++i)
         for (int64_t j = 0; j < nb; ++j) {
             const float* a = A + (size_t)i * d;

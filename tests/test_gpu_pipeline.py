@@ -28,9 +28,9 @@ def _dataset(n, seed=42, charge=2, **kw):
     return d, SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
 
 
-def _check_stages(ctx, d, ds, tol, mode, rt_tol, batch_size, p):
+def _check_stages(ctx, d, ds, tol, mode, rt_tol, batch_size, p, pipe=None):
     from falcon_amd.cluster.cluster import ClusterPipeline
-    pipe = ClusterPipeline(ctx)
+    pipe = pipe or ClusterPipeline(ctx)
     labels, medoids = pipe.run(ds, tol, mode, rt_tol, 0.05, batch_size, p, keep_intermediates=True)
     L = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in pipe.last.items() if k != "index"}
     labels, medoids = labels.cpu().numpy(), medoids.cpu().numpy()

@@ -1,0 +1,124 @@
+"""GPU parity in the bucket regimes of BASELINE configs[2] and configs[3] at reduced size (VERDICT r1 #1a).
+
+configs[2] (10 M spectra): the 1 m/z precursor windows hold ~8,750 spectra -> n_list = 128, n_probe = 16, k_ann = 128.
+configs[3] (50 M spectra): windows of ~20-35 k spectra -> n_list = 512, n_probe = 32, k_ann = 128.
+A handful of such buckets is enough for the oracle (oracle/kordered.c sums in the kernels' k order), so every stage
+is compared bit for bit: k-means index, n_probe search, neighbour lists, DBSCAN, refinement, labels and medoids."""
+import numpy as np
+import pytest
+
+from oracle import falcon_oracle as fo
+from tests.test_gpu_pipeline import _check_stages
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from falcon_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _dense_dataset(n, mz_lo, mz_hi, seed):
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import SpectrumDataset
+    d = synth.select_charge(synth.generate(n, seed=seed, mz_lo=mz_lo, mz_hi=mz_hi), 2)
+    return d, SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+
+
+def _check_index_equals_oracle(pipe_last, X, kmeans_iters):
+    """the GPU's k-means index (centroids, assignment, lists) against the oracle's own build of every IVF bucket"""
+    cent, asg, perm, loff = [t.cpu().numpy() for t in pipe_last["index"].export()]
+    splits, n_list = pipe_last["splits"], pipe_last["n_list"]
+    lb = np.concatenate([[0], np.cumsum(n_list)])
+    n_ivf = 0
+    for b, (a, e) in enumerate(zip(splits[:-1], splits[1:])):
+        if n_list[b] == 1:
+            continue
+        C, ra, rperm, roff = fo.ivf_build(X[a:e], int(n_list[b]), kmeans_iters)
+        assert np.array_equal(asg[a:e], ra), (b, int((asg[a:e] != ra).sum()))
+        assert np.array_equal(cent[lb[b]:lb[b + 1]], C), b
+        assert np.array_equal(loff[lb[b]:lb[b + 1] + 1] - a, roff) and np.array_equal(perm[a:e] - a, rperm)
+        n_ivf += 1
+    return n_ivf
+
+
+def test_config3_regime_buckets_of_8750_rows_n_list_128(ctx):
+    """three 1 m/z windows of ~9 k charge-2 spectra: n_list 128, n_probe 16, k_ann 128, d 400, 10 k-means iterations
+    (the whole-job settings of BASELINE configs[2])."""
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
+    d, ds = _dense_dataset(39000, 600.0, 603.0, seed=71)
+    p = AnnParams()                                                      # defaults: 400 / 16 / 64 / 128 / eps 0.1 / 10 iterations
+    pipe = ClusterPipeline(ctx)
+    labels, medoids = _check_stages(ctx, d, ds, 20.0, "ppm", None, 2 ** 15, p, pipe=pipe)
+    L = pipe.last
+    sizes = np.diff(L["splits"])
+    assert (np.asarray(L["n_list"]) == 128).sum() >= 3 and sizes.max() > 8000
+    X = L["X"].cpu().numpy()
+    assert _check_index_equals_oracle(L, X, p.kmeans_iters) >= 3
+    ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"])
+    assert np.array_equal(labels, ref) and np.array_equal(medoids, rmed)
+
+
+def test_config4_regime_bucket_of_25k_rows_n_list_512_n_probe_32(ctx):
+    """one 1 m/z window of ~25 k charge-2 spectra: n_list 512, n_probe 32, k_ann 128 (BASELINE configs[3])."""
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
+    d, ds = _dense_dataset(36000, 600.02, 600.98, seed=72)
+    p = AnnParams(n_probe=32, n_neighbors_ann=128, n_neighbors=64)
+    pipe = ClusterPipeline(ctx)
+    labels, medoids = _check_stages(ctx, d, ds, 20.0, "ppm", None, 2 ** 15, p, pipe=pipe)
+    L = pipe.last
+    assert 512 in list(L["n_list"]) and np.diff(L["splits"]).max() > 20000
+    X = L["X"].cpu().numpy()
+    assert _check_index_equals_oracle(L, X, p.kmeans_iters) >= 1
+    ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"], n_probe=32)
+    assert np.array_equal(labels, ref) and np.array_equal(medoids, rmed)
+
+
+def test_bucket_sharded_run_many_equals_single_gpu(ctx):
+    """bench.py's multi-GPU step on one device: `run_many(shard=(r, 3))` for r = 0, 1, 2 (the same buckets -> ranks
+    assignment every rank derives) and `SparseGraphExchange.assemble_labels`-style merging give the single-GPU
+    partition; the CSR payload maps neighbour ids back to dataset rows."""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    data = synth.generate(9000, seed=29)
+    parts = []
+    for ch in (2, 3):
+        c = synth.select_charge(data, ch)
+        parts.append(SpectrumDataset(c["precursor_mz"], c["retention_time"], c["mz"], c["intensity"], c["indptr"]))
+    pipe = ClusterPipeline(ctx)
+    p = AnnParams(eps=0.3)
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, p)
+    single = pipe.run_many(parts, *args)
+    single_nb = [(x["nb_idx"].cpu().numpy(), x["nb_dist"].cpu().numpy(), x["order"].cpu().numpy()) for x in pipe.lasts]
+    world = 3
+    merged = [np.full(len(ds), -1, np.int64) for ds in parts]
+    offs = [0] * len(parts)
+    seen_edges = [set() for _ in parts]
+    for r in range(world):
+        outs = pipe.run_many(parts, *args, shard=(r, world))
+        for j, ((lab, med), last) in enumerate(zip(outs, pipe.lasts)):
+            rows = last["rows"].cpu().numpy()
+            lab, med = lab.cpu().numpy(), med.cpu().numpy()
+            assert len(lab) == len(rows) and (merged[j][rows] == -1).all()
+            merged[j][rows] = lab + offs[j]
+            offs[j] += len(med)
+            assert np.array_equal(lab[med], np.arange(len(med)))
+            if len(rows):
+                ip, ci, cd = ctx.neighbors_to_csr(last["nb_idx"], last["nb_dist"], 1000000 * j, nb_count=last["nb_count"],
+                                                  id_map=last["rows"])
+                ip, ci, cd = ip.cpu().numpy(), ci.cpu().numpy(), cd.cpu().numpy()
+                for i in np.flatnonzero(np.diff(ip))[:200]:
+                    for e in range(ip[i], ip[i + 1]):
+                        seen_edges[j].add((int(rows[i]), int(ci[e]) - 1000000 * j, float(cd[e])))
+    for j, ds in enumerate(parts):
+        ref = single[j][0].cpu().numpy()
+        assert (merged[j] >= 0).all()
+        pairs = np.unique(np.stack([ref, merged[j]]), axis=1)
+        assert pairs.shape[1] == len(np.unique(ref)) == len(np.unique(merged[j]))         # same partition
+        nb_idx, nb_dist, order = single_nb[j]
+        full = {(int(order[i]), int(order[c]), float(dd)) for i in range(len(order)) for c, dd in zip(nb_idx[i], nb_dist[i]) if c >= 0}
+        assert len(seen_edges[j]) > 100 and seen_edges[j] <= full                           # ids are dataset rows

@@ -226,3 +226,28 @@ def test_csv_writer_quotes_like_pandas(tmp_path):
     assert back[1] == ["/d/a,b.mgf", 'id "x", 1', "2", "500.23", "12.5", "3"]
     assert back[2] == ["/d/c.mgf", "plain", "None", "1199.9999", "-1.0", "4"]
     assert '"id ""x"", 1"' in lines[1]
+
+
+def test_device_generator_matches_the_numpy_recipe_statistically():
+    """bench.py draws its workloads with `synth.generate_device` (torch; here on the CPU device): same recipe as the
+    numpy generator of the parity tests, another random stream."""
+    import torch
+    from falcon_amd import synth
+    n = 60000
+    a = synth.generate(n)
+    b = {k: v.numpy() for k, v in synth.generate_device(n, torch.device("cpu")).items()}
+    assert np.array_equal(b["indptr"][:1], [0]) and b["indptr"][-1] == len(b["mz"]) and b["mz"].dtype == np.float32
+    ca, cb = np.diff(a["indptr"]), np.diff(b["indptr"])
+    assert cb.max() <= 50 and cb.min() >= 1 and abs(ca.mean() - cb.mean()) < 0.05
+    for k, rel in (("mz", 0.005), ("intensity", 0.01), ("precursor_mz", 0.01), ("retention_time", 0.01)):
+        assert abs(a[k].mean() - b[k].mean()) <= rel * abs(a[k].mean()), k
+        assert abs(a[k].std() - b[k].std()) <= 2 * rel * a[k].std(), k
+    assert abs((a["precursor_charge"] == 2).mean() - (b["precursor_charge"] == 2).mean()) < 0.01
+    ha, hb = np.bincount(np.bincount(a["truth"]), minlength=30)[:30], np.bincount(np.bincount(b["truth"]), minlength=30)[:30]
+    assert np.abs(ha - hb).max() <= 0.1 * ha.max()                        # same cluster-size distribution
+    for i in (0, 77, n - 1):                                              # sorted peaks, unit norm
+        m = b["mz"][b["indptr"][i]:b["indptr"][i + 1]]
+        assert np.all(np.diff(m) >= 0) and m.min() >= 101 and m.max() <= 1500
+        assert abs(np.linalg.norm(b["intensity"][b["indptr"][i]:b["indptr"][i + 1]].astype(np.float64)) - 1) < 1e-5
+    c2 = synth.select_charge_device(synth.generate_device(5000, torch.device("cpu")), 2)
+    assert int(c2["indptr"][-1]) == c2["mz"].numel() and (c2["precursor_charge"] == 2).all()
