@@ -314,7 +314,7 @@ def test_star_graphs_more_clusters_than_half_the_rows(ctx):
     ref_db = fo.dbscan_components(nb_idx, nb_dist, 0.1)
     assert np.array_equal(db.cpu().numpy(), ref_db)
     assert n_db == 4 * m and n_db > n // 2 + 1
-    lab, n_cl = ctx.refine_clusters(db, n_db, ctx.to_dev(mz, torch.float32), None, 20.0, "ppm", None)
+    lab, n_cl = ctx.refine_clusters(db.clone(), n_db, ctx.to_dev(mz, torch.float32), None, 20.0, "ppm", None)   # (in place)
     ref_lab = fo.refine_and_number(ref_db, None, mz, None, 20.0, "ppm", None)
     assert np.array_equal(lab.cpu().numpy(), ref_lab)
     assert n_cl == m                                    # {core 0, border} survives, the three lone cores become noise
