@@ -44,6 +44,7 @@ _SIGNATURES = {
                               c_void_p, c_int64, P(c_int64)], c_int),
     "fal_ivf_build": ([c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, P(c_void_p)], c_int),
     "fal_ivf_attach_f16": ([c_void_p, c_void_p, c_int], c_int),
+    "fal_ivf_attach_prefilter": ([c_void_p, c_void_p], c_int),
     "fal_ivf_destroy": ([c_void_p], c_int),
     "fal_ivf_total_lists": ([c_void_p, P(c_int64)], c_int),
     "fal_ivf_export": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),

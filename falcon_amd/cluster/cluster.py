@@ -40,6 +40,8 @@ class AnnParams:
     dtype: str = "f32"            # "f32", or "f16": float16 vectors + f16 MFMA scan (BASELINE config 5)
     scan: str = "f32"             # flat-bucket scan arithmetic for float32 vectors: "f32" (exact fp32 MFMA) or
                                   # "f16x3" (hi/lo float16 split, 3 f16 MFMAs per step, ~3e-7 absolute error)
+    prefilter: bool = True        # float32 flat buckets: keep the top-k on chip (f16-MFMA prefilter + exact float32
+                                  # refinement, fused.hip); results are bit-identical with and without it
     rescore: bool = False         # re-score the ANN neighbours with the reference's matched-peak cosine
                                   # (similarity.py:17-80) before DBSCAN; uses fragment_tol and min_matches
     min_matches: int = 0          # (set from generate_clusters' `min_matches` when rescore is on)
@@ -142,7 +144,7 @@ class ClusterPipeline:
         all_flat = bool((n_list == 1).all())
         vec = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
                                      p.hash_seed, True, dt)
-        X = X16 = None
+        X = X16 = Xpre = None
         if p.dtype == "f16":
             X16 = vec("f16")
         elif p.scan == "f16x3":
@@ -151,7 +153,9 @@ class ClusterPipeline:
                 X = vec("f32")              # k-means, coarse quantiser and IVF fine scan stay exact fp32
         else:
             X = vec("f32")
-        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16)
+            if p.prefilter and not keep_intermediates and p.low_dim in (64, 128, 256, 400) and bool((n_list == 1).any()):
+                Xpre = vec("f16")
+        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre)
         if keep_intermediates:
             sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
             nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
@@ -164,7 +168,7 @@ class ClusterPipeline:
         if p.rescore:
             nb_dist = c.rescore_neighbors(nb_idx, nb_dist, ds.mz, ds.intensity, ds.indptr, order, fragment_tol,
                                           p.min_matches)
-        st.update(X=X, X16=X16, index=index, nb_idx=nb_idx, nb_dist=nb_dist,
+        st.update(X=X, X16=X16, Xpre=Xpre, index=index, nb_idx=nb_idx, nb_dist=nb_dist,
                   nb_count=None if keep_intermediates else index.nb_count)
 
     def _graph(self, st, precursor_tol_mass, precursor_tol_mode, rt_tol, p, keep_intermediates):

@@ -179,6 +179,7 @@ int fal_ctx_destroy(fal_ctx* c) {
         if (s.ptr) (void)hipFree(s.ptr);
     for (auto& b : c->pool) (void)hipFree(b.ptr);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->fb_host) (void)hipHostFree(c->fb_host);
     if (c->arena) (void)hipHostFree(c->arena);
     for (auto& t : c->timers)
         for (auto& p : t.ev) {
@@ -213,6 +214,7 @@ int fal_ctx_enable_timing(fal_ctx* c, int on) {
 int fal_ctx_counter(fal_ctx* c, int which, int64_t* value) {
     FAL_REQUIRE(c && value && which >= 0 && which < 8, FAL_EINVAL, "fal_ctx_counter: bad argument");
     *value = c->counters[which];
+    if (which == 5) *value = c->fb_host ? (int64_t)*c->fb_host : 0;      // fallback queries of the last fused scan (after a sync)
     return FAL_OK;
 }
 

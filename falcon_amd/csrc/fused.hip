@@ -53,7 +53,9 @@ constexpr int kKeepCap = 48;         // selected window candidates kept per quer
 constexpr int kHistStride = 516;     // bytes per query: 256 x u16 + 4 (lane = query reads stay conflict-free)
 constexpr int kWaveHist = 32 * kHistStride;                     // 16,512 B: histogram, later the member lists
 static_assert(32 * kMemCap * 8 <= kWaveHist, "member lists alias the histograms");
-constexpr int kWaveSmall = 1536;     // per-wave per-query scalars + the sort staging of phase E
+constexpr int kWaveSmall = 2048;     // per-wave per-query scalars + the sort staging of phase E
+constexpr int kKeptBytes = 4 * 32 * kKeepCap * 8;               // kept lists of the four waves (alias the staging buffers)
+__host__ __device__ constexpr int region_a_bytes(int d) { return 2 * 32 * (d * 2 + 16) > kKeptBytes ? 2 * 32 * (d * 2 + 16) : kKeptBytes; }
 
 __device__ __forceinline__ int rowoff16(int i) { return (i & 3) + 8 * (i >> 2); }
 
@@ -112,8 +114,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
     constexpr int PIECES = 32 * RB16;
     constexpr int kStage = (PIECES + 255) / 256;
     constexpr int NB = STEPS < 4 ? STEPS : 4;
-    constexpr int kStageBytes = 2 * 32 * RS;
-    static_assert(kStageBytes / 4 >= 32 * kKeepCap * 8, "kept lists alias the staging buffers");
+    constexpr int kStageBytes = region_a_bytes(D);   // staging buffers, later the kept lists
     extern __shared__ __align__(16) unsigned char lds[];
     int ji, T;
     if (!find_job_xcd128f(a.jobs, a.n_jobs, blockIdx.x, &ji, &T)) return;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
     static_assert((11 * 32 + 128) * 4 <= kWaveSmall, "per-wave scalars");
     uint32_t* mem_id = reinterpret_cast<uint32_t*>(whist);              // [32][kMemCap]
     float* mem_v = reinterpret_cast<float*>(whist + 32 * kMemCap * 4);  // [32][kMemCap]
-    uint32_t* kept_u = reinterpret_cast<uint32_t*>(lds + w * (kStageBytes / 4));   // [32][kKeepCap] (after the passes)
+    uint32_t* kept_u = reinterpret_cast<uint32_t*>(lds + w * (kKeptBytes / 4));    // [32][kKeepCap] (after the passes)
     uint32_t* kept_id = kept_u + 32 * kKeepCap;
 
     if (lane < 32) {
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
         q_kcnt[lane] = 0;
     }
 
-    if (need_thr) {
+    const int dbg = a.dbg;
+    if (need_thr && !(dbg & 32)) {
         // ================= approximate passes on the f16 matrix cores ==============================================
         const __half* X16 = a.X16;
         half8 q[STEPS];
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
         // ---- pass 1: histogram of the approximate similarities (bin = floor(256 v), 255 = everything above) ----
         unsigned char* hbase = whist + (4 * h) * kHistStride;
         FAL_PASS({
-            const bool cval = c0 + r < nc;
+            const bool cval = c0 + r < nc && !(dbg & 1);
             _Pragma("unroll") for (int i = 0; i < 16; ++i) {
                 const float v = fmaxf(acc[i], 0.f);
                 const uint32_t b = min(255u, (uint32_t)(v * 256.f));
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
         }
         const uint32_t below = (1u << r) - 1u;
         FAL_PASS({
-            const bool cval = c0 + r < nc;
+            const bool cval = c0 + r < nc && !(dbg & 2);
             _Pragma("unroll") for (int i = 0; i < 16; ++i) {
                 const float v = fmaxf(acc[i], 0.f);
                 const bool hit = cval && v >= lo_r[i] && v <= hi_r[i];
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
         }
         __syncthreads();
         // ---- T~ = the (k - n_above)-th best approximate value inside bin b*; exact k-th value in [T~ - eps, T~ + eps] --
-        for (int ql = 0; ql < 32; ++ql) {
+        for (int ql = 0; ql < ((dbg & 4) ? 0 : 32); ++ql) {
             const int mc = q_mcnt[ql];
             if (mc > kMemCap) {                              // too many values share the bin: exact fallback
                 if (lane == 0) q_flag[ql] = 2;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
             kc[i] = 0;
         }
         const uint32_t below = (1u << r) - 1u;
-        const int n_chunks = (whi - wlo + 31) >> 5;
+        const int n_chunks = (dbg & 8) ? 0 : (whi - wlo + 31) >> 5;
         CandStream<DH4> cs;
         auto crow = [&](int c0) -> const float* { return X + (row0 + min(c0 + r, nc - 1)) * D + (int64_t)h * DH; };
         const float* cur = crow(wlo);
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
     __syncthreads();
 
     // ================= per query: exact resolution of ambiguous candidates, sort, neighbour lists =====================
-    if (!active) return;
+    if (!active || (dbg & 16)) return;
     for (int ql = 0; ql < nqw; ++ql) {
         const int64_t row = row0 + qbase + ql;
         int flag = q_flag[ql];
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
             }
         }
         if (flag & 2) {
-            if (lane == 0) push_fallback(a, row, ji);
+            if (lane == 0 && !(dbg & 64)) push_fallback(a, row, ji);
             continue;
         }
         // compact the selected candidates (ambiguous ones against the exact k-th key) and sort them
@@ -548,6 +550,10 @@ __global__ __launch_bounds__(64) void fused_fallback_kernel(FusedArgs a, SelectA
 int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t list_tiles, int max_nc) {
     if (a_in.n_jobs <= 0 || list_tiles <= 0) return FAL_OK;
     FusedArgs a = a_in;
+    {
+        const char* e = getenv("FALCON_FUSED_DBG");
+        a.dbg = e ? atoi(e) : 0;
+    }
     FAL_REQUIRE(list_tiles * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     FAL_REQUIRE(max_nc < 65536, FAL_EUNSUPPORTED, "fused scan: buckets must hold fewer than 65,536 rows");
     const int steps = d / 16;
@@ -563,7 +569,7 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t list_tiles,
     a.fb_list = fb + 16;
     a.fb_cap = fb_cap;
     FAL_CHECK_HIP(hipMemsetAsync(fb, 0, sizeof(int32_t) * 16, ctx->stream));
-    const size_t lds = (size_t)2 * 32 * ((size_t)d * 2 + 16) + 4 * kWaveHist + 4 * kWaveSmall;
+    const size_t lds = (size_t)region_a_bytes(d) + 4 * kWaveHist + 4 * kWaveSmall;
     dim3 grid((unsigned)(list_tiles * 8)), block(256);
     {
         StageScope ts(ctx, ST_SCAN);
@@ -593,8 +599,9 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t list_tiles,
         hipLaunchKernelGGL(fused_fallback_kernel, dim3((unsigned)fb_grid), dim3(64), 0, ctx->stream, a, sa, scratch, stride, d);
         FAL_CHECK_HIP(hipGetLastError());
     }
-    // the number of fallback queries of the last call: readable through fal_ctx_counter(5) after a sync
-    FAL_CHECK_HIP(hipMemcpyAsync(&ctx->counters_dev_shadow, fb, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    // the number of fallback queries of this call: fal_ctx_counter(5) after a sync (pinned target: truly asynchronous)
+    if (!ctx->fb_host) FAL_CHECK_HIP(hipHostMalloc((void**)&ctx->fb_host, 64, hipHostMallocDefault));
+    FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host, fb, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     return FAL_OK;
 }
 

@@ -214,6 +214,13 @@ int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes) {
     return FAL_OK;
 }
 
+int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16) {
+    FAL_REQUIRE(ivf && X16, FAL_EINVAL, "fal_ivf_attach_prefilter: NULL argument");
+    FAL_REQUIRE(ivf->X, FAL_EINVAL, "fal_ivf_attach_prefilter: the index has no float32 rows to refine with");
+    ivf->Xpre = X16;
+    return FAL_OK;
+}
+
 int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists) {
     FAL_REQUIRE(ivf && total_lists, FAL_EINVAL, "fal_ivf_total_lists: NULL");
     *total_lists = ivf->total_lists;

@@ -12,6 +12,7 @@
 #include "scan.h"
 #include "ivf.h"
 #include "util.h"
+#include "fused.h"
 
 namespace fal {
 
@@ -162,6 +163,37 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     }
     std::vector<DenseJob> flat, coarse;    // coarse doubles as the IVF tile table
     flat.reserve(border.size());
+    // Flat buckets with the top-k kept on chip (fused.hip): needs the float16 prefilter rows and the fused a8 output
+    static const bool no_fused = getenv("FALCON_NO_FUSED") != nullptr;
+    const bool fused = nf && ivf->Xpre && ivf->X && fused_supports(d) && !no_fused && !border.empty() &&
+                       (ivf->bucket_off[border[0] + 1] - ivf->bucket_off[border[0]]) < 65536;
+    if (fused) {
+        std::vector<DenseJob> fj;
+        fj.reserve(border.size());
+        int64_t xt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t pairs = 0, band = 0;
+        for (size_t j = 0; j < border.size(); ++j) {
+            const int64_t b = border[j];
+            const int64_t row0 = ivf->bucket_off[b], nb = ivf->bucket_off[b + 1] - row0;
+            const int x = (int)(j & 7);
+            fj.push_back({row0, row0, 0, 0, (int32_t)nb, (int32_t)nb, xt[x]});
+            xt[x] += ceil_div(nb, 128);
+            pairs += nb * nb;
+        }
+        DenseJob* fj_dev = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * fj.size(), (void**)&fj_dev));
+        FAL_TRY(ctx->upload(fj_dev, fj.data(), sizeof(DenseJob) * fj.size()));
+        FusedArgs fa{};
+        fa.X = ivf->X; fa.X16 = reinterpret_cast<const __half*>(ivf->Xpre); fa.jobs = fj_dev; fa.n_jobs = (int)fj.size();
+        fa.k = k_ann; fa.pmz = nf->pmz; fa.rt = nf->rt; fa.tol = nf->tol; fa.rt_tol = nf->rt_tol; fa.is_da = nf->is_da;
+        fa.keep = nf->keep; fa.nb_idx = nf->nb_idx; fa.nb_dist = nf->nb_dist; fa.nb_count = nf->nb_count;
+        FAL_TRY(launch_fused(ctx, fa, d, *std::max_element(xt, xt + 8), fj[0].nc));
+        ctx->counters[0] = pairs;
+        ctx->counters[4] = band;
+        ctx->counters[2] = 1;
+        ctx->counters[3] = 0;
+        border.clear();                       // nothing left for the staged flat path
+    }
     // a batch = jobs [j0, j1): [j0, jm) go to the f16-MFMA kernel (128-query tiles), [jm, j1) to the fp32 one
     struct FlatBatch { size_t j0, jm, j1; int64_t tiles, list_tiles16, list_tiles32, floats; };
     std::vector<FlatBatch> flat_batches;
@@ -308,8 +340,10 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     }
     for (int b = 0; b < 2; ++b)
         if (sel_pending[b]) FAL_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_sel[b], 0));     // join
-    ctx->counters[0] = 0;
-    ctx->counters[4] = 0;                      // inner products the matrix cores actually computed (incl. padding)
+    if (!fused) {
+        ctx->counters[0] = 0;
+        ctx->counters[4] = 0;                  // inner products the matrix cores actually computed (incl. padding)
+    }
     for (const FlatBatch& fb : flat_batches)
         for (size_t j = fb.j0; j < fb.j1; ++j) {
             const int64_t ch = ceil_div(flat[j].nc, 32);
@@ -318,8 +352,10 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         }
     for (const DenseJob& j : flat) ctx->counters[0] += (int64_t)j.nq * j.nc;
     ctx->counters[1] = 0;
-    ctx->counters[2] = (int64_t)flat_batches.size();
-    ctx->counters[3] = (int64_t)(sizeof(float) * std::max(need_flat, need_coarse));
+    if (!fused) {
+        ctx->counters[2] = (int64_t)flat_batches.size();
+        ctx->counters[3] = (int64_t)(sizeof(float) * std::max(need_flat, need_coarse));
+    }
     if (coarse.empty()) return FAL_OK;   // (job tables went through the pinned upload ring: nothing to wait for)
     for (const DenseJob& j : coarse) ctx->counters[1] += (int64_t)j.nq * j.nc;
 

@@ -114,9 +114,10 @@ class Context:
 
     # ------------------------------------------------------------------ a6 / a7
     def ivf_build(self, X, bucket_off: np.ndarray, n_list: np.ndarray, kmeans_iters: int = 10,
-                  X16=None) -> "IvfIndex":
+                  X16=None, Xpre=None) -> "IvfIndex":
         """X: float32 [n, d] (may be None when every bucket is flat and X16 is given);
-        X16: optional float16 [n, d] (plain rows) or [n, 2, d] (hi/lo split) for the f16 flat scan."""
+        X16: optional float16 [n, d] (plain rows) or [n, 2, d] (hi/lo split) for the f16 flat scan;
+        Xpre: optional float16 [n, d] copy of X used only as the prefilter of `search_neighbors` (exact results)."""
         torch = _torch()
         if X is not None:
             assert X.dtype == torch.float32 and X.is_contiguous() and X.device == self.tdev
@@ -135,6 +136,10 @@ class Context:
             planes = 2 if X16.dim() == 3 else 1
             check(self.lib.fal_ivf_attach_f16(h, self._p(X16), planes), "fal_ivf_attach_f16")
             index.X16 = X16
+        if Xpre is not None:
+            assert Xpre.dtype == torch.float16 and Xpre.is_contiguous() and Xpre.device == self.tdev and Xpre.shape == (n, d)
+            check(self.lib.fal_ivf_attach_prefilter(h, self._p(Xpre)), "fal_ivf_attach_prefilter")
+            index.Xpre = Xpre
         return index
 
 
@@ -297,7 +302,7 @@ class IvfIndex:
     """Opaque `fal_ivf` handle (keeps the vectors alive: the index borrows them)."""
 
     def __init__(self, ctx: Context, handle, X, bucket_off, n_list, n, d):
-        self.ctx, self._h, self.X, self.X16 = ctx, handle, X, None
+        self.ctx, self._h, self.X, self.X16, self.Xpre = ctx, handle, X, None, None
         self.bucket_off, self.n_list = bucket_off, n_list
         self.n, self.d = n, d
         t = C.c_int64()
@@ -306,7 +311,8 @@ class IvfIndex:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.ctx.lib.fal_ivf_destroy(self._h)
+            if getattr(self.ctx, "_h", None):            # (the context owns the pool the index's arrays return to)
+                self.ctx.lib.fal_ivf_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -123,6 +123,14 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim,
  * rows (FAL_DTYPE_SPLIT16; float32-accurate to ~3e-7).  With planes = 1 fal_ivf_build may be given
  * X = NULL as long as every bucket is flat.  The buffer is borrowed. ------------------- [dev] */
 int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes);
+/* Optional: float16 copies [n, low_dim] of the float32 vectors (fal_vectorize FAL_DTYPE_F16 on the same
+ * peaks) used ONLY as a PREFILTER by fal_ivf_search_neighbors on flat buckets: the bucket is scanned on the
+ * f16 matrix cores to bracket every query's n_neighbors_ann-th best similarity, the candidates inside the
+ * precursor window are then evaluated exactly in float32 and the bracket is resolved exactly where it
+ * matters -- the neighbour lists are BIT-IDENTICAL to the ones computed without the prefilter, the
+ * [n, candidates] similarity matrix never exists in HBM.  low_dim in {64, 128, 256, 400}; other sizes
+ * ignore the prefilter.  fal_ivf_search_topk never uses it.  The buffer is borrowed. ------------ [dev] */
+int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16);
 int fal_ivf_destroy(fal_ivf* ivf);
 int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists);
 /* Copy the index out for inspection (any pointer may be NULL): centroids
