@@ -24,6 +24,7 @@ struct FusedArgs {
     int32_t* fb_list;            // (row, job) pairs of the queries left to the exact fallback
     int32_t* fb_count;
     int fb_cap;
+    unsigned long long* stamps;  // FALCON_FUSED_DBG bit 128: per-workgroup phase time stamps [grid][10] (s_memtime)
     int dbg;                     // FALCON_FUSED_DBG: phase-skipping bits for timing experiments (results invalid when set)
 };
 

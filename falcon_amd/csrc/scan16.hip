@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void scan16_kernel(const __half* __restrict
     constexpr int RS = ROW_HALVES * 2 + 16;         // LDS row stride in bytes (padded: conflict-free b128 reads)
     constexpr int PIECES = 32 * RB16;               // per 32-row chunk
     constexpr int kStage = (PIECES + 255) / 256;    // 16-B pieces per thread per chunk
-    constexpr int NB = STEPS < 4 ? STEPS : 4;       // LDS operand ring: steps in flight ahead of the MFMAs
+    constexpr int NB = STEPS < 8 / PLANES ? STEPS : 8 / PLANES;   // LDS operand ring: steps in flight ahead of the MFMAs
     extern __shared__ __align__(16) unsigned char lds[];
     int ji, T;
     if (!find_job_xcd128(jobs, n_jobs, blockIdx.x, &ji, &T)) return;
@@ -132,6 +132,9 @@ __global__ __launch_bounds__(256, 1) void scan16_kernel(const __half* __restrict
             rh[s] = *reinterpret_cast<const half8*>(rowp + s * 16);
             if (PLANES == 2) rl[s] = *reinterpret_cast<const half8*>(rowp + D * 2 + s * 16);
         }
+        // pin the whole operand ring in front of the first MFMA (otherwise the scheduler issues the reads one step ahead
+        // only and every MFMA waits for an LDS round trip)
+        __builtin_amdgcn_sched_group_barrier(0x100, NB * PLANES, 0);
         f32x16 acc_hh, acc_x;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

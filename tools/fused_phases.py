@@ -34,3 +34,35 @@ for dbg in modes:
         index.search_neighbors(16, 128, mzs, None, 20.0, "ppm", None, 64)
     s, f = ctx.stage_ms("scan")[0], ctx.stage_ms("select")[0]
     print(f"dbg={dbg:3d} fused {s:.3f} ms  fallback kernel {f:.3f} ms  fallback rows {ctx.counter(5)}", flush=True)
+
+# ---- in-kernel time stamps (dbg bit 128): cycles per phase, per workgroup -------------------------------------------
+import ctypes
+os.environ["FALCON_FUSED_DBG"] = "128"
+index.search_neighbors(16, 128, mzs, None, 20.0, "ppm", None, 64)
+ctx.sync()
+ptr, nwg = ctx.counter(6), ctx.counter(7)
+hip = ctypes.CDLL("libamdhip64.so")
+buf = np.zeros((nwg, 10), np.uint64)
+hip.hipMemcpy(ctypes.c_void_p(buf.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(buf.nbytes), 2)
+live = buf[:, 0] > 0
+st = buf[live].astype(np.int64)
+nc = st[:, 8]
+names = ["pass1", "binsearch", "pass2", "Ttilde", "band", "exact-resolve", "rank+store"]
+print("workgroups", live.sum(), "of grid", nwg, " with passes (nc>128):", int((nc > 128).sum()))
+t0, t1 = st[:, 0].min(), st[:, 7].max()
+print("kernel span cycles (s_memtime ticks)", t1 - t0)
+big = nc > 128
+for name, sel in (("nc>128", big), ("nc<=128", ~big)):
+    if sel.sum() == 0:
+        continue
+    s = st[sel]
+    print(name, "count", sel.sum(), "mean nc", s[:, 8].mean(), "mean band chunks (wave 0)", s[:, 9].mean())
+    prev = s[:, 0]
+    for i, nme in enumerate(names):
+        cur = np.where(s[:, i + 1] > 0, s[:, i + 1], prev)
+        print(f"   {nme:14s} mean {np.mean(cur - prev):10.0f} ticks   total/CU {np.sum(cur - prev) / 256:12.0f}")
+        prev = cur
+    chunks = np.ceil(s[:, 8] / 32)
+    if name == "nc>128":
+        p1 = np.where(s[:, 1] > 0, s[:, 1] - s[:, 0], 0)
+        print("   pass1 ticks per chunk:", np.sum(p1) / np.sum(chunks))
