@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--scan", choices=["f32", "f16x3"], default="f32",
                     help="flat-scan arithmetic: exact fp32 MFMA (default) or hi/lo float16 split on the f16 MFMA")
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32", help="vector dtype (f16 = BASELINE config 5)")
+    ap.add_argument("--prefilter", action="store_true",
+                    help="flat buckets: top-k kept on chip (f16-MFMA prefilter + exact float32 window, fused.hip; same results)")
     ap.add_argument("--rescore", action="store_true",
                     help="re-score the neighbours with the matched-peak cosine before DBSCAN (SURVEY 8f-4; not the headline)")
     ap.add_argument("--generator", choices=["device", "numpy"], default="device",
@@ -153,7 +155,7 @@ def main():
     def params(**kw):
         base = dict(eps=args.eps, low_dim=args.low_dim, n_probe=args.n_probe, n_neighbors=args.n_neighbors,
                     n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval, scan=args.scan, dtype=args.dtype,
-                    rescore=args.rescore, min_matches=6 if args.rescore else 0)
+                    rescore=args.rescore, min_matches=6 if args.rescore else 0, prefilter=args.prefilter)
         base.update(kw)
         return AnnParams(**base)
 

@@ -40,8 +40,10 @@ class AnnParams:
     dtype: str = "f32"            # "f32", or "f16": float16 vectors + f16 MFMA scan (BASELINE config 5)
     scan: str = "f32"             # flat-bucket scan arithmetic for float32 vectors: "f32" (exact fp32 MFMA) or
                                   # "f16x3" (hi/lo float16 split, 3 f16 MFMAs per step, ~3e-7 absolute error)
-    prefilter: bool = True        # float32 flat buckets: keep the top-k on chip (f16-MFMA prefilter + exact float32
-                                  # refinement, fused.hip); results are bit-identical with and without it
+    prefilter: bool = False       # float32 flat buckets: keep the top-k on chip (f16-MFMA prefilter + exact float32
+                                  # refinement, fused.hip); results are bit-identical with and without it.  Off by default:
+                                  # at BASELINE configs[1]'s bucket sizes (<= ~1,100 rows) it is on par with the staged
+                                  # scan + select, it pays on larger flat buckets
     rescore: bool = False         # re-score the ANN neighbours with the reference's matched-peak cosine
                                   # (similarity.py:17-80) before DBSCAN; uses fragment_tol and min_matches
     min_matches: int = 0          # (set from generate_clusters' `min_matches` when rescore is on)

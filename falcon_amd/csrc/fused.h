@@ -1,35 +1,58 @@
 // Internal interface of fused.hip: flat-bucket cosine scan with the top-k kept on chip (f16-MFMA prefilter,
-// exact fp32 refinement of the precursor window, exact fallback for the rows the chip cannot hold).
+// exact fp32 refinement of the precursor window, exact resolution of the k-th key, exact fallback for the rows the
+// chip cannot hold).
 #pragma once
 #include <hip/hip_fp16.h>
 #include "common.h"
 #include "simtile.h"
 
+#define FAL_FUSED_MEM 40      /* members (candidates inside the threshold bin) kept per query: 20 per lane half */
+#define FAL_FUSED_KEEP 64     /* selected window candidates kept per query: 32 per lane half */
+
 namespace fal {
+
+struct QThr {                    // per query, approx_kernel -> band_kernel / resolve_kernel
+    float L, U;                  // the exact k-th best similarity lies in [L, U]
+    float T, eps;                // k-th best approximate similarity, bound of |approx - exact| around it
+    int bstar, nabove;           // its histogram bin, candidates in higher bins
+    int mc;                      // members of half 0 | half 1 << 16
+    int flags;                   // bit 1: exact fallback
+};
 
 struct FusedArgs {
     const float* X;              // [n, d] float32 rows, precursor-sorted
     const __half* X16;           // [n, d] the same rows rounded to float16 (prefilter only)
-    const DenseJob* jobs;        // flat buckets sorted by decreasing size; xtile0 = 128-query tiles of earlier jobs of
-    int n_jobs;                  // the same XCD list (jobs j, j + 8, ...); q_row0 == c_row0, nq == nc
+    // flat buckets sorted by decreasing size, q_row0 == c_row0, nq == nc; xtile0 = tiles of earlier jobs of the same XCD list
+    const DenseJob* jobs128;     // buckets with more than k rows, 128-query tiles (approx_kernel)
+    int n_jobs128;
+    const DenseJob* jobs32;      // every flat bucket, 32-query tiles (band_kernel, resolve_kernel, fallback)
+    int n_jobs32;
     int k;                       // n_neighbors_ann
     const float* pmz;            // [n] precursor m/z by sorted row
     const float* rt;             // [n] or nullptr
     double tol, rt_tol;
+    float tol_f, rt_f;           // float32 forms of the tolerance tests (launch_fused)
     int is_da;
     int keep;                    // n_neighbors
     int32_t* nb_idx;             // [n, keep]
     float* nb_dist;              // [n, keep]
     int32_t* nb_count;           // [n] or nullptr
+    // hand-off between the kernels, indexed by sorted row (launch_fused)
+    QThr* thr;
+    float* gmem_v;               // [n, FAL_FUSED_MEM] approximate values of the members (half 0 | half 1)
+    uint32_t* gmem_id;           // [n, FAL_FUSED_MEM] bucket-local candidate
+    uint32_t* gkept_u;           // [n, FAL_FUSED_KEEP] sortable exact similarity of the kept window candidates
+    uint32_t* gkept_id;          // [n, FAL_FUSED_KEEP] sorted row | 0x80000000 (ambiguous)
+    int32_t* gkcnt;              // [n, 2] kept per half | 0x100 ambiguous | 0x200 overflow
     int32_t* fb_list;            // (row, job) pairs of the queries left to the exact fallback
     int32_t* fb_count;
     int fb_cap;
-    unsigned long long* stamps;  // FALCON_FUSED_DBG bit 128: per-workgroup phase time stamps [grid][10] (s_memtime)
-    int dbg;                     // FALCON_FUSED_DBG: phase-skipping bits for timing experiments (results invalid when set)
+    int dbg;                     // FALCON_FUSED_DBG: experiment bits (results invalid when set)
 };
 
 bool fused_supports(int d);
-// list_tiles = 128-query tiles of the longest XCD list; max_nc = largest bucket
-int launch_fused(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles, int max_nc);
+// n_rows = rows of the index (the hand-off buffers are indexed by sorted row); list_tiles* = tiles of the longest XCD list
+int launch_fused(fal_ctx* ctx, const FusedArgs& a, int d, int64_t n_rows, int64_t list_tiles128, int64_t list_tiles32,
+                 int max_nc);
 
 }  // namespace fal

@@ -1,31 +1,33 @@
-// a7 + a8 for FLAT buckets in one kernel: the cosine scan with the top-k kept on chip.
+// a7 + a8 for FLAT buckets with the top-k kept on chip: no [queries, candidates] similarity matrix in HBM.
 //
 // What the staged path does (scan.hip): fp32-MFMA similarity of every (query, candidate) pair of the bucket ->
 // [32, nc] block in HBM -> select kernel: k_ann best per query -> precursor / RT filter -> sort -> neighbour
 // lists.  The result only needs (i) the exact similarities of the candidates inside the query's precursor
 // window -- a contiguous band next to the diagonal, because the bucket's rows are sorted by precursor m/z -- and
-// (ii) the k_ann-th best key of the row, to decide which of them made the top-k_ann.  So this kernel
+// (ii) the k_ann-th best key of the row, to decide which of them made the top-k_ann.  Three kernels:
 //
-//   1. scans the whole bucket on the f16 matrix cores (float16 copies of the rows, float32 accumulation:
-//      1/16 of the fp32 matrix-pipe cycles) and builds a 256-bin histogram of the APPROXIMATE similarities of
-//      every query in LDS; the bin b* that holds the k_ann-th best approximate value follows from a suffix sum;
-//   2. scans a second time and collects the candidates whose approximate value lies in (a slightly widened) b*:
-//      the "members", <= 64 per query, in LDS.  The k_ann-th best approximate value T~ is selected among them;
-//      |approx - exact| <= eps(value) (bound below) puts the exact k_ann-th best value inside [T~ - eps, T~ + eps];
-//   3. computes the EXACT similarities of the precursor window with the fp32 matrix cores (same k-ordered
-//      fmaf chain as dense_kernel: bit-identical values) and classifies every in-tolerance candidate:
-//      above T~ + eps -> selected, below T~ - eps -> not selected, in between -> resolved exactly: the few
-//      members within 2 eps of T~ are re-evaluated exactly (VALU fmaf chain, the same bits) and the true
-//      k_ann-th key (value, id) decides;
-//   4. sorts the selected in-tolerance candidates and writes the neighbour lists.
+//   approx_kernel  (f16 matrix cores; buckets with more than k_ann rows)  scans the whole bucket twice on float16
+//      copies of the rows (float32 accumulation, 1/16 of the fp32 matrix-pipe cycles).  Pass 1 builds a 256-bin
+//      histogram of the APPROXIMATE similarities of every query in LDS (fine bins below 0.25 where the k-th value of
+//      spectra lies, coarse ones above); a suffix sum gives the bin b* of the k_ann-th best approximate value.  Pass 2
+//      collects the candidates whose approximate value lies in (a slightly widened) b* -- the "members", a handful per
+//      query -- and selects the k_ann-th best approximate value T~ among them.  |approx - exact| <= eps(value) (bound
+//      below) puts the exact k_ann-th best value inside [L, U] = [T~ - eps, T~ + eps].  Out: 32 B of thresholds and the
+//      member list per query.
+//   band_kernel  (fp32 matrix cores)  computes the EXACT similarities of the precursor window (the same k-ordered fmaf
+//      chain as dense_kernel: bit-identical values), applies the precursor / RT tolerance and keeps the candidates
+//      that are not certainly outside the top-k_ann (s >= L); those inside [L, U] are marked ambiguous.
+//   resolve_kernel  (one wave per query, full occupancy)  decides ambiguous candidates exactly -- the few members within
+//      2 eps of T~ are re-evaluated by VALU fmaf chains (the same bits), the true k_ann-th key (value, id) follows by
+//      counting --, sorts the survivors and writes the neighbour lists.
 //
-// Nothing but the neighbour lists leaves the CU: no [n, nc] similarity hand-off through HBM.  The output is
-// BIT-IDENTICAL to fal_ivf_search_topk -> fal_filter_neighbors (tests/test_gpu_search.py).  Queries the
-// on-chip structures cannot hold (more than 64 members -- e.g. hundreds of identical spectra --, more than 48
-// selected window candidates) are appended to a fallback list and redone by fused_fallback_kernel: exact row
-// by VALU fmaf chains + the staged path's own selection code.
+// The hand-off between the kernels is ~0.9 kB per query (thresholds, members, kept candidates) instead of 4 B per
+// (query, candidate) pair.  The output is BIT-IDENTICAL to fal_ivf_search_topk -> fal_filter_neighbors
+// (tests/test_gpu_fused.py).  Queries the on-chip structures cannot hold (more than 32 members per lane half -- e.g.
+// hundreds of identical spectra --, more than 24 kept window candidates per half) go to fused_fallback_kernel: exact
+// row by VALU fmaf chains + the staged path's own selection code.
 //
-// Error bound of step 1 (non-negative unit vectors x, y; ^ = rounded to float16): each factor carries a relative
+// Error bound of the prefilter (non-negative unit vectors x, y; ^ = rounded to float16): each factor carries a relative
 // error <= 2^-11 (normal range) or an absolute one <= 2^-25 (below 2^-14), products of float16 values are exact
 // in float32, the MFMA's float32 accumulation of d <= 1024 terms is within d * 2^-23 of the exact sum, and
 // the exact path's own fmaf chain within d * 2^-24:  |approx - exact| <= 1.3e-3 * approx + 2e-6.
@@ -48,15 +50,29 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr float kEpsRel = 1.3e-3f;
 constexpr float kEpsAbs = 2e-6f;
-constexpr int kMemCap = 64;          // members (candidates inside the threshold bin) kept per query
-constexpr int kKeepCap = 48;         // selected window candidates kept per query
-constexpr int kHistStride = 516;     // bytes per query: 256 x u16 + 4 (lane = query reads stay conflict-free)
-constexpr int kWaveHist = 17408;                                // >= 32 * kHistStride: histogram, later member lists / output rows
-constexpr int kWaveSmall = 2560;     // per-wave per-query scalars + the sort staging of phase E
-constexpr int kKeptBytes = 4 * 2 * 32 * (kKeepCap + 1) * 4;       // kept lists of the four waves (alias the staging buffers)
-__host__ __device__ constexpr int region_a_bytes(int d) { return 2 * 32 * (d * 2 + 16) > kKeptBytes ? 2 * 32 * (d * 2 + 16) : kKeptBytes; }
+constexpr int kBins = 160;           // 128 fine bins below 0.25 + 32 coarse ones
+constexpr int kHistStride = kBins * 2 + 4;   // bytes per query: u16 counters + 4 (lane = query reads stay conflict-free)
+constexpr int kWaveHist = 11008;     // >= 32 * kHistStride: histogram, later the member lists
+constexpr int kWaveSmall = 1280;     // per-wave per-query scalars
+constexpr int kMemHalf = FAL_FUSED_MEM / 2;      // members kept per (query, lane half)
+constexpr int kMemSlot = kMemHalf + 1;           // ... plus the dump slot the branch-free append writes to when full
+constexpr int kMemStride = 43;                   // dwords per query row (odd: lane = query accesses are conflict-free)
+constexpr int kKeepHalf = FAL_FUSED_KEEP / 2;    // selected window candidates kept per (query, lane half)
+static_assert(2 * 32 * kMemStride * 4 <= kWaveHist && 32 * kHistStride <= kWaveHist && 2 * kMemSlot <= kMemStride, "member lists alias the histograms");
 
 __device__ __forceinline__ int rowoff16(int i) { return (i & 3) + 8 * (i >> 2); }
+
+// histogram bin of an approximate similarity: 128 bins of 1/512 below 0.25 (where the k-th best value of hashed spectra
+// lies: a handful of members per bin), 32 bins of 3/128 above
+__device__ __forceinline__ uint32_t bin_of(float v) {
+    const uint32_t lo = (uint32_t)(v * 512.f);
+    const uint32_t hi = min((uint32_t)kBins - 1u, 128u + (uint32_t)(fmaxf(v - 0.25f, 0.f) * (128.f / 3.f)));
+    return v < 0.25f ? lo : hi;
+}
+__device__ __forceinline__ float bin_lo(int b) { return b < 128 ? (float)b * (1.f / 512.f) : 0.25f + (float)(b - 128) * (3.f / 128.f); }
+__device__ __forceinline__ float bin_hi(int b) {
+    return b < 128 ? (float)(b + 1) * (1.f / 512.f) : (b == kBins - 1 ? 1.0625f : 0.25f + (float)(b - 127) * (3.f / 128.f));
+}
 
 // the exact similarity on the vector ALU: the k-ordered fmaf chain of simtile.h, bit for bit
 __device__ __forceinline__ float exact_dot(const float* __restrict__ a, const float* __restrict__ b, int d) {
@@ -120,103 +136,64 @@ __device__ __forceinline__ bool find_job_xcd128f(const DenseJob* __restrict__ jo
     return true;
 }
 
-__device__ __forceinline__ void push_fallback(const FusedArgs& a, int64_t row, int job) {
-    const int at = atomicAdd(a.fb_count, 1);
-    if (at < a.fb_cap) {
-        a.fb_list[2 * at] = (int32_t)row;
-        a.fb_list[2 * at + 1] = job;
-    }
-}
 
-// LDS per wave while the passes run: histogram [32 queries][256 x u16 (+4 B pad)]; afterwards the member lists
-// [32 queries][2 halves][32] (value f32 + candidate u32, row stride 65 dwords); in phase E the sorted output rows.
-constexpr int kMemHalf = kMemCap / 2;            // members kept per (query, lane half)
-constexpr int kMemSlot = kMemHalf + 1;           // ... plus the dump slot the branch-free append writes to when full
-constexpr int kMemStride = 67;                   // dwords per query row (odd: lane = query accesses are conflict-free)
-constexpr int kKeepHalf = kKeepCap / 2;          // selected window candidates kept per (query, lane half)
-constexpr int kKeepStride = kKeepCap + 1;        // dwords per query row of the kept lists
-static_assert(2 * 32 * kMemStride * 4 <= kWaveHist, "member lists alias the histograms");
-static_assert(4 * 2 * 32 * kKeepStride * 4 <= kKeptBytes + 4096, "kept lists");
-
+// ------------------------------------------------------------------------------------------------------------
+// approx_kernel: workgroup = 4 waves = 128 queries of one bucket; lane (r, h) serves query r of its wave throughout --
+// MFMA results are D[candidate][query] (column = lane & 31), so a lane's 16 accumulator registers hold 16 candidates of
+// ITS query and every per-query structure is lane-private (the two halves of a query keep separate sub-lists)
+// ------------------------------------------------------------------------------------------------------------
 template <int STEPS>
-__global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
-    constexpr int D = STEPS * 16, DH = D / 2, DH4 = D / 8;
+__global__ __launch_bounds__(256, 2) void approx_kernel(FusedArgs a) {
+    constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int RB16 = D / 8;                     // 16-byte pieces per float16 row
     constexpr int RS = D * 2 + 16;                  // LDS row stride (padded: conflict-free b128 reads)
     constexpr int PIECES = 32 * RB16;
     constexpr int kStage = (PIECES + 255) / 256;
-    constexpr int NB = STEPS < 8 ? STEPS : 8;         // LDS operand reads in flight ahead of the MFMAs (8 passes each)
-    constexpr int kStageBytes = region_a_bytes(D);   // staging buffers, later the kept lists
+    constexpr int NB = STEPS < 4 ? STEPS : 4;       // LDS operand reads in flight ahead of the MFMAs (two waves per SIMD)
+    constexpr int kStageBytes = 32 * RS;            // ONE staging buffer: two workgroups share a CU and fill each other's gaps
     static_assert(kStage <= 7, "staging registers");
     extern __shared__ __align__(16) unsigned char lds[];
     int ji, T;
-    if (!find_job_xcd128f(a.jobs, a.n_jobs, blockIdx.x, &ji, &T)) return;
-    const DenseJob job = a.jobs[ji];
+    if (!find_job_xcd128f(a.jobs128, a.n_jobs128, blockIdx.x, &ji, &T)) return;
+    const DenseJob job = a.jobs128[ji];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int nc = job.nc, k = a.k;
     const int64_t row0 = job.q_row0;
     const int tile32 = 4 * T + w;
     const int nqw = min(32, nc - 32 * tile32);      // <= 0: the wave only helps with staging
     const bool active = nqw > 0;
-    const bool need_thr = nc > k;                   // otherwise every candidate is among the k best
     const int qbase = 32 * tile32;                  // first query of this wave inside the bucket
     const int dbg = a.dbg;
-    unsigned long long* stamp = ((dbg & 128) && threadIdx.x == 0) ? a.stamps + (size_t)blockIdx.x * 10 : nullptr;
-#define FAL_STAMP(I) { if (stamp) stamp[I] = __builtin_amdgcn_s_memtime(); }
-    FAL_STAMP(0)
-    if (stamp) { stamp[8] = (unsigned long long)nc; stamp[9] = 0; }
-    // lane (r, h) serves query r of the wave throughout: MFMA results are D[candidate][query] (column = lane & 31),
-    // so its 16 accumulator registers hold 16 candidates of ITS query -- every per-query structure is lane-private
-    // (the two halves of a query keep separate sub-lists), no ballots, no cross-lane traffic in the epilogues
 
-    unsigned char* whist = lds + kStageBytes + w * kWaveHist;                  // histogram / member lists / output rows
+    unsigned char* whist = lds + kStageBytes + w * kWaveHist;                  // histogram, then the member lists
     unsigned char* wsmall = lds + kStageBytes + 4 * kWaveHist + w * kWaveSmall;
     float* q_lo = reinterpret_cast<float*>(wsmall);          // [32] member interval
     float* q_hi = q_lo + 32;
-    float* q_L = q_hi + 32;                                  // [32] exact k-th value lies in [L, U]
-    float* q_U = q_L + 32;
-    float* q_T = q_U + 32;                                   // [32] k-th best approximate value
-    float* q_eps = q_T + 32;
-    int* q_bstar = reinterpret_cast<int*>(q_eps + 32);       // [32]
+    float* q_eps = q_hi + 32;
+    float* q_T = q_eps + 32;                                 // [32] k-th best approximate value
+    int* q_bstar = reinterpret_cast<int*>(q_T + 32);         // [32]
     int* q_nabove = q_bstar + 32;
     int* q_mcnt = q_nabove + 32;                             // [64] members per (query, half)
-    int* q_kcnt = q_mcnt + 64;                               // [64] kept per (query, half)
-    int* q_flag = q_kcnt + 64;                               // [64] bit 0: ambiguous candidate present, bit 1: fallback
-    uint32_t* q_uT = reinterpret_cast<uint32_t*>(q_flag + 64);   // [32] exact k-th key of ambiguous queries
-    uint32_t* q_iT = q_uT + 32;
-    int* e_q = reinterpret_cast<int*>(q_iT + 32);            // [32] the exact chunk of phase D': query, candidate, value
-    int* e_c = e_q + 32;
-    float* e_v = reinterpret_cast<float*>(e_c + 32);
-    static_assert((8 * 32 + 3 * 64 + 2 * 32 + 3 * 32) * 4 <= kWaveSmall, "per-wave scalars");
+    int* q_flag = q_mcnt + 64;                               // [64] bit 1: fallback
+    static_assert((6 * 32 + 2 * 64) * 4 <= kWaveSmall, "per-wave scalars");
     float* mem_v = reinterpret_cast<float*>(whist);                            // [32][kMemStride]: half h at [h * kMemSlot ...)
     uint32_t* mem_id = reinterpret_cast<uint32_t*>(whist + 32 * kMemStride * 4);
-    uint32_t* kept_u = reinterpret_cast<uint32_t*>(lds + w * (2 * 32 * kKeepStride * 4));   // [32][kKeepStride] (after the passes)
-    uint32_t* kept_id = kept_u + 32 * kKeepStride;
-
     q_flag[lane] = 0;
     q_mcnt[lane] = 0;
-    q_kcnt[lane] = 0;
-    if (lane < 32) {
-        q_L[lane] = -INFINITY;
-        q_U[lane] = -INFINITY;
-        q_uT[lane] = 0u;
-        q_iT[lane] = 0xFFFFFFFFu;
-    }
+    if (lane < 32) q_T[lane] = 0.f;
 
-    if (need_thr && !(dbg & 32)) {
-        // ================= approximate passes on the f16 matrix cores ==============================================
-        const __half* X16 = a.X16;
-        half8 q[STEPS];
-        {
-            const int64_t qrow = row0 + (active ? qbase + min(r, nqw - 1) : 0);
-            const half8* src = reinterpret_cast<const half8*>(X16 + qrow * D + h * DH);
+    const __half* X16 = a.X16;
+    half8 q[STEPS];
+    {
+        const int64_t qrow = row0 + (active ? qbase + min(r, nqw - 1) : 0);
+        const half8* src = reinterpret_cast<const half8*>(X16 + qrow * D + h * DH);
 #pragma unroll
-            for (int s = 0; s < STEPS; ++s) q[s] = src[s];
-        }
-        for (int e = lane; e < kWaveHist / 16; e += 64) reinterpret_cast<uint4*>(whist)[e] = make_uint4(0, 0, 0, 0);
-        const __half* cbase = X16 + row0 * (int64_t)D;
-        // candidate chunks travel global -> registers -> LDS two chunks ahead of their use: two register sets
-        uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sb0, sb1, sb2, sb3, sb4, sb5, sb6;
+        for (int s = 0; s < STEPS; ++s) q[s] = src[s];
+    }
+    for (int e = lane; e < kWaveHist / 16; e += 64) reinterpret_cast<uint4*>(whist)[e] = make_uint4(0, 0, 0, 0);
+    const __half* cbase = X16 + row0 * (int64_t)D;
+    // candidate chunks travel global -> registers -> LDS two chunks ahead of their use: two register sets
+    uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sb0, sb1, sb2, sb3, sb4, sb5, sb6;
 #define FAL_FOR_A(M) M(0, sa0) M(1, sa1) M(2, sa2) M(3, sa3) M(4, sa4) M(5, sa5) M(6, sa6)
 #define FAL_FOR_B(M) M(0, sb0) M(1, sb1) M(2, sb2) M(3, sb3) M(4, sb4) M(5, sb5) M(6, sb6)
 #define FAL_LOAD_ONE(I, R)                                                                             \
@@ -233,94 +210,102 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
     }
 #define FAL_LOAD(SET, C0) { const int stage_c0 = min((C0), nc - 1); FAL_FOR_##SET(FAL_LOAD_ONE) }
 #define FAL_STORE(SET, BUF) { const int stage_buf = (BUF); FAL_FOR_##SET(FAL_STORE_ONE) }
-        // One pass over all candidate chunks.  acc = D[candidate][query] of a chunk; its epilogue (16 values per lane)
-        // runs one chunk LATER, spread over the MFMA steps of the next chunk: the matrix pipe holds the issue port for 8 of
-        // its 32 cycles and the branch-free epilogue pieces fill the rest.  piece(i, v, c, valid) consumes value i.
-        constexpr int kPiecesPerStep = (16 + STEPS - 1) / STEPS;
-        auto run_pass = [&](auto&& piece) {
-            __syncthreads();
-            FAL_LOAD(A, 0)
-            FAL_STORE(A, 0)
-            FAL_LOAD(A, 32)
-            FAL_LOAD(B, 64)
-            __syncthreads();
-            f32x16 prev;
+    // One pass over all candidate chunks.  acc = D[candidate][query] of a chunk; its epilogue (16 values per lane)
+    // runs one chunk LATER, spread over the MFMA steps of the next chunk: the matrix pipe holds the issue port for 8 of
+    // its 32 cycles and the branch-free epilogue pieces fill the rest.  piece(i, v, c, valid) consumes value i.
+    constexpr int kPiecesPerStep = (16 + STEPS - 1) / STEPS;
+    auto run_pass = [&](auto&& piece) {
+        __syncthreads();
+        FAL_LOAD(A, 0)
+        FAL_STORE(A, 0)
+        FAL_LOAD(A, 32)
+        FAL_LOAD(B, 64)
+        __syncthreads();
+        f32x16 prev;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) prev[i] = 0.f;
-            int prev_c0 = nc;                                // "no previous chunk": every candidate index is invalid
-            auto chunk = [&](const int bufcur) {
-                const unsigned char* rowp = lds + (size_t)bufcur * 32 * RS + r * RS + h * DH * 2;
-                half8 rh[NB];
+        for (int i = 0; i < 16; ++i) prev[i] = 0.f;
+        int prev_c0 = nc;                                // "no previous chunk": every candidate index is invalid
+        auto chunk = [&]() {
+            const unsigned char* rowp = lds + r * RS + h * DH * 2;
+            half8 rh[NB];
 #pragma unroll
-                for (int s = 0; s < NB; ++s) rh[s] = *reinterpret_cast<const half8*>(rowp + s * 16);
-                // pin the whole operand ring in front of the first MFMA: without this group the scheduler satisfies the
-                // "one read per step" pattern below by issuing the reads one at a time -- each MFMA then waits for an LDS
-                // round trip (measured: 6.4k instead of ~1k cycles per chunk)
-                __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
-                f32x16 acc;
+            for (int s = 0; s < NB; ++s) rh[s] = *reinterpret_cast<const half8*>(rowp + s * 16);
+            // pin the whole operand ring in front of the first MFMA: without this group the scheduler satisfies the
+            // "one read per step" pattern below by issuing the reads one at a time and every MFMA waits for an LDS
+            // round trip
+            __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
+            f32x16 acc;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-                for (int s = 0; s < STEPS; ++s) {
-                    const half8 ch = rh[s % NB];
-                    if (s + NB < STEPS) rh[s % NB] = *reinterpret_cast<const half8*>(rowp + (s + NB) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, q[s], acc, 0, 0, 0);
+            for (int s = 0; s < STEPS; ++s) {
+                const half8 ch = rh[s % NB];
+                if (s + NB < STEPS) rh[s % NB] = *reinterpret_cast<const half8*>(rowp + (s + NB) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, q[s], acc, 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < kPiecesPerStep; ++t) {
-                        const int i = s * kPiecesPerStep + t;
-                        if (i < 16) {
-                            const int c = prev_c0 + rowoff16(i) + 4 * h;
-                            piece(i, fmaxf(prev[i], 0.f), c, c < nc);
-                        }
+                for (int t = 0; t < kPiecesPerStep; ++t) {
+                    const int i = s * kPiecesPerStep + t;
+                    if (i < 16) {
+                        const int c = prev_c0 + rowoff16(i) + 4 * h;
+                        piece(i, fmaxf(prev[i], 0.f), c, c < nc);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // this step's MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // the operand read for step s + NB
-                    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);    // a piece of the previous chunk's epilogue
-                    __builtin_amdgcn_sched_group_barrier(0x200, 2 * kPiecesPerStep, 0);
                 }
-                return acc;
-            };
-            for (int cc0 = 0; cc0 < nc; cc0 += 64) {
-                {
-                    const f32x16 acc = chunk(0);
-                    prev = acc;
-                    prev_c0 = cc0;
-                    FAL_STORE(A, 1)                          // set A holds chunk cc0 + 32 ...
-                    FAL_LOAD(A, cc0 + 96)                    // ... and now fetches chunk cc0 + 96
-                    __syncthreads();
-                }
-                if (cc0 + 32 >= nc) break;
-                {
-                    const f32x16 acc = chunk(1);
-                    prev = acc;
-                    prev_c0 = cc0 + 32;
-                    FAL_STORE(B, 0)
-                    FAL_LOAD(B, cc0 + 128)
-                    __syncthreads();
-                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // this step's MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // the operand read for step s + NB
+                __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);    // a piece of the previous chunk's epilogue
+                __builtin_amdgcn_sched_group_barrier(0x200, 2 * kPiecesPerStep, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {                   // the last chunk's epilogue
-                const int c = prev_c0 + rowoff16(i) + 4 * h;
-                piece(i, fmaxf(prev[i], 0.f), c, c < nc);
-            }
+            return acc;
         };
+        // chunk cc0 is in LDS, register set A holds cc0 + 32, B holds cc0 + 64 (two chunks of loads in flight)
+        for (int cc0 = 0; cc0 < nc; cc0 += 64) {
+            {
+                const f32x16 acc = chunk();
+                prev = acc;
+                prev_c0 = cc0;
+                __syncthreads();                         // every wave is done reading the buffer
+                FAL_STORE(A, 0)
+                FAL_LOAD(A, cc0 + 96)
+                __syncthreads();
+            }
+            if (cc0 + 32 >= nc) break;
+            {
+                const f32x16 acc = chunk();
+                prev = acc;
+                prev_c0 = cc0 + 32;
+                __syncthreads();
+                FAL_STORE(B, 0)
+                FAL_LOAD(B, cc0 + 128)
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                   // the last chunk's epilogue
+            const int c = prev_c0 + rowoff16(i) + 4 * h;
+            piece(i, fmaxf(prev[i], 0.f), c, c < nc);
+        }
+    };
 
-        // ---- pass 1: histogram of the approximate similarities (bin = floor(256 v), 255 = everything above) ----
-        unsigned char* hrow_b = whist + r * kHistStride;
-        run_pass([&](int, float v, int, bool valid) {
-            const uint32_t b = min(255u, (uint32_t)(v * 256.f));
-            const uint32_t inc = (b & 1) ? 0x10000u : 1u;
-            atomicAdd(reinterpret_cast<unsigned*>(hrow_b + ((b >> 1) << 2)), (valid && !(dbg & 1)) ? inc : 0u);
-        });
-        FAL_STAMP(1)
-        // ---- the bin of the k-th best approximate value: suffix sums from the top, lane = query ------------------
-        {
-            const unsigned* hrow = reinterpret_cast<const unsigned*>(whist + r * kHistStride);
-            int cum = 0, bstar = -1, nabove = 0;
-            for (int j = 127; j >= 0; --j) {
-                const unsigned wv = hrow[j];
-                const int chi = (int)(wv >> 16), clo = (int)(wv & 0xFFFFu);
+    // ---- pass 1: histogram of the approximate similarities ---------------------------------------------------------
+    unsigned char* hrow_b = whist + r * kHistStride;
+    if (!(dbg & 256)) run_pass([&](int, float v, int, bool valid) {
+        const uint32_t b = bin_of(v);
+        const uint32_t inc = (b & 1) ? 0x10000u : 1u;
+        atomicAdd(reinterpret_cast<unsigned*>(hrow_b + ((b >> 1) << 2)), (valid && !(dbg & 1)) ? inc : 0u);
+    });
+    // ---- the bin of the k-th best approximate value: suffix sums from the top, lane = query (reads in batches of 8:
+    //      one wave per SIMD, every dependent LDS round trip is exposed) ------------------------------------------------
+    {
+        const unsigned* hrow = reinterpret_cast<const unsigned*>(whist + r * kHistStride);
+        int cum = 0, bstar = -1, nabove = 0;
+        for (int j0 = kBins / 2 - 1; j0 >= 0; j0 -= 8) {
+            unsigned wv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) wv[t] = hrow[j0 - t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = j0 - t;
+                const int chi = (int)(wv[t] >> 16), clo = (int)(wv[t] & 0xFFFFu);
                 if (bstar < 0) {
                     if (cum + chi >= k) {
                         bstar = 2 * j + 1;
@@ -331,338 +316,362 @@ __global__ __launch_bounds__(256, 1) void fused_kernel(FusedArgs a) {
                     }
                     cum += chi + clo;
                 }
-                if (__ballot(bstar < 0) == 0ull) break;
-            }
-            if (bstar < 0) bstar = 0;                       // (cannot happen: the row holds nc > k values)
-            const float binlo = (float)bstar * (1.f / 256.f);
-            const float binhi = bstar == 255 ? 1.0625f : (float)(bstar + 1) * (1.f / 256.f);
-            const float e0 = kEpsRel * binhi + kEpsAbs;
-            const float m = 2.5f * e0;
-            if (lane < 32) {
-                q_lo[r] = binlo - m;
-                q_hi[r] = bstar == 255 ? INFINITY : binhi + m;
-                q_eps[r] = kEpsRel * (binhi + m) + kEpsAbs;  // bounds |approx - exact| of every value <= binhi + m
-                q_bstar[r] = bstar;
-                q_nabove[r] = nabove;
             }
         }
-        __syncthreads();
-        FAL_STAMP(2)
-        // ---- pass 2: the members of the (widened) threshold bin -> lane-private LDS lists (the histograms' memory).
-        //      Branch-free: every value is written at the list's end, the end only advances on a hit (slot kMemHalf
-        //      is the dump slot of a full list) -------------------------------------------------------------------------
-        {
-            const float lo_q = q_lo[r], hi_q = q_hi[r];
-            int cnt = 0;
-            float* mv = mem_v + r * kMemStride + h * kMemSlot;
-            uint32_t* mi = mem_id + r * kMemStride + h * kMemSlot;
-            run_pass([&](int, float v, int c, bool valid) {
-                const bool hit = valid && v >= lo_q && v <= hi_q && !(dbg & 2);
-                const int at = min(cnt, kMemHalf);
-                mv[at] = v;
-                mi[at] = (uint32_t)c;
-                cnt += hit ? 1 : 0;
-            });
-            q_mcnt[r * 2 + h] = cnt;
+        if (bstar < 0) bstar = 0;                           // (cannot happen: the row holds nc > k values)
+        const float binlo = bin_lo(bstar), binhi = bin_hi(bstar);
+        const float e0 = kEpsRel * binhi + kEpsAbs;
+        const float m = 2.5f * e0;
+        if (lane < 32) {
+            q_lo[r] = binlo - m;
+            q_hi[r] = bstar == kBins - 1 ? INFINITY : binhi + m;
+            q_eps[r] = kEpsRel * (binhi + m) + kEpsAbs;      // bounds |approx - exact| of every value <= binhi + m
+            q_bstar[r] = bstar;
+            q_nabove[r] = nabove;
         }
-#undef FAL_PASS
-#undef FAL_CHUNK
+    }
+    __syncthreads();
+    // ---- pass 2: the members of the (widened) threshold bin -> lane-private LDS lists (the histograms' memory).
+    //      Branch-free: every value is written at the list's end, the end only advances on a hit (slot kMemHalf
+    //      is the dump slot of a full list) -----------------------------------------------------------------------------
+    {
+        const float lo_q = q_lo[r], hi_q = q_hi[r];
+        int cnt = 0;
+        float* mv = mem_v + r * kMemStride + h * kMemSlot;
+        uint32_t* mi = mem_id + r * kMemStride + h * kMemSlot;
+        if (!(dbg & 512)) run_pass([&](int, float v, int c, bool valid) {
+            const bool hit = valid && v >= lo_q && v <= hi_q && !(dbg & 2);
+            const int at = min(cnt, kMemHalf);
+            mv[at] = v;
+            mi[at] = (uint32_t)c;
+            cnt += hit ? 1 : 0;
+        });
+        q_mcnt[r * 2 + h] = cnt;
+    }
 #undef FAL_LOAD
 #undef FAL_STORE
 #undef FAL_LOAD_ONE
 #undef FAL_STORE_ONE
 #undef FAL_FOR_A
 #undef FAL_FOR_B
-        __syncthreads();
-        FAL_STAMP(3)
-        // ---- T~ = the (k - n_above)-th best approximate value inside bin b*: lane (r, h) tries the members of ITS half as
-        //      pivots and ranks each against all members of the query; exact k-th value in [T~ - eps, T~ + eps] -------------
-        if (!(dbg & 4)) {
-            const int m0 = q_mcnt[r * 2], m1 = q_mcnt[r * 2 + 1];
-            const int bstar = q_bstar[r], need = k - q_nabove[r];
-            const float* mvq = mem_v + r * kMemStride;
-            bool found = false;
-            if (m0 > kMemHalf || m1 > kMemHalf || need < 1) {
-                q_flag[r * 2 + h] = 2;                       // too many values share the bin: exact fallback
-            } else {
-                const int mine = h ? m1 : m0;
-                for (int e = 0; e < mine; ++e) {
-                    const float ve = mvq[h * kMemSlot + e];
-                    if ((int)min(255u, (uint32_t)(ve * 256.f)) != bstar) continue;
-                    int better = 0;                          // in-bin members with a larger value (ties: lower slot first)
-                    for (int j = 0; j < m0; ++j) {
-                        const float vj = mvq[j];
-                        const bool inb = (int)min(255u, (uint32_t)(vj * 256.f)) == bstar;
-                        better += (inb && (vj > ve || (vj == ve && (h == 1 || j < e)))) ? 1 : 0;
-                    }
-                    for (int j = 0; j < m1; ++j) {
-                        const float vj = mvq[kMemSlot + j];
-                        const bool inb = (int)min(255u, (uint32_t)(vj * 256.f)) == bstar;
-                        better += (inb && (vj > ve || (vj == ve && h == 1 && j < e))) ? 1 : 0;
-                    }
-                    if (better == need - 1) {
-                        const float eq = q_eps[r];
-                        q_T[r] = ve;
-                        q_L[r] = ve - eq;
-                        q_U[r] = ve + eq;
-                        found = true;
+    __syncthreads();
+    // ---- T~ = the (k - n_above)-th best approximate value inside bin b*: lane (r, h) tries the members of ITS half as
+    //      pivots and ranks each against all members of the query (a handful); exact k-th value in [T~ - eps, T~ + eps] ----
+    if (!(dbg & 4)) {
+        const int m0 = q_mcnt[r * 2], m1 = q_mcnt[r * 2 + 1];
+        const int bstar = q_bstar[r], need = k - q_nabove[r];
+        const float bhi = bin_hi(bstar);
+        const float* mvq = mem_v + r * kMemStride;
+        bool found = false;
+        if (m0 > kMemHalf || m1 > kMemHalf || need < 1) {
+            q_flag[r * 2 + h] = 2;                           // too many values share the bin: exact fallback
+        } else {
+            const int mine = h ? m1 : m0;
+            // members with value >= bhi lie above the bin (margin): they count in n_above, not here
+            auto better_cnt = [&](const float ve, const int e) -> int {
+                int better = 0;                              // in-bin members with a larger value (ties: half 0 first, lower slot first)
+                for (int j0 = 0; j0 < m0; j0 += 8) {
+                    float vj[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) vj[t] = mvq[min(j0 + t, kMemHalf)];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int j = j0 + t;
+                        const bool inb = j < m0 && bin_of(vj[t]) == (uint32_t)bstar;
+                        better += (inb && (vj[t] > ve || (vj[t] == ve && (h == 1 || j < e)))) ? 1 : 0;
                     }
                 }
+                for (int j0 = 0; j0 < m1; j0 += 8) {
+                    float vj[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) vj[t] = mvq[kMemSlot + min(j0 + t, kMemHalf)];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int j = j0 + t;
+                        const bool inb = j < m1 && bin_of(vj[t]) == (uint32_t)bstar;
+                        better += (inb && (vj[t] > ve || (vj[t] == ve && h == 1 && j < e))) ? 1 : 0;
+                    }
+                }
+                return better;
+            };
+            (void)bhi;
+            for (int e = 0; e < mine; ++e) {
+                const float ve = mvq[h * kMemSlot + e];
+                if (bin_of(ve) != (uint32_t)bstar) continue;
+                if (better_cnt(ve, e) == need - 1) {
+                    q_T[r] = ve;
+                    found = true;
+                }
             }
-            // exactly one half finds the pivot; if neither does the lists are incomplete (defensive): fallback
-            const unsigned long long fm = __ballot(found);
-            const bool any = ((fm >> r) & 1ull) || ((fm >> (r + 32)) & 1ull);
-            if (!any) q_flag[r * 2 + h] = 2;
+        }
+        // exactly one half finds the pivot; if neither does the lists are incomplete (defensive): fallback
+        const unsigned long long fm = __ballot(found);
+        const bool any = ((fm >> r) & 1ull) || ((fm >> (r + 32)) & 1ull);
+        if (!any) q_flag[r * 2 + h] = 2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- hand-off: thresholds and member lists of the wave's queries --------------------------------------------------
+    if (!active) return;
+    if (lane < nqw) {
+        QThr t;
+        const float Tv = q_T[lane], e = q_eps[lane];
+        t.L = Tv - e;
+        t.U = Tv + e;
+        t.T = Tv;
+        t.eps = e;
+        t.bstar = q_bstar[lane];
+        t.nabove = q_nabove[lane];
+        t.mc = min(q_mcnt[lane * 2], kMemHalf) | (min(q_mcnt[lane * 2 + 1], kMemHalf) << 16);
+        t.flags = (q_flag[lane * 2] | q_flag[lane * 2 + 1]) & 2;
+        a.thr[row0 + qbase + lane] = t;
+    }
+    {
+        float* gv = a.gmem_v + (row0 + qbase) * (int64_t)FAL_FUSED_MEM;
+        uint32_t* gi = a.gmem_id + (row0 + qbase) * (int64_t)FAL_FUSED_MEM;
+        for (int e = lane; e < nqw * FAL_FUSED_MEM; e += 64) {
+            const int qq = e / FAL_FUSED_MEM, slot = e % FAL_FUSED_MEM;
+            const int src = qq * kMemStride + (slot < kMemHalf ? slot : kMemSlot + slot - kMemHalf);
+            gv[e] = mem_v[src];
+            gi[e] = mem_id[src];
         }
     }
-    __syncthreads();                 // the staging buffers become the kept lists; the per-query scalars are final
-    FAL_STAMP(4)
+}
 
-    // ================= exact similarities of the precursor window on the fp32 matrix cores ============================
+// ------------------------------------------------------------------------------------------------------------
+// band_kernel: one wave = 32 queries of one bucket; exact similarities of the precursor window on the fp32 matrix cores
+// ------------------------------------------------------------------------------------------------------------
+template <int DH4>
+__global__ __launch_bounds__(64, 1) void band_kernel(FusedArgs a) {
+    constexpr int D = DH4 * 8, DH = D / 2;
+    constexpr int kStride = FAL_FUSED_KEEP + 1;               // dwords per query row of the kept lists (odd: conflict-free)
+    __shared__ uint32_t kept_u[32 * kStride];
+    __shared__ uint32_t kept_id[32 * kStride];
+    int ji, lt;
+    if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
+    const DenseJob job = a.jobs32[ji];
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int nc = job.nc;
+    const int64_t row0 = job.q_row0;
+    const int qbase = 32 * lt;
+    const int nqw = min(32, nc - qbase);
+    const bool need_thr = nc > a.k;
     const int dh4 = DH4;
-    if (active) {
-        const float* X = a.X;
-        float qf[DH4 * 4];
-        load_half_row<DH4>(qf, X + (row0 + qbase + min(r, nqw - 1)) * D + (int64_t)h * DH, dh4);
-        const float* pm = a.pmz + row0;
-        const float* rtp = a.rt ? a.rt + row0 : nullptr;
-        const bool use_rt = rtp != nullptr && a.rt_tol >= 0.0;
-        // candidate range that can pass the tolerance for ANY query of the tile (slightly widened; the exact test
-        // decides below): rows are sorted by precursor m/z
-        int wlo, whi;
-        {
-            const double qf_first = (double)pm[qbase], qf_last = (double)pm[qbase + nqw - 1];
-            double lob, hib;
-            if (a.is_da) {
-                lob = qf_first - a.tol - 1e-3;
-                hib = qf_last + a.tol + 1e-3;
-            } else {
-                const double t = a.tol * 1e-6;
-                lob = qf_first * (1.0 - 1.01 * t - 2e-6);
-                hib = t < 0.5 ? qf_last * (1.0 + 1.01 * t / (1.0 - t) + 2e-6) : INFINITY;
-            }
-            int lo = 0, hi = nc;                             // first c with pm[c] >= lob
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((double)pm[mid] < lob) lo = mid + 1; else hi = mid;
-            }
-            wlo = lo;
-            lo = wlo;
-            hi = nc;                                         // first c with pm[c] > hib
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((double)pm[mid] <= hib) lo = mid + 1; else hi = mid;
-            }
-            whi = lo;
+    const float* X = a.X;
+    float qf[DH4 * 4];
+    load_half_row<DH4>(qf, X + (row0 + qbase + min(r, nqw - 1)) * D + (int64_t)h * DH, dh4);
+    const float* pm = a.pmz + row0;
+    const float* rtp = a.rt ? a.rt + row0 : nullptr;
+    const bool use_rt = rtp != nullptr && a.rt_tol >= 0.0;
+    // candidate range that can pass the tolerance for ANY query of the tile (slightly widened; the exact test decides
+    // below): rows are sorted by precursor m/z
+    int wlo, whi;
+    {
+        const double qf_first = (double)pm[qbase], qf_last = (double)pm[qbase + nqw - 1];
+        double lob, hib;
+        if (a.is_da) {
+            lob = qf_first - a.tol - 1e-3;
+            hib = qf_last + a.tol + 1e-3;
+        } else {
+            const double t = a.tol * 1e-6;
+            lob = qf_first * (1.0 - 1.01 * t - 2e-6);
+            hib = t < 0.5 ? qf_last * (1.0 + 1.01 * t / (1.0 - t) + 2e-6) : INFINITY;
         }
-        const int ql = r;
-        const bool qvalid = ql < nqw;
-        const float qmz = pm[qbase + min(ql, nqw - 1)];
-        const float qrt = use_rt ? rtp[qbase + min(ql, nqw - 1)] : 0.f;
-        const float Lq = q_L[ql], Uq = q_U[ql];
-        int kc = 0;
-        bool amb_any = false;
-        uint32_t* ku = kept_u + ql * kKeepStride + h * kKeepHalf;
-        uint32_t* kid = kept_id + ql * kKeepStride + h * kKeepHalf;
-        const int n_chunks = (dbg & 8) ? 0 : (whi - wlo + 31) >> 5;
-        CandStream<DH4> cs;
-        auto crow = [&](int c0) -> const float* { return X + (row0 + min(c0 + r, nc - 1)) * D + (int64_t)h * DH; };
-        const float* cur = crow(wlo);
-        cs.prime(cur, dh4);
-        for (int ci = 0, c0 = wlo; ci < n_chunks; ++ci, c0 += 32) {
-            const float* nxt = crow(c0 + 32);
-            // candidate metadata of this lane's 16 rows: issued before the MFMA chain, used after it
-            float nmz[16], nrt[16];
+        // rows are sorted: scan outwards from the tile 64 rows at a time (one load + ballot per step, typically one step)
+        // instead of a binary search whose every probe is a dependent global round trip
+        wlo = qbase;
+        for (;;) {
+            const int c = wlo - 1 - lane;
+            const bool in = c >= 0 && (double)pm[max(c, 0)] >= lob;
+            const int cnt = __popcll(__ballot(in));          // sorted => the lanes that pass are a prefix
+            wlo -= cnt;
+            if (cnt < 64) break;
+        }
+        whi = qbase + nqw;
+        for (;;) {
+            const int c = whi + lane;
+            const bool in = c < nc && (double)pm[min(c, nc - 1)] <= hib;
+            const int cnt = __popcll(__ballot(in));
+            whi += cnt;
+            if (cnt < 64) break;
+        }
+    }
+    const int ql = r;
+    const bool qvalid = ql < nqw;
+    const int64_t qrow = row0 + qbase + min(ql, nqw - 1);
+    const float qmz = pm[qbase + min(ql, nqw - 1)];
+    const float qrt = use_rt ? rtp[qbase + min(ql, nqw - 1)] : 0.f;
+    float Lq = -INFINITY, Uq = -INFINITY;
+    if (need_thr) {
+        const QThr t = a.thr[qrow];
+        Lq = t.L;
+        Uq = t.U;
+    }
+    // the tolerance tests in float32: |x| <= tol_f is EXACTLY fabs((double)x * scale) <= tol of filter_kernel (tol_f is the
+    // largest float32 for which the float64 form holds; the product with a positive constant is monotone)
+    const float tol_f = a.tol_f, rt_f = a.rt_f;
+    int kc = 0;
+    bool amb_any = false;
+    uint32_t* ku = kept_u + ql * kStride + h * kKeepHalf;
+    uint32_t* kid = kept_id + ql * kStride + h * kKeepHalf;
+    const int n_chunks = (whi - wlo + 31) >> 5;
+    CandStream<DH4> cs;
+    auto crow = [&](int c0) -> const float* { return X + (row0 + min(c0 + r, nc - 1)) * D + (int64_t)h * DH; };
+    const float* cur = crow(wlo);
+    cs.prime(cur, dh4);
+    for (int ci = 0, c0 = wlo; ci < n_chunks; ++ci, c0 += 32) {
+        const float* nxt = crow(c0 + 32);
+        // candidate metadata of this lane's 16 rows: issued before the MFMA chain, used after it
+        float nmz[16], nrt[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int cc = min(c0 + rowoff16(i) + 4 * h, nc - 1);
-                nmz[i] = pm[cc];
-                nrt[i] = use_rt ? rtp[cc] : 0.f;
-            }
-            const f32x16 acc = cs.template dot<false>(qf, cur, nxt, dh4, [] {});
-            cur = nxt;
+        for (int i = 0; i < 16; ++i) {
+            const int cc = min(c0 + rowoff16(i) + 4 * h, nc - 1);
+            nmz[i] = pm[cc];
+            nrt[i] = use_rt ? rtp[cc] : 0.f;
+        }
+        const f32x16 acc = cs.template dot<false>(qf, cur, nxt, dh4, [] {});
+        cur = nxt;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = c0 + rowoff16(i) + 4 * h;
-                const float s = acc[i];
-                const float diff = qmz - nmz[i];             // mass_diff(query, neighbour): the arithmetic of filter_kernel
-                const double md = a.is_da ? (double)diff : (double)(diff / nmz[i]) * 1e6;
-                bool ok = fabs(md) <= a.tol;
-                if (use_rt) ok = ok && fabs((double)(qrt - nrt[i])) <= a.rt_tol;
-                ok = ok && c < whi && qvalid && c != qbase + ql;
-                if (ok && s >= Lq) {                         // below L: certainly not among the k best
-                    const bool amb = s <= Uq;                // inside [L, U]: decided exactly in phase E
-                    if (kc < kKeepHalf) {
-                        ku[kc] = max(f32_sortable(s), 1u);
-                        kid[kc] = (uint32_t)(row0 + c) | (amb ? 0x80000000u : 0u);
-                    }
-                    ++kc;
-                    amb_any = amb_any || amb;
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + rowoff16(i) + 4 * h;
+            const float s = acc[i];
+            const float diff = qmz - nmz[i];                 // mass_diff(query, neighbour): the arithmetic of filter_kernel
+            const float x = a.is_da ? diff : diff / nmz[i];
+            bool ok = fabsf(x) <= tol_f;
+            if (use_rt) ok = ok && fabsf(qrt - nrt[i]) <= rt_f;
+            ok = ok && c < whi && qvalid && c != qbase + ql;
+            if (ok && s >= Lq) {                             // below L: certainly not among the k best
+                const bool amb = s <= Uq;                    // inside [L, U]: decided exactly by resolve_kernel
+                if (kc < kKeepHalf) {
+                    ku[kc] = max(f32_sortable(s), 1u);
+                    kid[kc] = (uint32_t)(row0 + c) | (amb ? 0x80000000u : 0u);
                 }
+                ++kc;
+                amb_any = amb_any || amb;
             }
         }
-        FAL_STAMP(5)
-        if (stamp) stamp[9] = (unsigned long long)n_chunks;
-        q_kcnt[ql * 2 + h] = kc;
-        if (amb_any) q_flag[ql * 2 + h] |= 1;
-        if (kc > kKeepHalf) q_flag[ql * 2 + h] |= 2;
+    }
+    if (qvalid) a.gkcnt[(row0 + qbase + ql) * 2 + h] = min(kc, kKeepHalf) | (amb_any ? 0x100 : 0) | (kc > kKeepHalf ? 0x200 : 0);
+    __syncthreads();
+    {
+        uint32_t* gu = a.gkept_u + (row0 + qbase) * (int64_t)FAL_FUSED_KEEP;
+        uint32_t* gi = a.gkept_id + (row0 + qbase) * (int64_t)FAL_FUSED_KEEP;
+        for (int e = lane; e < nqw * FAL_FUSED_KEEP; e += 64) {
+            const int qq = e / FAL_FUSED_KEEP, slot = e % FAL_FUSED_KEEP;
+            gu[e] = kept_u[qq * kStride + slot];
+            gi[e] = kept_id[qq * kStride + slot];
+        }
+    }
+}
+
+__device__ __forceinline__ void push_fallback(const FusedArgs& a, int64_t row, int job) {
+    const int at = atomicAdd(a.fb_count, 1);
+    if (at < a.fb_cap) {
+        a.fb_list[2 * at] = (int32_t)row;
+        a.fb_list[2 * at + 1] = job;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// resolve_kernel: one wave per query (4 per workgroup, 8 queries each per 32-query tile): ambiguous candidates against
+// the exact k-th key, sort, neighbour lists
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void resolve_kernel(FusedArgs a, int d) {
+    __shared__ uint32_t s_u_all[4 * 64];
+    __shared__ uint32_t s_lo_all[4 * 64];
+    int ji, lt;
+    if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
+    const DenseJob job = a.jobs32[ji];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* s_u = s_u_all + 64 * w;
+    uint32_t* s_lo = s_lo_all + 64 * w;
+    const int nc = job.nc, k = a.k;
+    const int64_t row0 = job.q_row0;
+    const int nqw = min(32, nc - 32 * lt);
+    const bool need_thr = nc > k;
+    for (int ql = w; ql < nqw; ql += 4) {
+        const int64_t row = row0 + 32 * lt + ql;
+        // every load of the common path is issued before the first use (one memory round trip, not four)
+        const int i0 = a.gkcnt[row * 2], i1 = a.gkcnt[row * 2 + 1];
+        const uint32_t ku_l = a.gkept_u[row * FAL_FUSED_KEEP + lane];
+        const uint32_t ki_l = a.gkept_id[row * FAL_FUSED_KEEP + lane];
+        QThr t{};
+        if (need_thr) t = a.thr[row];
+        const int k0 = i0 & 0xFF, k1 = i1 & 0xFF;
+        bool fb = ((i0 | i1) & 0x200) != 0;
+        const bool amb = ((i0 | i1) & 0x100) != 0;
+        int why = fb ? 2 : 0;                                // (reason counters of the fallback list: fb_count[1..3])
+        if (need_thr) {
+            if (!fb && (t.flags & 2)) why = 1;
+            fb = fb || (t.flags & 2);
+        }
+        uint32_t uT = 0, iT = 0xFFFFFFFFu;                  // exact k-th key (only when an ambiguous candidate exists)
+        if (!fb && amb) {
+            const int m0 = t.mc & 0xFFFF, m1 = t.mc >> 16;
+            const bool have = lane < kMemHalf ? lane < m0 : (lane - kMemHalf) < m1;
+            const float v = have ? a.gmem_v[row * FAL_FUSED_MEM + lane] : 0.f;
+            const uint32_t mid = have ? a.gmem_id[row * FAL_FUSED_MEM + lane] : 0u;
+            const bool inE = have && fabsf(v - t.T) <= 2.f * t.eps;
+            const int n_bin_above = __popcll(__ballot(have && (int)bin_of(v) > t.bstar));
+            const int n_hi = __popcll(__ballot(have && v > t.T + 2.f * t.eps));
+            const int need = k - (t.nabove - n_bin_above + n_hi);       // rank of the k-th key among the members of E
+            const unsigned long long em = __ballot(inE);
+            if (need < 1 || need > __popcll(em)) {
+                fb = true;
+                why = 3;
+            } else {
+                float s = 0.f;
+                if (inE) s = exact_dot(a.X + row * d, a.X + (row0 + mid) * d, d);
+                const uint32_t u = inE ? max(f32_sortable(s), 1u) : 0u;
+                const uint32_t id = (uint32_t)(row0 + mid);
+                int rank = 0;                                // members of E with a better key
+                unsigned long long rest = em;
+                while (rest) {
+                    const int j = __ffsll((unsigned long long)rest) - 1;
+                    rest &= rest - 1;
+                    const uint32_t uj = (uint32_t)__shfl((int)u, j, 64), idj = (uint32_t)__shfl((int)id, j, 64);
+                    if (uj > u || (uj == u && idj < id)) ++rank;
+                }
+                const unsigned long long pick = __ballot(inE && rank == need - 1);
+                const int src = __ffsll((unsigned long long)pick) - 1;
+                uT = (uint32_t)__shfl((int)u, src, 64);
+                iT = (uint32_t)__shfl((int)id, src, 64);
+            }
+        }
+        if (fb) {
+            if (lane == 0) {
+                push_fallback(a, row, ji);
+                atomicAdd(a.fb_count + why, 1);
+            }
+            continue;
+        }
+        // the kept candidates of the two lane halves, ambiguous ones against the exact k-th key; sort; store
+        bool keepit = false;
+        uint32_t u = 0, id = 0;
+        const int half = lane >= kKeepHalf, idx = lane - half * kKeepHalf;
+        if (lane < FAL_FUSED_KEEP && idx < (half ? k1 : k0)) {
+            u = ku_l;
+            id = ki_l;
+            keepit = true;
+            if (id & 0x80000000u) {
+                id &= 0x7FFFFFFFu;
+                keepit = u > uT || (u == uT && id <= iT);
+            }
+        }
+        const unsigned long long km = __ballot(keepit);
+        if (keepit) {
+            const int at = __popcll(km & ((1ull << lane) - 1ull));
+            s_u[at] = u;
+            s_lo[at] = ~id;
+        }
+        const int c = __popcll(km);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-
-        // ---- ambiguous candidates (exact similarity inside [L, U]): the exact k-th key of their queries.  The members
-        //      within 2 eps of T~ of ALL ambiguous queries of the wave (a few per query) form ONE more chunk for the fp32
-        //      matrix cores -- gathered rows, the same fmaf chain -- instead of latency-bound scalar chains -------------
-        if (need_thr && !(dbg & 16)) {
-            int fq = q_flag[r * 2] | q_flag[r * 2 + 1];
-            bool amb_q = (fq & 1) && !(fq & 2) && qvalid;
-            const int mcnt = min(q_mcnt[r * 2 + h], kMemHalf);
-            const float Tq = q_T[r], e2 = 2.f * q_eps[r];
-            const float* mvh = mem_v + r * kMemStride + h * kMemSlot;
-            const uint32_t* mih = mem_id + r * kMemStride + h * kMemSlot;
-            int total = 0;
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            for (int j = 0; j < kMemHalf; ++j) {
-                const bool live = amb_q && j < mcnt;
-                if (__ballot(live) == 0ull) break;
-                const bool pred = live && fabsf(mvh[j] - Tq) <= e2;
-                const unsigned long long mk = __ballot(pred);
-                if (mk) {
-                    const int pos = total + __popcll(mk & lt);
-                    if (pred && pos < 32) {
-                        e_q[pos] = r;
-                        e_c[pos] = (int)mih[j];
-                    }
-                    total += __popcll(mk);
-                }
-            }
-            if (total > 32) {                                // more pairs than one chunk holds (rare): exact fallback
-                if (amb_q) q_flag[r * 2 + h] |= 2;
-                amb_q = false;
-                total = 0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            if (total > 0) {                                 // wave-uniform
-                const float* er = X + (row0 + e_c[min(r, total - 1)]) * D + (int64_t)h * DH;
-                cs.prime(er, dh4);
-                const f32x16 acc = cs.template dot<false>(qf, er, er, dh4, [] {});
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int slot = rowoff16(i) + 4 * h;
-                    if (slot < total && e_q[slot] == r) e_v[slot] = acc[i];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                unsigned long long todo = __ballot(lane < 32 && amb_q);
-                while (todo) {
-                    const int qa = __ffsll((unsigned long long)todo) - 1;
-                    todo &= todo - 1;
-                    const int m0 = min(q_mcnt[qa * 2], kMemHalf), m1 = min(q_mcnt[qa * 2 + 1], kMemHalf);
-                    const float Tv = q_T[qa], ee = q_eps[qa];
-                    const int bstar = q_bstar[qa];
-                    // lanes 0..31 = member slots of half 0, lanes 32..63 = half 1: counts certainly above the k-th value
-                    const bool have = lane < 32 ? lane < m0 : (lane - 32) < m1;
-                    const float v = have ? mem_v[qa * kMemStride + (lane < 32 ? lane : kMemSlot + lane - 32)] : 0.f;
-                    const int n_bin_above = __popcll(__ballot(have && (int)min(255u, (uint32_t)(v * 256.f)) > bstar));
-                    const int n_hi = __popcll(__ballot(have && v > Tv + 2.f * ee));
-                    const int need = k - (q_nabove[qa] - n_bin_above + n_hi);
-                    // lanes 0..31 = slots of the exact chunk
-                    const bool mine = lane < total && e_q[lane & 31] == qa;
-                    const unsigned long long em = __ballot(mine);
-                    if (need < 1 || need > __popcll(em)) {
-                        if (lane == 0) q_flag[qa * 2] |= 2;
-                        continue;
-                    }
-                    const uint32_t u = mine ? max(f32_sortable(e_v[lane & 31]), 1u) : 0u;
-                    const uint32_t id = (uint32_t)(row0 + e_c[lane & 31]);
-                    int rank = 0;                            // pairs of this query with a better key
-                    unsigned long long rest = em;
-                    while (rest) {
-                        const int j = __ffsll((unsigned long long)rest) - 1;
-                        rest &= rest - 1;
-                        const uint32_t uj = (uint32_t)__shfl((int)u, j, 64), idj = (uint32_t)__shfl((int)id, j, 64);
-                        if (uj > u || (uj == u && idj < id)) ++rank;
-                    }
-                    const unsigned long long pick = __ballot(mine && rank == need - 1);
-                    const int src = __ffsll((unsigned long long)pick) - 1;
-                    const uint32_t uT = (uint32_t)__shfl((int)u, src, 64), iT = (uint32_t)__shfl((int)id, src, 64);
-                    if (lane == 0) {
-                        q_uT[qa] = uT;
-                        q_iT[qa] = iT;
-                    }
-                }
-            }
-        }
+        if (a.nb_count && lane == 0) a.nb_count[row] = min(c, a.keep);
+        sort_and_store_nb<1>(s_u, s_lo, c, a.keep, lane, a.nb_idx + row * a.keep, a.nb_dist + row * a.keep);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
-    FAL_STAMP(6)
-    if (!active || (dbg & 16)) return;
-
-    // ================= rank the selected candidates of every query (lane-private), stage the rows, write them ============
-    const int keep = a.keep;
-    const int scols = min(keep, 64);                         // staged columns (the kept lists hold <= 48 entries)
-    uint32_t* out_i = reinterpret_cast<uint32_t*>(whist);    // [32][scols] ids, then [32][scols] distances
-    float* out_d = reinterpret_cast<float*>(whist) + 32 * scols;
-    for (int e = lane; e < 32 * scols; e += 64) {
-        out_i[e] = 0xFFFFFFFFu;                              // -1
-        out_d[e] = INFINITY;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    {
-        const int ql = r;
-        const int f = q_flag[ql * 2] | q_flag[ql * 2 + 1];
-        const int k0 = min(q_kcnt[ql * 2], kKeepHalf), k1 = min(q_kcnt[ql * 2 + 1], kKeepHalf);
-        const uint32_t uT = q_uT[ql], iT = q_iT[ql];
-        const uint32_t* kuq = kept_u + ql * kKeepStride;
-        const uint32_t* kiq = kept_id + ql * kKeepStride;
-        // an entry survives unless it was ambiguous and lost against the exact k-th key
-        auto alive = [&](uint32_t u, uint32_t idf) -> bool {
-            if (!(idf & 0x80000000u)) return true;
-            const uint32_t id = idf & 0x7FFFFFFFu;
-            return u > uT || (u == uT && id <= iT);
-        };
-        int total = 0;
-        if (ql < nqw && !(f & 2)) {
-            const int mine = h ? k1 : k0;
-            for (int e = 0; e < mine; ++e) {
-                const uint32_t ue = kuq[h * kKeepHalf + e], ie = kiq[h * kKeepHalf + e];
-                if (!alive(ue, ie)) continue;
-                const uint32_t ide = ie & 0x7FFFFFFFu;
-                int rank = 0;                                // surviving entries with a better key (sim desc, id asc)
-                for (int j = 0; j < k0; ++j) {
-                    const uint32_t uj = kuq[j], ij = kiq[j];
-                    rank += (alive(uj, ij) && (uj > ue || (uj == ue && (ij & 0x7FFFFFFFu) < ide))) ? 1 : 0;
-                }
-                for (int j = 0; j < k1; ++j) {
-                    const uint32_t uj = kuq[kKeepHalf + j], ij = kiq[kKeepHalf + j];
-                    rank += (alive(uj, ij) && (uj > ue || (uj == ue && (ij & 0x7FFFFFFFu) < ide))) ? 1 : 0;
-                }
-                if (rank < scols) {
-                    out_i[ql * scols + rank] = ide;
-                    out_d[ql * scols + rank] = fminf(fmaxf(1.0f - sortable_f32(ue), 0.f), 1.f);
-                }
-                ++total;
-            }
-        }
-        const int other = __shfl(total, lane ^ 32, 64);
-        if (a.nb_count && h == 0 && ql < nqw && !(f & 2)) a.nb_count[row0 + qbase + ql] = min(total + other, keep);
-        if (h == 0 && ql < nqw && (f & 2) && !(dbg & 64)) push_fallback(a, row0 + qbase + ql, ji);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    // rows of the wave's queries are contiguous in the output arrays
-    {
-        int32_t* gi = a.nb_idx + (row0 + qbase) * (int64_t)keep;
-        float* gd = a.nb_dist + (row0 + qbase) * (int64_t)keep;
-        for (int qq = 0; qq < nqw; ++qq)
-            for (int col = lane; col < keep; col += 64) {
-                gi[qq * keep + col] = col < scols ? (int32_t)out_i[qq * scols + col] : -1;
-                gd[qq * keep + col] = col < scols ? out_d[qq * scols + col] : INFINITY;
-            }
-    }
-    FAL_STAMP(7)
-#undef FAL_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(64) void fused_fallback_kernel(FusedArgs a, SelectA
     float* row_s = scratch + (int64_t)blockIdx.x * scratch_stride;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int64_t row = a.fb_list[2 * t];
-        const DenseJob job = a.jobs[a.fb_list[2 * t + 1]];
+        const DenseJob job = a.jobs32[a.fb_list[2 * t + 1]];
         const int nc = job.nc;
         const float* qp = a.X + row * d;
         for (int c = lane; c < nc; c += 64) row_s[c] = exact_dot(qp, a.X + (job.c_row0 + c) * d, d);
@@ -695,16 +704,45 @@ __global__ __launch_bounds__(64) void fused_fallback_kernel(FusedArgs a, SelectA
     }
 }
 
-int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t list_tiles, int max_nc) {
-    if (a_in.n_jobs <= 0 || list_tiles <= 0) return FAL_OK;
+// largest float32 y >= 0 with (double)y * scale <= tol (-1 when there is none): the float32 form of the tolerance tests
+static float float_le_bound(double tol, double scale) {
+    if (!(tol >= 0.0)) return -1.f;
+    uint32_t lo = 0, hi = 0x7F7FFFFFu;                       // bit patterns of non-negative finite floats are ordered
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        float y;
+        memcpy(&y, &mid, 4);
+        if ((double)y * scale <= tol) lo = mid; else hi = mid - 1;
+    }
+    float y;
+    memcpy(&y, &lo, 4);
+    return y;
+}
+
+int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int64_t list_tiles128, int64_t list_tiles32,
+                 int max_nc) {
+    if (a_in.n_jobs32 <= 0 || list_tiles32 <= 0) return FAL_OK;
     FusedArgs a = a_in;
     {
         const char* e = getenv("FALCON_FUSED_DBG");
         a.dbg = e ? atoi(e) : 0;
     }
-    FAL_REQUIRE(list_tiles * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
+    FAL_REQUIRE(list_tiles32 * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     FAL_REQUIRE(max_nc < 65536, FAL_EUNSUPPORTED, "fused scan: buckets must hold fewer than 65,536 rows");
-    const int steps = d / 16;
+    a.tol_f = float_le_bound(a.tol, a.is_da ? 1.0 : 1e6);
+    a.rt_f = float_le_bound(a.rt_tol, 1.0);
+    // hand-off buffers, indexed by sorted row
+    unsigned char* hand = nullptr;
+    const size_t per_row = sizeof(QThr) + (size_t)FAL_FUSED_MEM * 8 + (size_t)FAL_FUSED_KEEP * 8 + 8;
+    FAL_TRY(ctx->reserve(SLOT_FUSED3, per_row * (size_t)n_rows + 256, (void**)&hand));
+    a.thr = reinterpret_cast<QThr*>(hand);
+    a.gmem_v = reinterpret_cast<float*>(a.thr + n_rows);
+    a.gmem_id = reinterpret_cast<uint32_t*>(a.gmem_v + n_rows * FAL_FUSED_MEM);
+    a.gkept_u = a.gmem_id + n_rows * FAL_FUSED_MEM;
+    a.gkept_id = a.gkept_u + n_rows * FAL_FUSED_KEEP;
+    a.gkcnt = reinterpret_cast<int32_t*>(a.gkept_id + n_rows * FAL_FUSED_KEEP);
+    ctx->counters[6] = (int64_t)(uintptr_t)hand;            // (debug tools read the hand-off buffers)
+    ctx->counters[7] = n_rows;
     // fallback list + its scratch rows
     const int fb_grid = ctx->num_cus * 16;
     const int64_t stride = (((int64_t)max_nc + 63) & ~63ll) + (int64_t)kSimsSlack;
@@ -713,40 +751,57 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t list_tiles,
     const int fb_cap = 1 << 22;
     FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(2 * fb_cap + 16), (void**)&fb));
     FAL_TRY(ctx->reserve(SLOT_FUSED2, sizeof(float) * (size_t)fb_grid * (size_t)stride, (void**)&scratch));
-    a.stamps = nullptr;
-    if (a.dbg & 128) {
-        FAL_TRY(ctx->reserve(SLOT_MISC2, sizeof(unsigned long long) * 10 * (size_t)(list_tiles * 8), (void**)&a.stamps));
-        FAL_CHECK_HIP(hipMemsetAsync(a.stamps, 0, sizeof(unsigned long long) * 10 * (size_t)(list_tiles * 8), ctx->stream));
-        ctx->counters[6] = (int64_t)(uintptr_t)a.stamps;
-        ctx->counters[7] = list_tiles * 8;
-    }
     a.fb_count = fb;
+    ctx->counters[7] = (int64_t)(uintptr_t)fb;              // (debug tools: fallback count + reason counters)
     a.fb_list = fb + 16;
     a.fb_cap = fb_cap;
     FAL_CHECK_HIP(hipMemsetAsync(fb, 0, sizeof(int32_t) * 16, ctx->stream));
-    const size_t lds = (size_t)region_a_bytes(d) + 4 * kWaveHist + 4 * kWaveSmall;
-    dim3 grid((unsigned)(list_tiles * 8)), block(256);
+    const int steps = d / 16;
+    static const bool split = getenv("FALCON_FUSED_SPLIT_TIMERS") != nullptr;
+    if (split) { ctx->stage_reset(ST_BUILD); ctx->stage_reset(ST_FILTER); }
+      // experiments: approx -> build, band -> scan, resolve -> select, fallback -> filter
+    {
+        StageScope ts(ctx, split ? ST_BUILD : ST_SCAN);
+        if (a.n_jobs128 > 0 && list_tiles128 > 0) {
+            const size_t lds = (size_t)32 * ((size_t)d * 2 + 16) + 4 * kWaveHist + 4 * kWaveSmall;
+            dim3 grid((unsigned)(list_tiles128 * 8)), block(256);
+#define FAL_LAUNCH_APPROX(S)                                                                                      \
+    do {                                                                                                          \
+        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)approx_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((approx_kernel<S>), grid, block, lds, ctx->stream, a);                                 \
+    } while (0)
+            switch (steps) {
+                case 4: FAL_LAUNCH_APPROX(4); break;
+                case 8: FAL_LAUNCH_APPROX(8); break;
+                case 16: FAL_LAUNCH_APPROX(16); break;
+                case 25: FAL_LAUNCH_APPROX(25); break;
+                default:
+                    set_error("fused scan: low_dim %d has no instantiation (64, 128, 256, 400)", d);
+                    return FAL_EUNSUPPORTED;
+            }
+#undef FAL_LAUNCH_APPROX
+            FAL_CHECK_HIP(hipGetLastError());
+        }
+    }
     {
         StageScope ts(ctx, ST_SCAN);
-#define FAL_LAUNCH_FUSED(S)                                                                                       \
-    do {                                                                                                          \
-        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)fused_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((fused_kernel<S>), grid, block, lds, ctx->stream, a);                                  \
-    } while (0)
+        dim3 grid((unsigned)(list_tiles32 * 8)), block(64);
         switch (steps) {
-            case 4: FAL_LAUNCH_FUSED(4); break;
-            case 8: FAL_LAUNCH_FUSED(8); break;
-            case 16: FAL_LAUNCH_FUSED(16); break;
-            case 25: FAL_LAUNCH_FUSED(25); break;
-            default:
-                set_error("fused scan: low_dim %d has no instantiation (64, 128, 256, 400)", d);
-                return FAL_EUNSUPPORTED;
+            case 4: hipLaunchKernelGGL((band_kernel<8>), grid, block, 0, ctx->stream, a); break;
+            case 8: hipLaunchKernelGGL((band_kernel<16>), grid, block, 0, ctx->stream, a); break;
+            case 16: hipLaunchKernelGGL((band_kernel<32>), grid, block, 0, ctx->stream, a); break;
+            case 25: hipLaunchKernelGGL((band_kernel<50>), grid, block, 0, ctx->stream, a); break;
+            default: return FAL_EUNSUPPORTED;
         }
-#undef FAL_LAUNCH_FUSED
         FAL_CHECK_HIP(hipGetLastError());
     }
     {
         StageScope ts(ctx, ST_SELECT);
+        hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
+        FAL_CHECK_HIP(hipGetLastError());
+    }
+    {
+        StageScope ts(ctx, split ? ST_FILTER : ST_SELECT);
         SelectArgs sa{};
         sa.k = a.k;
         sa.f_pmz = a.pmz; sa.f_rt = a.rt; sa.f_tol = a.tol; sa.f_rt_tol = a.rt_tol; sa.f_is_da = a.is_da;

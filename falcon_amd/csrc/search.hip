@@ -168,28 +168,38 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     const bool fused = nf && ivf->Xpre && ivf->X && fused_supports(d) && !no_fused && !border.empty() &&
                        (ivf->bucket_off[border[0] + 1] - ivf->bucket_off[border[0]]) < 65536;
     if (fused) {
-        std::vector<DenseJob> fj;
-        fj.reserve(border.size());
-        int64_t xt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int64_t pairs = 0, band = 0;
+        // two tables over the same buckets (sorted by decreasing size, dealt to the 8 XCD lists round-robin): 32-query
+        // tiles for the exact band / resolve kernels, 128-query tiles for the prefilter of buckets with more than k rows
+        std::vector<DenseJob> j32, j128;
+        j32.reserve(border.size());
+        int64_t xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt128[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t pairs = 0;
         for (size_t j = 0; j < border.size(); ++j) {
             const int64_t b = border[j];
             const int64_t row0 = ivf->bucket_off[b], nb = ivf->bucket_off[b + 1] - row0;
             const int x = (int)(j & 7);
-            fj.push_back({row0, row0, 0, 0, (int32_t)nb, (int32_t)nb, xt[x]});
-            xt[x] += ceil_div(nb, 128);
+            j32.push_back({row0, row0, 0, 0, (int32_t)nb, (int32_t)nb, xt32[x]});
+            xt32[x] += ceil_div(nb, 32);
+            if (nb > k_ann) {                                 // (sizes are non-increasing: a prefix)
+                const int y = (int)(j128.size() & 7);
+                j128.push_back({row0, row0, 0, 0, (int32_t)nb, (int32_t)nb, xt128[y]});
+                xt128[y] += ceil_div(nb, 128);
+            }
             pairs += nb * nb;
         }
-        DenseJob* fj_dev = nullptr;
-        FAL_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * fj.size(), (void**)&fj_dev));
-        FAL_TRY(ctx->upload(fj_dev, fj.data(), sizeof(DenseJob) * fj.size()));
+        DenseJob* jd = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * (j32.size() + j128.size() + 1), (void**)&jd));
+        FAL_TRY(ctx->upload(jd, j32.data(), sizeof(DenseJob) * j32.size()));
+        if (!j128.empty()) FAL_TRY(ctx->upload(jd + j32.size(), j128.data(), sizeof(DenseJob) * j128.size()));
         FusedArgs fa{};
-        fa.X = ivf->X; fa.X16 = reinterpret_cast<const __half*>(ivf->Xpre); fa.jobs = fj_dev; fa.n_jobs = (int)fj.size();
+        fa.X = ivf->X; fa.X16 = reinterpret_cast<const __half*>(ivf->Xpre);
+        fa.jobs32 = jd; fa.n_jobs32 = (int)j32.size(); fa.jobs128 = jd + j32.size(); fa.n_jobs128 = (int)j128.size();
         fa.k = k_ann; fa.pmz = nf->pmz; fa.rt = nf->rt; fa.tol = nf->tol; fa.rt_tol = nf->rt_tol; fa.is_da = nf->is_da;
         fa.keep = nf->keep; fa.nb_idx = nf->nb_idx; fa.nb_dist = nf->nb_dist; fa.nb_count = nf->nb_count;
-        FAL_TRY(launch_fused(ctx, fa, d, *std::max_element(xt, xt + 8), fj[0].nc));
+        FAL_TRY(launch_fused(ctx, fa, d, ivf->n, *std::max_element(xt128, xt128 + 8), *std::max_element(xt32, xt32 + 8),
+                             j32[0].nc));
         ctx->counters[0] = pairs;
-        ctx->counters[4] = band;
+        ctx->counters[4] = 0;
         ctx->counters[2] = 1;
         ctx->counters[3] = 0;
         border.clear();                       // nothing left for the staged flat path

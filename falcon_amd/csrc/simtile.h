@@ -94,6 +94,11 @@ struct CandStream {
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             if (j == kMidStep) mid();
         }
+        // The last MFMA needs 16 passes before its accumulators may be read.  hipcc's hazard recognizer counts the wait
+        // states along the fall-through path only: with a taken branch right behind the chain (band_kernel<16>) the
+        // first v_accvgpr_read came 12 states after the MFMA and saw the sum WITHOUT the last k-slot pair (found by
+        // tests/test_gpu_fused.py at low_dim 128).  24 explicit wait states cost 0.2 % of a chunk.
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc));      // (tied to acc: cannot move in front of the last MFMA)
         return acc;
     }
 };

@@ -12,6 +12,7 @@ from falcon_amd.device import Context
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 modes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else \
     [0, 64, 1 + 64, 2 + 64, 3 + 64, 4 + 64, 8 + 64, 16 + 64, 32 + 4 + 64, 32 + 4 + 8 + 64, 32 + 4 + 8 + 16 + 64, 3 + 4 + 8 + 16 + 64]
+os.environ['FALCON_FUSED_SPLIT_TIMERS'] = '1'
 ctx = Context(0)
 data = synth.generate_device(n, ctx.tdev)
 c = synth.select_charge_device(data, 2)
@@ -32,37 +33,20 @@ for dbg in modes:
     os.environ["FALCON_FUSED_DBG"] = str(dbg)
     for _ in range(2):
         index.search_neighbors(16, 128, mzs, None, 20.0, "ppm", None, 64)
-    s, f = ctx.stage_ms("scan")[0], ctx.stage_ms("select")[0]
-    print(f"dbg={dbg:3d} fused {s:.3f} ms  fallback kernel {f:.3f} ms  fallback rows {ctx.counter(5)}", flush=True)
+    t = {k: ctx.stage_ms(k)[0] for k in ("build", "scan", "select", "filter")}
+    print(f"dbg={dbg:4d} approx {t['build']:.3f}  band {t['scan']:.3f}  resolve {t['select']:.3f}  fallback {t['filter']:.3f} ms  fallback rows {ctx.counter(5)}", flush=True)
 
-# ---- in-kernel time stamps (dbg bit 128): cycles per phase, per workgroup -------------------------------------------
+
 import ctypes
-os.environ["FALCON_FUSED_DBG"] = "128"
-index.search_neighbors(16, 128, mzs, None, 20.0, "ppm", None, 64)
-ctx.sync()
-ptr, nwg = ctx.counter(6), ctx.counter(7)
 hip = ctypes.CDLL("libamdhip64.so")
-buf = np.zeros((nwg, 10), np.uint64)
-hip.hipMemcpy(ctypes.c_void_p(buf.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(buf.nbytes), 2)
-live = buf[:, 0] > 0
-st = buf[live].astype(np.int64)
-nc = st[:, 8]
-names = ["pass1", "binsearch", "pass2", "Ttilde", "band", "exact-resolve", "rank+store"]
-print("workgroups", live.sum(), "of grid", nwg, " with passes (nc>128):", int((nc > 128).sum()))
-t0, t1 = st[:, 0].min(), st[:, 7].max()
-print("kernel span cycles (s_memtime ticks)", t1 - t0)
-big = nc > 128
-for name, sel in (("nc>128", big), ("nc<=128", ~big)):
-    if sel.sum() == 0:
-        continue
-    s = st[sel]
-    print(name, "count", sel.sum(), "mean nc", s[:, 8].mean(), "mean band chunks (wave 0)", s[:, 9].mean())
-    prev = s[:, 0]
-    for i, nme in enumerate(names):
-        cur = np.where(s[:, i + 1] > 0, s[:, i + 1], prev)
-        print(f"   {nme:14s} mean {np.mean(cur - prev):10.0f} ticks   total/CU {np.sum(cur - prev) / 256:12.0f}")
-        prev = cur
-    chunks = np.ceil(s[:, 8] / 32)
-    if name == "nc>128":
-        p1 = np.where(s[:, 1] > 0, s[:, 1] - s[:, 0], 0)
-        print("   pass1 ticks per chunk:", np.sum(p1) / np.sum(chunks))
+why = np.zeros(4, np.int32)
+hip.hipMemcpy(ctypes.c_void_p(why.ctypes.data), ctypes.c_void_p(ctx.counter(7)), ctypes.c_size_t(16), 2)
+print("fallback rows", why[0], "reasons: approx-stage (members / T~)", why[1], " kept overflow", why[2], " need out of range", why[3])
+thr = np.zeros((X.shape[0], 8), np.float32)
+hip.hipMemcpy(ctypes.c_void_p(thr.ctypes.data), ctypes.c_void_p(ctx.counter(6)), ctypes.c_size_t(thr.nbytes), 2)
+ti = thr.view(np.int32)
+big = np.diff(splits)
+rows_big = np.concatenate([np.arange(a, b) for a, b in zip(splits[:-1], splits[1:]) if b - a > 128])
+mc = ti[rows_big, 6]
+m0, m1 = mc & 0xffff, mc >> 16
+print("members per half: mean", (m0 + m1).mean() / 2, "max", max(m0.max(), m1.max()), " rows with a full half:", int(((m0 >= 20) | (m1 >= 20)).sum()), "flags set", int((ti[rows_big, 7] & 2 > 0).sum()))
