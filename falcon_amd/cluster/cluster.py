@@ -177,9 +177,10 @@ class ClusterPipeline:
         """a9 DBSCAN, a10 refinement, a11/a12 medoids + labels -> (labels, medoids); `last` describes the partition."""
         c = self.ctx
         order, mzs, rts, nb_idx, nb_dist, index = (st[k] for k in ("order", "mzs", "rts", "nb_idx", "nb_dist", "index"))
+        hier = p.linkage if p.clustering == "hierarchical" else None      # f4: the snapshot's linkage + cut at the threshold
         if keep_intermediates:
             # staged calls (one C-ABI call per SURVEY 8a row) so that every intermediate can be inspected
-            db, n_db = c.dbscan(nb_idx, nb_dist, p.eps)
+            db, n_db = c.linkage_cluster(nb_idx, nb_dist, p.eps, hier) if hier else c.dbscan(nb_idx, nb_dist, p.eps)
             last = dict(order=order, mz_sorted=mzs, rt_sorted=rts, splits=st["splits"], X=st["X"], X16=st["X16"],
                         n_list=st["n_list"], sim=st["sim"], idx=st["idx"], nb_idx=nb_idx, nb_dist=nb_dist, db=db.clone(),
                         n_db=n_db, index=index)
@@ -189,7 +190,7 @@ class ClusterPipeline:
         else:
             # production: a9..a12 fused, counts stay on the device, one synchronisation
             labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
-                                                    precursor_tol_mode, rt_tol, order)
+                                                    precursor_tol_mode, rt_tol, order, linkage=hier)
             last = dict(nb_idx=nb_idx, nb_dist=nb_dist, nb_count=st["nb_count"], order=order)   # the sparse graph (exchange)
             index.close()
         return labels, medoids, last
@@ -353,8 +354,12 @@ def generate_clusters(dataset, linkage: str, distance_threshold: float, min_matc
         p = dataclasses.replace(ann)                 # never mutate the caller's parameters
     if p.rescore:
         p.min_matches = int(min_matches)
+    if p.clustering not in ("dbscan", "hierarchical"):
+        raise ValueError(f"unknown clustering {p.clustering!r}")
     if p.clustering == "hierarchical":
         p.linkage = linkage
+        p.rescore = True                 # the linkage runs on the exact matched-peak distances (cluster.py:283-290)
+        p.min_matches = int(min_matches)
     elif linkage != "complete":
         raise ValueError(f"linkage={linkage!r} only applies to the hierarchical clustering of the exact distances "
                          "(AnnParams(clustering=\"hierarchical\", rescore=True) / --clustering hierarchical); the default "

@@ -1,0 +1,295 @@
+// f4: hierarchical clustering of the (re-scored) neighbour graph -- the clustering the reference snapshot ships:
+// `fcluster(fastcluster.linkage(pdist, linkage), distance_threshold, "distance")` on the exact cosine distances of a
+// block (reference cluster.py:283-290), here on the sparse neighbour graph with "missing pair = distance 1"
+// (the reference's own convention for pairs below min_matched_peaks, cluster.py:621-626).
+//
+// Cut at a threshold t < 1 a flat cluster can only join spectra of one connected component of the graph of edges with
+// d <= t (single: the components themselves; complete / average: a merge across two components has height 1).  So:
+//   1. lock-free union-find over the stored edges with d <= t (both directions) -> components, root = lowest row;
+//   2. single linkage: done.  complete / average: one wave per component of >= 2 rows -- dense matrix of the component
+//      (d(i, j) = the smaller of the stored directions, 1 where neither is stored), naive agglomeration with the
+//      Lance-Williams update in float64 (scipy's formulas), always merging the pair with the smallest height (ties:
+//      lowest (a, b)), until the smallest height exceeds t;
+//   3. clusters of one row become noise (-1: the reference's _postprocess_cluster drops groups < 2, cluster.py:441-454),
+//      the others are numbered by their lowest row -- the interface of the DBSCAN stage (a9), so a10..a12 follow
+//      unchanged.
+// fastcluster is not available and scipy's tie order is not specified: PARITY UNPINNED for exact ties (the partition is
+// identical whenever merge heights are distinct; tests/test_gpu_linkage.py against scipy.cluster.hierarchy).
+#include <math.h>
+#include <algorithm>
+#include "common.h"
+#include "ivf.h"
+#include "util.h"
+
+namespace fal {
+
+__device__ __forceinline__ int32_t lk_find(int32_t* parent, int32_t x) {
+    int32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        const int32_t g = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g != p) __hip_atomic_store(&parent[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p;
+        p = g;
+    }
+    return x;
+}
+
+__device__ __forceinline__ void lk_union(int32_t* parent, int32_t a, int32_t b) {
+    while (true) {
+        a = lk_find(parent, a);
+        b = lk_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int32_t t = a; a = b; b = t; }     // hook the larger root under the smaller
+        if (atomicCAS(&parent[a], a, b) == a) return;
+    }
+}
+
+__global__ void lk_init_kernel(int32_t* __restrict__ parent, int32_t* __restrict__ count, int32_t* __restrict__ rep, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        parent[i] = (int32_t)i;
+        count[i] = 0;
+        rep[i] = -1;
+    }
+}
+
+__global__ void lk_edges_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist, int64_t n, int k,
+                                float t, int32_t* __restrict__ parent) {
+    const int64_t total = n * k;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / k;
+        const int32_t j = nb_idx[e];
+        if (j >= 0 && (int64_t)j != i && nb_dist[e] <= t) lk_union(parent, (int32_t)i, j);
+    }
+}
+
+__global__ void lk_roots_kernel(int32_t* __restrict__ parent, int32_t* __restrict__ count, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t root = lk_find(parent, (int32_t)i);
+        parent[i] = root;
+        atomicAdd(&count[root], 1);
+    }
+}
+
+// per row: 1 where the row is the root of a component of >= 2 rows; sizes / squared sizes for the member and matrix offsets
+__global__ void lk_comp_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ count, int64_t n,
+                               int32_t* __restrict__ is_comp, int64_t* __restrict__ msz, int64_t* __restrict__ msq) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool c = parent[i] == (int32_t)i && count[i] >= 2;
+        is_comp[i] = c;
+        msz[i] = c ? count[i] : 0;
+        msq[i] = c ? (int64_t)count[i] * count[i] : 0;
+    }
+}
+
+__global__ void lk_scatter_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ count, int64_t n,
+                                  const int64_t* __restrict__ moff, int32_t* __restrict__ cursor, int32_t* __restrict__ mem,
+                                  const int64_t* __restrict__ comp_rank, int32_t* __restrict__ comp_root) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t root = parent[i];
+        if (count[root] < 2) continue;
+        mem[moff[root] + atomicAdd(&cursor[root], 1)] = (int32_t)i;
+        if (root == (int32_t)i) comp_root[comp_rank[i]] = root;
+    }
+}
+
+// single linkage: the component is the cluster
+__global__ void lk_single_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ count, int64_t n,
+                                 int32_t* __restrict__ rep) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        rep[i] = count[parent[i]] >= 2 ? parent[i] : -1;
+}
+
+// one wave per component: method 1 = complete, 2 = average
+__global__ __launch_bounds__(64) void lk_agglomerate_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
+                                                            int k, double t, int method, const int32_t* __restrict__ parent,
+                                                            const int32_t* __restrict__ count, const int32_t* __restrict__ comp_root,
+                                                            const int64_t* __restrict__ moff, const int64_t* __restrict__ qoff,
+                                                            const int32_t* __restrict__ mem, int32_t* __restrict__ mem_sorted,
+                                                            int32_t* __restrict__ lidx, int32_t* __restrict__ act,
+                                                            int32_t* __restrict__ sz, int32_t* __restrict__ cl,
+                                                            double* __restrict__ Dall, int32_t* __restrict__ rep) {
+    const int lane = threadIdx.x;
+    const int32_t root = comp_root[blockIdx.x];
+    const int m = count[root];
+    const int64_t mo = moff[root];
+    const int32_t* mu = mem + mo;
+    int32_t* ms = mem_sorted + mo;
+    int32_t* a_act = act + mo;
+    int32_t* a_sz = sz + mo;
+    int32_t* a_cl = cl + mo;
+    double* D = Dall + qoff[root];
+    // members in ascending row order (rank by counting); local index of every member row
+    for (int x = lane; x < m; x += 64) {
+        const int32_t rx = mu[x];
+        int rank = 0;
+        for (int y = 0; y < m; ++y) rank += mu[y] < rx;
+        ms[rank] = rx;
+        lidx[rx] = rank;
+        a_act[x] = 1;
+        a_sz[x] = 1;
+        a_cl[x] = x;
+    }
+    for (int64_t c = lane; c < (int64_t)m * m; c += 64) D[c] = 1.0;              // missing pair = distance 1
+    __threadfence_block();
+    __syncthreads();
+    for (int a = 0; a < m; ++a) {
+        const int64_t row = ms[a];
+        for (int s = lane; s < k; s += 64) {
+            const int32_t j = nb_idx[row * k + s];
+            if (j >= 0 && (int64_t)j != row && parent[j] == root) D[(int64_t)a * m + lidx[j]] = (double)nb_dist[row * k + s];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t c = lane; c < (int64_t)m * m; c += 64) {                          // d(i, j) = the smaller stored direction
+        const int a = (int)(c / m), b = (int)(c % m);
+        if (a < b) {
+            const double v = fmin(D[c], D[(int64_t)b * m + a]);
+            D[c] = v;
+            D[(int64_t)b * m + a] = v;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int step = 0; step < m - 1; ++step) {
+        double bv = INFINITY;
+        int ba = 0x7fffffff, bb = 0x7fffffff;
+        for (int a = lane; a < m; a += 64) {
+            if (!a_act[a]) continue;
+            for (int b = a + 1; b < m; ++b) {
+                if (!a_act[b]) continue;
+                const double v = D[(int64_t)a * m + b];
+                if (v < bv || (v == bv && (a < ba || (a == ba && b < bb)))) {
+                    bv = v;
+                    ba = a;
+                    bb = b;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int oa = __shfl_xor(ba, off, 64), ob = __shfl_xor(bb, off, 64);
+            if (ov < bv || (ov == bv && (oa < ba || (oa == ba && ob < bb)))) {
+                bv = ov;
+                ba = oa;
+                bb = ob;
+            }
+        }
+        if (!(bv <= t)) break;                                                      // fcluster(Z, t, "distance")
+        const double sa = (double)a_sz[ba], sb = (double)a_sz[bb];
+        for (int c = lane; c < m; c += 64) {
+            if (!a_act[c] || c == ba || c == bb) continue;
+            const double dac = D[(int64_t)ba * m + c], dbc = D[(int64_t)bb * m + c];
+            const double nv = method == 1 ? fmax(dac, dbc) : (sa * dac + sb * dbc) / (sa + sb);   // scipy's Lance-Williams forms
+            D[(int64_t)ba * m + c] = nv;
+            D[(int64_t)c * m + ba] = nv;
+        }
+        for (int x = lane; x < m; x += 64)
+            if (a_cl[x] == bb) a_cl[x] = ba;
+        __threadfence_block();
+        __syncthreads();
+        if (lane == 0) {
+            a_act[bb] = 0;
+            a_sz[ba] += a_sz[bb];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int x = lane; x < m; x += 64) {
+        const int c = a_cl[x];                              // representative = the cluster's lowest member (a < b in every merge)
+        rep[ms[x]] = a_sz[c] >= 2 ? ms[c] : -1;
+    }
+}
+
+__global__ void lk_isrep_kernel(const int32_t* __restrict__ rep, int64_t n, int32_t* __restrict__ is_rep) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        is_rep[i] = rep[i] == (int32_t)i;
+}
+
+__global__ void lk_label_kernel(const int32_t* __restrict__ rep, const int64_t* __restrict__ rank, int64_t n,
+                                int32_t* __restrict__ labels) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        labels[i] = rep[i] >= 0 ? (int32_t)rank[rep[i]] : -1;
+}
+
+// labels + cluster count on the device (the interface of dbscan_dev); synchronises once for the scratch sizes of the
+// complete / average forms
+int linkage_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float t, int method,
+                int32_t* labels, int64_t** d_count_out) {
+    hipStream_t st = ctx->stream;
+    int32_t* buf = nullptr;
+    int64_t* rank = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_DB, sizeof(int32_t) * (size_t)n * 4, (void**)&buf));
+    FAL_TRY(ctx->reserve(SLOT_DB2, sizeof(int64_t) * (size_t)(n + 1), (void**)&rank));
+    int32_t *parent = buf, *count = buf + n, *rep = buf + 2 * n, *flag = buf + 3 * n;
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
+    const int egrid = (int)std::min<int64_t>(ceil_div(n * k, 256), (int64_t)ctx->num_cus * 32);
+    ctx->stage_reset(ST_DBSCAN);
+    StageScope ts(ctx, ST_DBSCAN);
+    hipLaunchKernelGGL(lk_init_kernel, dim3(grid), dim3(256), 0, st, parent, count, rep, n);
+    hipLaunchKernelGGL(lk_edges_kernel, dim3(egrid), dim3(256), 0, st, nb_idx, nb_dist, n, k, t, parent);
+    hipLaunchKernelGGL(lk_roots_kernel, dim3(grid), dim3(256), 0, st, parent, count, n);
+    if (method == 0) {
+        hipLaunchKernelGGL(lk_single_kernel, dim3(grid), dim3(256), 0, st, parent, count, n, rep);
+    } else {
+        int64_t *msz = nullptr, *moff = nullptr, *qoff = nullptr, *crank = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_TAIL, sizeof(int64_t) * (size_t)(4 * (n + 1)), (void**)&msz));
+        int64_t* msq = msz + (n + 1);
+        moff = msq + (n + 1);
+        qoff = moff + (n + 1);
+        FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(n + 1), (void**)&crank));
+        hipLaunchKernelGGL(lk_comp_kernel, dim3(grid), dim3(256), 0, st, parent, count, n, flag, msz, msq);
+        FAL_TRY(device_scan_i32(ctx, flag, n, crank, SLOT_DB3));
+        FAL_TRY(device_scan_i64(ctx, msz, n, moff, SLOT_DB3));
+        FAL_TRY(device_scan_i64(ctx, msq, n, qoff, SLOT_DB3));
+        int64_t tot[3] = {0, 0, 0};
+        FAL_CHECK_HIP(hipMemcpyAsync(&tot[0], crank + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        FAL_CHECK_HIP(hipMemcpyAsync(&tot[1], moff + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        FAL_CHECK_HIP(hipMemcpyAsync(&tot[2], qoff + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        FAL_CHECK_HIP(hipStreamSynchronize(st));
+        const int64_t n_comp = tot[0], n_mem = tot[1], n_sq = tot[2];
+        FAL_REQUIRE(n_sq < ((int64_t)1 << 32), FAL_EUNSUPPORTED,
+                    "hierarchical clustering: the connected groups need %lld matrix entries (a group of tens of thousands of "
+                    "spectra within the distance threshold); use single linkage or DBSCAN", (long long)n_sq);
+        if (n_comp > 0) {
+            int32_t* ibuf = nullptr;
+            double* D = nullptr;
+            FAL_TRY(ctx->reserve(SLOT_TAIL3, sizeof(int32_t) * (size_t)(5 * n_mem + 2 * n + n_comp + 16), (void**)&ibuf));
+            FAL_TRY(ctx->reserve(SLOT_TAIL4, sizeof(double) * (size_t)(n_sq + 16), (void**)&D));
+            int32_t *mem = ibuf, *mem_sorted = mem + n_mem, *act = mem_sorted + n_mem, *sz = act + n_mem, *cl = sz + n_mem;
+            int32_t *lidx = cl + n_mem, *cursor = lidx + n, *comp_root = cursor + n;
+            FAL_CHECK_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n, st));
+            hipLaunchKernelGGL(lk_scatter_kernel, dim3(grid), dim3(256), 0, st, parent, count, n, moff, cursor, mem, crank, comp_root);
+            hipLaunchKernelGGL(lk_agglomerate_kernel, dim3((unsigned)n_comp), dim3(64), 0, st, nb_idx, nb_dist, k, (double)t, method,
+                               parent, count, comp_root, moff, qoff, mem, mem_sorted, lidx, act, sz, cl, D, rep);
+        }
+    }
+    hipLaunchKernelGGL(lk_isrep_kernel, dim3(grid), dim3(256), 0, st, rep, n, flag);
+    FAL_TRY(device_scan_i32(ctx, flag, n, rank, SLOT_DB3));
+    hipLaunchKernelGGL(lk_label_kernel, dim3(grid), dim3(256), 0, st, rep, rank, n, labels);
+    FAL_CHECK_HIP(hipGetLastError());
+    *d_count_out = rank + n;
+    return FAL_OK;
+}
+
+}  // namespace fal
+
+using namespace fal;
+
+extern "C" int fal_linkage_cluster(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float threshold,
+                                   int method, int32_t* labels, int64_t* n_clusters) {
+    FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_linkage_cluster: bad argument");
+    FAL_REQUIRE(method >= 0 && method <= 2, FAL_EINVAL, "fal_linkage_cluster: method must be 0 (single), 1 (complete) or 2 (average)");
+    FAL_REQUIRE(threshold < 1.0f, FAL_EUNSUPPORTED, "fal_linkage_cluster: the threshold must be below 1 (the distance of a missing pair)");
+    if (n_clusters) *n_clusters = 0;
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(nb_idx && nb_dist && labels, FAL_EINVAL, "fal_linkage_cluster: NULL array");
+    int64_t* d_count = nullptr;
+    FAL_TRY(linkage_dev(ctx, nb_idx, nb_dist, n, k, threshold, method, labels, &d_count));
+    if (n_clusters) {
+        FAL_CHECK_HIP(hipMemcpyAsync(n_clusters, d_count, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return FAL_OK;
+}

@@ -532,10 +532,10 @@ int fal_finalize(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, int64_t 
 
 // a9 + a10 + a11 + a12 in one call with every intermediate count on the device: one host
 // synchronisation (for the two output counts) instead of three.
-int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps,
-                      const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
-                      double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
-                      int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+static int cluster_graph_impl(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps, int method,
+                              const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
+                              double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
+                              int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX && n_clusters && n_labels, FAL_EINVAL,
                 "fal_cluster_graph: bad argument");
     *n_clusters = *n_labels = 0;
@@ -544,7 +544,8 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
                 FAL_EINVAL, "fal_cluster_graph: NULL array");
     int64_t *d_db = nullptr, *d_cl = nullptr, *d_noise = nullptr;
     ctx->stage_reset(ST_TAIL);
-    FAL_TRY(dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels_sorted_scratch, &d_db));
+    if (method < 0) FAL_TRY(dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels_sorted_scratch, &d_db));
+    else FAL_TRY(linkage_dev(ctx, nb_idx, nb_dist, n, k, eps, method, labels_sorted_scratch, &d_db));
     FAL_TRY(refine_dev(ctx, labels_sorted_scratch, n, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol, d_db, &d_cl));
     FAL_TRY(finalize_dev(ctx, labels_sorted_scratch, n, d_cl, row_order, nb_idx, nb_dist, k, labels_out, medoids_out,
                          &d_noise));
@@ -555,6 +556,24 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
     *n_clusters = h[0];
     *n_labels = h[0] + h[1];
     return FAL_OK;
+}
+
+int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps,
+                      const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
+                      double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
+                      int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+    return cluster_graph_impl(ctx, nb_idx, nb_dist, n, k, eps, -1, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol,
+                              row_order, labels_sorted_scratch, labels_out, medoids_out, n_clusters, n_labels);
+}
+
+int fal_cluster_graph_linkage(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float threshold,
+                              int method, const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
+                              double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
+                              int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+    FAL_REQUIRE(method >= 0 && method <= 2, FAL_EINVAL, "fal_cluster_graph_linkage: method must be 0 (single), 1 (complete) or 2 (average)");
+    FAL_REQUIRE(threshold < 1.0f, FAL_EUNSUPPORTED, "fal_cluster_graph_linkage: the threshold must be below 1 (the distance of a missing pair)");
+    return cluster_graph_impl(ctx, nb_idx, nb_dist, n, k, threshold, method, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol,
+                              row_order, labels_sorted_scratch, labels_out, medoids_out, n_clusters, n_labels);
 }
 
 }  // extern "C"

@@ -282,20 +282,38 @@ class Context:
         return labels, medoids[:int(nl.value)]
 
 
-    def cluster_graph(self, nb_idx, nb_dist, eps: float, mz_sorted, rt_sorted, tol: float, mode: str, rt_tol, order):
-        """a9..a12 fused: -> labels i32[n] (dataset rows), medoids i32[n_labels], labels_sorted, n_clusters"""
+    LINKAGE = {"single": 0, "complete": 1, "average": 2}
+
+    def cluster_graph(self, nb_idx, nb_dist, eps: float, mz_sorted, rt_sorted, tol: float, mode: str, rt_tol, order,
+                      linkage: Optional[str] = None):
+        """a9..a12 fused: -> labels i32[n] (dataset rows), medoids i32[n_labels], labels_sorted, n_clusters.
+        `linkage` = None: DBSCAN(eps); "single" / "complete" / "average": hierarchical clustering cut at `eps` (f4)."""
         torch = _torch()
         n, k = nb_idx.shape
         lab_sorted = self.empty((n,), torch.int32)
         labels = self.empty((n,), torch.int32)
         medoids = self.empty((n,), torch.int32)
         nc, nl = C.c_int64(), C.c_int64()
-        check(self.lib.fal_cluster_graph(self._h, self._p(nb_idx), self._p(nb_dist), n, k, float(eps),
-                                         self._p(mz_sorted), self._p(rt_sorted), float(tol), int(mode == "Da"),
-                                         -1.0 if rt_tol is None else float(rt_tol), self._p(order),
-                                         self._p(lab_sorted), self._p(labels), self._p(medoids), C.byref(nc),
-                                         C.byref(nl)), "fal_cluster_graph")
+        tail = (self._p(mz_sorted), self._p(rt_sorted), float(tol), int(mode == "Da"),
+                -1.0 if rt_tol is None else float(rt_tol), self._p(order), self._p(lab_sorted), self._p(labels),
+                self._p(medoids), C.byref(nc), C.byref(nl))
+        if linkage is None:
+            check(self.lib.fal_cluster_graph(self._h, self._p(nb_idx), self._p(nb_dist), n, k, float(eps), *tail),
+                  "fal_cluster_graph")
+        else:
+            check(self.lib.fal_cluster_graph_linkage(self._h, self._p(nb_idx), self._p(nb_dist), n, k, float(eps),
+                                                     self.LINKAGE[linkage], *tail), "fal_cluster_graph_linkage")
         return labels, medoids[:int(nl.value)], lab_sorted, int(nc.value)
+
+    def linkage_cluster(self, nb_idx, nb_dist, threshold: float, linkage: str):
+        """f4 staged (`fal_linkage_cluster`): -> labels i32[n] (clusters by lowest row, -1 = groups of one), n_clusters"""
+        torch = _torch()
+        n, k = nb_idx.shape
+        labels = self.empty((n,), torch.int32)
+        nc = C.c_int64()
+        check(self.lib.fal_linkage_cluster(self._h, self._p(nb_idx), self._p(nb_dist), n, k, float(threshold),
+                                           self.LINKAGE[linkage], self._p(labels), C.byref(nc)), "fal_linkage_cluster")
+        return labels, int(nc.value)
 
 
 class IvfIndex:

@@ -231,6 +231,21 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
                       int32_t* labels_sorted_scratch, int32_t* labels_out, int32_t* medoids_out,
                       int64_t* n_clusters /*[host]*/, int64_t* n_labels /*[host]*/);
 
+/* ---- f4  hierarchical clustering of the neighbour graph: the clustering the reference snapshot ships,
+ *          fcluster(fastcluster.linkage(pdist, linkage), distance_threshold, "distance") (cluster.py:283-290), on the
+ *          sparse graph with "missing pair = distance 1" (cluster.py:621-626), normally after fal_rescore_neighbors
+ *          put the exact matched-peak distances into it.  method: 0 single, 1 complete, 2 average; threshold < 1.
+ *          Same output contract as fal_dbscan (clusters numbered by lowest row, groups of one row = -1), so
+ *          fal_refine_clusters / fal_finalize follow unchanged; fal_cluster_graph_linkage is the fused a9..a12
+ *          form.  Tie order between equal merge heights is the build's own (PARITY UNPINNED: fastcluster absent). [dev] */
+int fal_linkage_cluster(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k,
+                        float threshold, int method, int32_t* labels, int64_t* n_clusters /*[host]*/);
+int fal_cluster_graph_linkage(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k,
+                              float threshold, int method, const float* precursor_mz_sorted,
+                              const float* rt_sorted, double tol, int tol_is_da, double rt_tol,
+                              const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
+                              int32_t* medoids_out, int64_t* n_clusters /*[host]*/, int64_t* n_labels /*[host]*/);
+
 /* ---- f1  spectrum preprocessing, the step in front of the path: reference
  *          spectrum.py:73-169 `process_spectrum` over a CSR of raw peaks (m/z float64
  *          sorted per spectrum, intensity float32): m/z range cut (135), precursor-peak

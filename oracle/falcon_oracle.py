@@ -502,6 +502,64 @@ def dbscan_components(nb_idx: np.ndarray, nb_dist: np.ndarray, eps: float) -> np
     return labels.astype(np.int32)
 
 
+
+# --------------------------------------------------------------------------- f4
+def linkage_clusters(nb_idx: np.ndarray, nb_dist: np.ndarray, t: float, method: str) -> np.ndarray:
+    """Hierarchical clustering of the sparse neighbour graph cut at distance t: the snapshot's
+    `fcluster(fastcluster.linkage(pdist, linkage), distance_threshold, "distance")` (cluster.py:283-290) with
+    "missing pair = distance 1" (cluster.py:621-626); scipy's `linkage` stands in for fastcluster (absent; same
+    dendrogram up to the order of equal heights -- PARITY UNPINNED for exact ties).  Only the connected components of
+    the edges with d <= t can merge below t < 1, so the dense matrix is built per component.
+    d(i, j) = the smaller of the stored directions.  -> labels int32[n]: clusters numbered by lowest row, groups of
+    one row = -1 (what _postprocess_cluster makes of them, cluster.py:441-454) -- the contract of `dbscan_components`."""
+    from scipy.cluster.hierarchy import fcluster, linkage
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial.distance import squareform
+    assert t < 1.0 and method in ("single", "complete", "average")
+    n, k = nb_idx.shape
+    rows = np.repeat(np.arange(n), k)
+    cols = nb_idx.ravel().astype(np.int64)
+    d = nb_dist.ravel()
+    ok = (cols >= 0) & (cols != rows)
+    e = ok & (d <= f32(t))
+    g = coo_matrix((np.ones(int(e.sum())), (rows[e], cols[e])), shape=(n, n))
+    _, comp = connected_components(g, directed=False)
+    rep = np.full(n, -1, np.int64)
+    order = np.argsort(comp, kind="stable")
+    cs = comp[order]
+    lidx = np.zeros(n, np.int64)
+    for a, b in cluster_group_idx(cs):
+        members = order[a:b]                                    # ascending rows (stable sort of arange)
+        m = b - a
+        if m < 2:
+            continue
+        if method == "single":
+            rep[members] = members[0]
+            continue
+        lidx[members] = np.arange(m)
+        D = np.ones((m, m), f64)
+        for la, r in enumerate(members):
+            for s in range(k):
+                j = int(nb_idx[r, s])
+                if j >= 0 and j != r and comp[j] == comp[r]:
+                    D[la, lidx[j]] = f64(nb_dist[r, s])
+        D = np.minimum(D, D.T)
+        np.fill_diagonal(D, 0.0)
+        fl = fcluster(linkage(squareform(D, checks=False), method), float(f32(t)), "distance")
+        for c in np.unique(fl):
+            mm = members[fl == c]
+            if len(mm) >= 2:
+                rep[mm] = mm.min()
+    labels = np.full(n, -1, np.int32)
+    reps = np.unique(rep[rep >= 0])
+    rank = {int(r): i for i, r in enumerate(reps)}
+    for i in np.flatnonzero(rep >= 0):
+        labels[i] = rank[int(rep[i])]
+    return labels
+
+
+
 # -------------------------------------------------------------------------- a10
 def linkage_1d(values: np.ndarray, mode: Optional[str]) -> np.ndarray:
     """cluster.py:458-509: complete linkage of a 1-D array by repeatedly merging the
@@ -706,7 +764,8 @@ def generate_clusters(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
                       rt_tol=None, batch_size=2 ** 15, low_dim=400, n_probe=16, n_neighbors=64,
                       n_neighbors_ann=128, min_mz=101.0, max_mz=1500.0, fragment_tol=0.05,
                       mz_interval=1.0, kmeans_iters=10, hash_seed=0, dbscan="components",
-                      dtype=np.float32, return_intermediates=False, n_jobs=1):
+                      dtype=np.float32, return_intermediates=False, n_jobs=1, rescore=False, min_matches=0,
+                      clustering="dbscan", linkage="complete"):
     """Whole hot path for ONE charge partition -> (labels int32[N] by dataset row,
     no -1 left; medoids int32[n_labels]: medoids[c] = dataset row representing
     cluster c).  Mirrors cluster.generate_clusters (cluster.py:24-156) with the
@@ -745,7 +804,11 @@ def generate_clusters(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
         for ab in buckets:
             one_bucket(ab)
     nb_idx, nb_dist = filter_neighbors(sim, idx, mzs, rts, tol, mode, rt_tol, n_neighbors)
-    if dbscan == "sklearn":
+    if rescore or clustering == "hierarchical":                 # f4: exact matched-peak distances (cluster.py:593-639)
+        nb_dist = rescore_neighbors(nb_idx, nb_dist, mz, intensity, indptr, order, fragment_tol, min_matches)
+    if clustering == "hierarchical":                            # f4: the snapshot's linkage + cut (cluster.py:283-290)
+        db = linkage_clusters(nb_idx, nb_dist, eps, linkage)
+    elif dbscan == "sklearn":
         db = dbscan_sklearn_order(nb_idx, nb_dist, eps)
     else:
         db = dbscan_components(nb_idx, nb_dist, eps)

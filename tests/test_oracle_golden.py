@@ -1,9 +1,13 @@
 """Pin the CPU oracle against golden vectors produced by the reference's own
 function bodies (tests/golden/make_golden.py) and by scikit-learn."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import falcon_oracle as fo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_get_dim(ref_golden):
@@ -157,3 +161,13 @@ def test_cosine_fast_matches_reference_golden():
         # same matched pairs; the golden was produced without numba, where NumPy 2 keeps the running sum in
         # float32 (`0.0 += np.float32`), while numba -- and the oracle -- accumulate in float64: last-bit slack
         assert abs(sc - float(g["score"][c])) <= 4e-7, c
+
+
+def test_linkage_clusters_match_the_reference_composition():
+    """f4: the per-component restatement equals fcluster(linkage(dense pdist, method), t, "distance") on the whole graph
+    (tests/golden/make_linkage_golden.py: reference cluster.py:283-290 with scipy's linkage for fastcluster)."""
+    g = np.load(os.path.join(GOLDEN, "linkage.npz"))
+    for c in range(int(g["n_cases"])):
+        for method in ("single", "complete", "average"):
+            lab = fo.linkage_clusters(g[f"c{c}_idx"], g[f"c{c}_dist"], float(g[f"c{c}_t"]), method)
+            assert np.array_equal(lab, g[f"c{c}_{method}"]), (c, method)
