@@ -43,6 +43,7 @@ _SIGNATURES = {
     "fal_precursor_splits": ([c_void_p, c_void_p, c_int64, c_double, c_int, c_int64, c_double, c_int,
                               c_void_p, c_int64, P(c_int64)], c_int),
     "fal_ivf_build": ([c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, P(c_void_p)], c_int),
+    "fal_ivf_build_x16": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, P(c_void_p)], c_int),
     "fal_ivf_attach_f16": ([c_void_p, c_void_p, c_int], c_int),
     "fal_ivf_attach_prefilter": ([c_void_p, c_void_p], c_int),
     "fal_ivf_destroy": ([c_void_p], c_int),

@@ -44,6 +44,9 @@ class AnnParams:
                                   # refinement, fused.hip); results are bit-identical with and without it.  Off by default:
                                   # at BASELINE configs[1]'s bucket sizes (<= ~1,100 rows) it is on par with the staged
                                   # scan + select, it pays on larger flat buckets
+    kmeans_prefilter: bool = True # IVF buckets with <= 128 lists: k-means assignment on the f16 matrix cores, rows whose two
+                                  # best centroids are closer than the float16 error bound re-evaluated exactly in float32
+                                  # (assign16.hip): the index is identical, the build several times faster
     rescore: bool = False         # re-score the ANN neighbours with the reference's matched-peak cosine
                                   # (similarity.py:17-80) before DBSCAN; uses fragment_tol and min_matches
     min_matches: int = 0          # (set from generate_clusters' `min_matches` when rescore is on)
@@ -146,7 +149,7 @@ class ClusterPipeline:
         all_flat = bool((n_list == 1).all())
         vec = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
                                      p.hash_seed, True, dt)
-        X = X16 = Xpre = None
+        X = X16 = Xpre = Xkm = None
         if p.dtype == "f16":
             X16 = vec("f16")
         elif p.scan == "f16x3":
@@ -157,7 +160,9 @@ class ClusterPipeline:
             X = vec("f32")
             if p.prefilter and not keep_intermediates and p.low_dim in (64, 128, 256, 400) and bool((n_list == 1).any()):
                 Xpre = vec("f16")
-        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre)
+            if p.kmeans_prefilter and p.low_dim in (64, 128, 256, 400) and bool(((n_list > 1) & (n_list <= 128)).any()):
+                Xkm = Xpre if Xpre is not None else vec("f16")
+        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre, Xkm=Xkm)
         if keep_intermediates:
             sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
             nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,

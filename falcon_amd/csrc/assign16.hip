@@ -1,0 +1,258 @@
+// a6 with a float16 prefilter: k-means / final list assignment for buckets with <= 128 lists.
+//
+// The exact assignment (assign.hip) runs the fp32 matrix cores at 2 * d * n_list flop per row and iteration -- the largest
+// single cost of the IVF regime (10 M spectra: 11 passes x 1.02 TFLOP).  A row's list is the arg-max of its inner
+// products with the bucket's centroids; the arg-max only needs EXACT values where the two best are close.  So:
+//   1. assign16_kernel: float16 copies of the rows (fal_vectorize FAL_DTYPE_F16) against float16 copies of the
+//      centroids on the f16 matrix cores (float32 accumulation, 1/16 of the fp32 cycles): best and runner-up per row.
+//      |approx - exact| <= eps(v) = 1.3e-3 v + 2e-6 (bound derived in fused.hip): if runner-up < best - 2.2 eps(best) the
+//      approximate winner IS the exact arg-max and is written; otherwise the row goes to a list;
+//   2. assign_exact_rows_kernel: the listed rows (a few per cent) against all their centroids by the exact k-ordered
+//      fmaf chain (VALU, bit-identical to the matrix-core chain), arg-max with ties -> lowest id.
+// The assignment -- and with it every centroid, list and search result -- is IDENTICAL to the exact kernels'
+// (tests/test_gpu_search.py builds both and compares bit for bit).  Reference: README.md:132-136 (Faiss IVF train / add).
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <algorithm>
+#include "common.h"
+#include "ivf.h"
+#include "scan.h"
+#include "simtile.h"
+
+namespace fal {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr float kA16EpsRel = 1.3e-3f, kA16EpsAbs = 2e-6f;
+
+__global__ void cvt_f16_kernel(const float* __restrict__ in, __half* __restrict__ out, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+        reinterpret_cast<__half2*>(out)[2 * i] = a;
+        reinterpret_cast<__half2*>(out)[2 * i + 1] = b;
+    }
+}
+
+struct Assign16Args {
+    const __half* X16;       // [n, d] float16 rows (sorted order)
+    const __half* C16;       // [total_lists, d] float16 centroids
+    const AssignJob* jobs;   // (row segment) x (ALL lists of the bucket, <= 128)
+    int64_t n_jobs;
+    int32_t* assign;         // [n]
+    int32_t* amb_list;       // (row, job) pairs left to the exact kernel
+    int32_t* amb_count;
+    int amb_cap;
+};
+
+__device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
+
+template <int STEPS>
+__global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
+    constexpr int D = STEPS * 16, DH = D / 2;
+    constexpr int RB16 = D / 8;
+    constexpr int RS = D * 2 + 16;
+    constexpr int PIECES = 32 * RB16;
+    constexpr int kStage = (PIECES + 255) / 256;
+    constexpr int NB = STEPS < 4 ? STEPS : 4;
+    static_assert(kStage <= 7, "staging registers");
+    __shared__ __align__(16) unsigned char stage[2 * 32 * RS];
+    __shared__ float r_best[2][4][32];       // per chunk parity, wave, row: best / runner-up value and best id
+    __shared__ float r_second[2][4][32];
+    __shared__ int r_id[2][4][32];
+    const int64_t per_xcd = (a.n_jobs + 7) / 8;
+    const int64_t ji = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || ji >= a.n_jobs) return;
+    const AssignJob job = a.jobs[ji];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int nr = job.nrows;
+    const int ncw = min(32, job.ncent - 32 * w);                 // centroids of this wave's tile (<= 0: only helps staging)
+    half8 c16[STEPS];
+    {
+        const int cr = min(32 * w + min(r, max(ncw, 1) - 1), job.ncent - 1);
+        const half8* src = reinterpret_cast<const half8*>(a.C16 + (job.cent0 + cr) * (int64_t)D + h * DH);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) c16[s] = src[s];
+    }
+    const __half* rbase = a.X16 + job.row0 * (int64_t)D;
+    uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6;
+#define FAL_FOR_A(M) M(0, sa0) M(1, sa1) M(2, sa2) M(3, sa3) M(4, sa4) M(5, sa5) M(6, sa6)
+#define FAL_LOAD_ONE(I, R)                                                                             \
+    if constexpr (I < kStage) {                                                                        \
+        const int idx = min((int)threadIdx.x + 256 * I, PIECES - 1);                                   \
+        const int row = idx / RB16, col = idx - row * RB16;                                            \
+        R = reinterpret_cast<const uint4*>(rbase + (int64_t)min(stage_c0 + row, nr - 1) * D)[col];     \
+    }
+#define FAL_STORE_ONE(I, R)                                                                            \
+    if constexpr (I < kStage) {                                                                        \
+        const int idx = min((int)threadIdx.x + 256 * I, PIECES - 1);                                   \
+        const int row = idx / RB16, col = idx - row * RB16;                                            \
+        *reinterpret_cast<uint4*>(stage + (size_t)stage_buf * 32 * RS + row * RS + col * 16) = R;      \
+    }
+#define FAL_LOAD(C0) { const int stage_c0 = min((C0), nr - 1); FAL_FOR_A(FAL_LOAD_ONE) }
+#define FAL_STORE(BUF) { const int stage_buf = (BUF); FAL_FOR_A(FAL_STORE_ONE) }
+    // decision for the 32 rows of a finished chunk: lanes 0..31 of the duty wave combine the four waves' results
+    auto decide = [&](int par, int c0) {
+        if (lane >= 32 || c0 + lane >= nr) return;
+        float best = -INFINITY, second = -INFINITY;
+        int bid = 0x7fffffff;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float b = r_best[par][ww][lane], s2 = r_second[par][ww][lane];
+            const int id = r_id[par][ww][lane];
+            if (b > best || (b == best && id < bid)) {
+                second = fmaxf(second, best);
+                best = b;
+                bid = id;
+            } else {
+                second = fmaxf(second, b);
+            }
+            second = fmaxf(second, s2);
+        }
+        const int64_t row = job.row0 + c0 + lane;
+        const float eps = kA16EpsRel * best + kA16EpsAbs;
+        if (second < best - 2.2f * eps) {
+            a.assign[row] = job.id_base + bid;
+        } else {                                                     // too close to call in float16: exact re-evaluation
+            const int at = atomicAdd(a.amb_count, 1);
+            if (at < a.amb_cap) {
+                a.amb_list[2 * at] = (int32_t)row;
+                a.amb_list[2 * at + 1] = (int32_t)ji;
+            }
+        }
+    };
+    FAL_LOAD(0)
+    FAL_STORE(0)
+    FAL_LOAD(32)
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < nr; c0 += 32) {
+        const unsigned char* rowp = stage + (size_t)buf * 32 * RS + r * RS + h * DH * 2;
+        half8 rh[NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) rh[s] = *reinterpret_cast<const half8*>(rowp + s * 16);
+        __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const half8 rv = rh[s % NB];
+            if (s + NB < STEPS) rh[s % NB] = *reinterpret_cast<const half8*>(rowp + (s + NB) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c16[s], rv, acc, 0, 0, 0);      // D[centroid][row]: lane = row
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // this lane's row against its 16 centroids (of the wave's 32): best, runner-up
+        float best = -INFINITY, second = -INFINITY;
+        int bid = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ci = a16_rowoff(i) + 4 * h;
+            const float v = ci < ncw ? acc[i] : -INFINITY;
+            if (v > best) {                                          // (ids ascend with i: an equal later value is a runner-up)
+                second = best;
+                best = v;
+                bid = 32 * w + ci;
+            } else {
+                second = fmaxf(second, v);
+            }
+        }
+        {
+            const float ob = __shfl_xor(best, 32, 64), os = __shfl_xor(second, 32, 64);
+            const int oi = __shfl_xor(bid, 32, 64);
+            if (ob > best || (ob == best && oi < bid)) {
+                second = fmaxf(best, os);
+                best = ob;
+                bid = oi;
+            } else {
+                second = fmaxf(second, ob);
+            }
+        }
+        const int par = (c0 >> 5) & 1;
+        if (h == 0) {
+            r_best[par][w][r] = best;
+            r_second[par][w][r] = second;
+            r_id[par][w][r] = bid;
+        }
+        FAL_STORE(buf ^ 1)                       // chunk c0 + 32
+        FAL_LOAD(c0 + 64)
+        __syncthreads();
+        if (w == ((c0 >> 5) & 3)) decide(par, c0);                   // (the duty rotates over the waves)
+        buf ^= 1;
+    }
+#undef FAL_LOAD
+#undef FAL_STORE
+#undef FAL_LOAD_ONE
+#undef FAL_STORE_ONE
+#undef FAL_FOR_A
+}
+
+// the rows the prefilter could not decide: exact arg-max over all centroids of the bucket (<= 128: two per lane)
+__global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, const float* __restrict__ X, const float* __restrict__ Cn,
+                                                               int d) {
+    const int lane = threadIdx.x;
+    const int total = min(*a.amb_count, a.amb_cap);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int64_t row = a.amb_list[2 * t];
+        const AssignJob job = a.jobs[a.amb_list[2 * t + 1]];
+        float best = -INFINITY;
+        int bid = 0x7fffffff;
+        for (int c = lane; c < job.ncent; c += 64) {
+            const float s = exact_dot(X + row * d, Cn + (job.cent0 + c) * d, d);
+            if (s > best) {                                          // (ids ascend: ties keep the lowest)
+                best = s;
+                bid = c;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bid, off, 64);
+            if (ob > best || (ob == best && oi < bid)) {
+                best = ob;
+                bid = oi;
+            }
+        }
+        if (lane == 0) a.assign[row] = job.id_base + bid;
+    }
+}
+
+bool assign16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
+
+int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
+    if (count <= 0) return FAL_OK;
+    const int64_t n4 = count / 4;
+    hipLaunchKernelGGL(cvt_f16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n4, 256), (int64_t)ctx->num_cus * 16)), dim3(256), 0,
+                       ctx->stream, in, reinterpret_cast<__half*>(out), n4);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+// jobs: device table of `n_jobs` jobs, each covering ALL (<= 128) lists of its bucket
+int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
+                    const AssignJob* jobs, int64_t n_jobs, int32_t* assign) {
+    if (n_jobs <= 0) return FAL_OK;
+    int32_t* amb = nullptr;
+    const int amb_cap = 1 << 24;
+    FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(2 * amb_cap + 16), (void**)&amb));
+    FAL_CHECK_HIP(hipMemsetAsync(amb, 0, sizeof(int32_t) * 16, ctx->stream));
+    Assign16Args a{reinterpret_cast<const __half*>(X16), reinterpret_cast<const __half*>(C16), jobs, n_jobs, assign, amb + 16, amb, amb_cap};
+    const int64_t per_xcd = (n_jobs + 7) / 8;
+    StageScope ts(ctx, stage);
+    dim3 grid((unsigned)(per_xcd * 8)), block(256);
+    switch (d / 16) {
+        case 4: hipLaunchKernelGGL((assign16_kernel<4>), grid, block, 0, ctx->stream, a); break;
+        case 8: hipLaunchKernelGGL((assign16_kernel<8>), grid, block, 0, ctx->stream, a); break;
+        case 16: hipLaunchKernelGGL((assign16_kernel<16>), grid, block, 0, ctx->stream, a); break;
+        case 25: hipLaunchKernelGGL((assign16_kernel<25>), grid, block, 0, ctx->stream, a); break;
+        default: set_error("assign16: low_dim %d has no instantiation", d); return FAL_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(assign_exact_rows_kernel, dim3((unsigned)(ctx->num_cus * 16)), dim3(64), 0, ctx->stream, a, X, Cn, d);
+    FAL_CHECK_HIP(hipGetLastError());
+    if (!ctx->fb_host) FAL_CHECK_HIP(hipHostMalloc((void**)&ctx->fb_host, 64, hipHostMallocDefault));
+    FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 1, amb, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));   // counter(6'): last pass
+    return FAL_OK;
+}
+
+}  // namespace fal

@@ -74,49 +74,6 @@ __device__ __forceinline__ float bin_hi(int b) {
     return b < 128 ? (float)(b + 1) * (1.f / 512.f) : (b == kBins - 1 ? 1.0625f : 0.25f + (float)(b - 127) * (3.f / 128.f));
 }
 
-// the exact similarity on the vector ALU: the k-ordered fmaf chain of simtile.h, bit for bit
-__device__ __forceinline__ float exact_dot(const float* __restrict__ a, const float* __restrict__ b, int d) {
-    const int dh4 = d >> 3;
-    const float4* a4 = reinterpret_cast<const float4*>(a);
-    const float4* b4 = reinterpret_cast<const float4*>(b);
-    float acc = 0.f;
-    constexpr int U = 4;                       // 16 loads in flight per lane: the chain itself is latency-bound otherwise
-    int j = 0;
-    for (; j + U <= dh4; j += U) {
-        float4 al[U], ah[U], bl[U], bh[U];
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            al[t] = a4[j + t];
-            ah[t] = a4[dh4 + j + t];
-            bl[t] = b4[j + t];
-            bh[t] = b4[dh4 + j + t];
-        }
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            acc = __builtin_fmaf(al[t].x, bl[t].x, acc);
-            acc = __builtin_fmaf(ah[t].x, bh[t].x, acc);
-            acc = __builtin_fmaf(al[t].y, bl[t].y, acc);
-            acc = __builtin_fmaf(ah[t].y, bh[t].y, acc);
-            acc = __builtin_fmaf(al[t].z, bl[t].z, acc);
-            acc = __builtin_fmaf(ah[t].z, bh[t].z, acc);
-            acc = __builtin_fmaf(al[t].w, bl[t].w, acc);
-            acc = __builtin_fmaf(ah[t].w, bh[t].w, acc);
-        }
-    }
-    for (; j < dh4; ++j) {
-        const float4 al = a4[j], ah = a4[dh4 + j], bl = b4[j], bh = b4[dh4 + j];
-        acc = __builtin_fmaf(al.x, bl.x, acc);
-        acc = __builtin_fmaf(ah.x, bh.x, acc);
-        acc = __builtin_fmaf(al.y, bl.y, acc);
-        acc = __builtin_fmaf(ah.y, bh.y, acc);
-        acc = __builtin_fmaf(al.z, bl.z, acc);
-        acc = __builtin_fmaf(ah.z, bh.z, acc);
-        acc = __builtin_fmaf(al.w, bl.w, acc);
-        acc = __builtin_fmaf(ah.w, bh.w, acc);
-    }
-    return acc;
-}
-
 __device__ __forceinline__ bool find_job_xcd128f(const DenseJob* __restrict__ jobs, int n_jobs, unsigned bid,
                                                  int* job_index, int* local_tile) {
     const int x = bid & 7;

@@ -229,6 +229,11 @@ int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists) {
 
 int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const int64_t* bucket_off,
                   int64_t n_buckets, const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
+    return fal_ivf_build_x16(ctx, X, nullptr, n, low_dim, bucket_off, n_buckets, n_list, kmeans_iters, out);
+}
+
+int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, int low_dim, const int64_t* bucket_off,
+                      int64_t n_buckets, const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
     FAL_REQUIRE(ctx && out, FAL_EINVAL, "fal_ivf_build: NULL ctx/out");
     *out = nullptr;
     FAL_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "fal_ivf_build: n must be < 2^31 per partition");
@@ -337,8 +342,15 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
         for (const BucketDev& b : bk)
             if (!row_major && b.n_list <= 64) wave_rows += (int64_t)b.n * ceil_div(b.n_list, 32);
         const int64_t wseg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(wave_rows, (int64_t)ctx->num_cus * 16 * 32) * 32));
+        // buckets with <= 128 lists and float16 rows at hand: the prefiltered assignment (assign16.hip; identical results)
+        static const bool no_a16 = getenv("FALCON_NO_ASSIGN16") != nullptr;
+        const bool use16 = X16 != nullptr && assign16_supports(low_dim) && !no_a16 && !row_major;
+        std::vector<AssignJob> hjobs;
         for (const BucketDev& b : bk) {
-            if (!row_major && b.n_list <= 64) {
+            if (use16 && b.n_list <= kAssignGroup) {
+                for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg)
+                    hjobs.push_back({b.row0 + s0, b.list0, (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0), b.n_list, 0, 0});
+            } else if (!row_major && b.n_list <= 64) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += wseg)
                     for (int t0 = 0; t0 < b.n_list; t0 += 32)
                         wjobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(wseg, b.n - s0),
@@ -367,11 +379,26 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
             B_TRY(ctx->reserve(SLOT_JOBS, sizeof(DenseJob) * djobs.size(), (void**)&djobs_dev));
             B_TRY(ctx->upload(djobs_dev, djobs.data(), sizeof(DenseJob) * djobs.size()));
         }
+        AssignJob* hjobs_dev = nullptr;
+        void* C16 = nullptr;
+        if (!hjobs.empty()) {
+            B_TRY(ctx->reserve(SLOT_INV, sizeof(AssignJob) * hjobs.size(), (void**)&hjobs_dev));
+            B_TRY(ctx->upload(hjobs_dev, hjobs.data(), sizeof(AssignJob) * hjobs.size()));
+            B_TRY(ctx->reserve(SLOT_INVCNT, sizeof(uint16_t) * (size_t)total * low_dim + 64, &C16));
+        }
         for (int it = 0; it <= kmeans_iters; ++it) {
+            if (!hjobs.empty()) {
+                {
+                    StageScope ts(ctx, ST_BUILD);
+                    B_TRY(launch_cvt_f16(ctx, ivf->centroids, C16, total * low_dim));
+                }
+                B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, (int64_t)hjobs.size(), ivf->assign));
+            }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,
                                    dtiles, nullptr, 0, ivf->assign));
-            B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, n_wide, n_wave, n, keys, ivf->assign));
+            if (n_wide + n_wave > 0)
+                B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, n_wide, n_wave, n, keys, ivf->assign));
             if (it == kmeans_iters) break;   // final assignment against the final centroids
             StageScope ts(ctx, ST_BUILD);
             hipLaunchKernelGGL(list_walk_kernel<0>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign,

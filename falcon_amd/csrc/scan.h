@@ -64,6 +64,11 @@ struct AssignJob {
 // jobs[0, n_jobs): 4-wave jobs (<= 128 centroids each); jobs[n_jobs, n_jobs + n_wave_jobs): one-wave jobs (<= 32 centroids)
 int launch_assign(fal_ctx* ctx, int stage, const float* X, const float* centroids, int d, const AssignJob* jobs, int64_t n_jobs,
                   int64_t n_wave_jobs, int64_t n, unsigned long long* keys, int32_t* assign);
+// Assignment with a float16 prefilter (assign16.hip): jobs cover ALL lists of a bucket (<= 128); identical results
+bool assign16_supports(int d);
+int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count);
+int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
+                    const AssignJob* jobs, int64_t n_jobs, int32_t* assign);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order

@@ -114,10 +114,11 @@ class Context:
 
     # ------------------------------------------------------------------ a6 / a7
     def ivf_build(self, X, bucket_off: np.ndarray, n_list: np.ndarray, kmeans_iters: int = 10,
-                  X16=None, Xpre=None) -> "IvfIndex":
+                  X16=None, Xpre=None, Xkm=None) -> "IvfIndex":
         """X: float32 [n, d] (may be None when every bucket is flat and X16 is given);
         X16: optional float16 [n, d] (plain rows) or [n, 2, d] (hi/lo split) for the f16 flat scan;
-        Xpre: optional float16 [n, d] copy of X used only as the prefilter of `search_neighbors` (exact results)."""
+        Xpre: optional float16 [n, d] copy of X used only as the prefilter of `search_neighbors` (exact results);
+        Xkm: optional float16 [n, d] copy of X used as the prefilter of the k-means assignment (identical index)."""
         torch = _torch()
         if X is not None:
             assert X.dtype == torch.float32 and X.is_contiguous() and X.device == self.tdev
@@ -128,9 +129,12 @@ class Context:
         bo = np.ascontiguousarray(bucket_off, np.int64)
         nl = np.ascontiguousarray(n_list, np.int32)
         h = C.c_void_p()
-        check(self.lib.fal_ivf_build(self._h, self._p(X), n, d, bo.ctypes.data_as(C.c_void_p), len(nl),
-                                     nl.ctypes.data_as(C.c_void_p), int(kmeans_iters), C.byref(h)), "fal_ivf_build")
+        if Xkm is not None:
+            assert Xkm.dtype == torch.float16 and Xkm.is_contiguous() and Xkm.device == self.tdev and tuple(Xkm.shape) == (n, d)
+        check(self.lib.fal_ivf_build_x16(self._h, self._p(X), self._p(Xkm), n, d, bo.ctypes.data_as(C.c_void_p), len(nl),
+                                         nl.ctypes.data_as(C.c_void_p), int(kmeans_iters), C.byref(h)), "fal_ivf_build")
         index = IvfIndex(self, h, X, bo, nl, n, d)
+        index.Xkm = Xkm
         if X16 is not None:
             assert X16.dtype == torch.float16 and X16.is_contiguous() and X16.device == self.tdev
             planes = 2 if X16.dim() == 3 else 1

@@ -196,3 +196,24 @@ def test_search_neighbors_equals_search_then_filter(ctx, k_ann, keep, tol, mode,
     assert (e_idx >= 0).sum() > 0
     assert np.array_equal(g_idx, e_idx)
     assert np.array_equal(g_dist.view(np.uint32), e_dist.view(np.uint32))
+
+
+@pytest.mark.parametrize("sizes,nlists,d", [([3000], [64], 400), ([900, 40, 2500, 9000], [16, 1, 32, 128], 400),
+                                           ([5000, 2100], [100, 33], 128), ([2600], [32], 64)])
+def test_ivf_build_with_f16_prefilter_is_identical(ctx, sizes, nlists, d):
+    """a6 with the float16 prefilter (assign16.hip: arg-max on the f16 matrix cores, close calls re-evaluated exactly):
+    assignments, centroids and lists are bit-identical to the exact build -- and therefore to the oracle's."""
+    import torch
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    X = unit_vectors(off[-1], d, 13)
+    X[50:60] = X[50]                                     # duplicates: exact ties between rows, equal sims to every centroid
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    exact = ctx.ivf_build(Xd, off, np.array(nlists, np.int32), kmeans_iters=5)
+    pre = ctx.ivf_build(Xd, off, np.array(nlists, np.int32), kmeans_iters=5, Xkm=Xd.to(torch.float16).contiguous())
+    for a, b in zip(exact.export(), pre.export()):
+        assert torch.equal(a, b)
+    C, ra, rperm, roff = fo.ivf_build(X[off[-2]:off[-1]], nlists[-1], 5)
+    cent, asg, perm, loff = [t.cpu().numpy() for t in pre.export()]
+    assert np.array_equal(asg[off[-2]:off[-1]], ra)
+    lb = np.concatenate([[0], np.cumsum(nlists)])
+    assert np.array_equal(cent[lb[-2]:lb[-1]], C)
