@@ -85,19 +85,38 @@ __global__ __launch_bounds__(64) void list_walk_kernel(const float* __restrict__
             cnt += __popcll(mask);
         } else {
             cnt += __popcll(mask);
+            // members are added IN ROW ORDER (the sum must not depend on scheduling), but their rows are fetched four at
+            // a time: one member per memory round trip made this kernel half of the k-means time
             while (mask) {
-                const int j = __ffsll((unsigned long long)mask) - 1;
-                mask &= mask - 1;
-                const float4* row = reinterpret_cast<const float4*>(X + (b.row0 + r0 + j) * d);
+                constexpr int G = 4;
+                int js[G];
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const int e = 64 * p + lane;        // float4 index
-                    if (p < passes && e < d / 4) {
-                        const float4 v = row[e];
-                        acc[p].x += v.x;
-                        acc[p].y += v.y;
-                        acc[p].z += v.z;
-                        acc[p].w += v.w;
+                for (int t = 0; t < G; ++t) {
+                    js[t] = mask ? __ffsll((unsigned long long)mask) - 1 : -1;       // (mask is wave-uniform)
+                    if (mask) mask &= mask - 1;
+                }
+                float4 v[G][P];
+#pragma unroll
+                for (int t = 0; t < G; ++t) {
+                    const float4* row = reinterpret_cast<const float4*>(X + (b.row0 + r0 + max(js[t], 0)) * d);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const int e = 64 * p + lane;    // float4 index
+                        v[t][p] = (js[t] >= 0 && p < passes && e < d / 4) ? row[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < G; ++t) {
+                    if (js[t] < 0) continue;            // (-0.0 + 0.0 would flip a sign bit: skip, do not add zeros)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const int e = 64 * p + lane;
+                        if (p < passes && e < d / 4) {
+                            acc[p].x += v[t][p].x;
+                            acc[p].y += v[t][p].y;
+                            acc[p].z += v[t][p].z;
+                            acc[p].w += v[t][p].w;
+                        }
                     }
                 }
             }

@@ -15,6 +15,10 @@ import sys
 
 GROUPS = {  # kernel-name substring -> stage key
     "vectorize_kernel": "vectorize", "dense_kernel": "scan", "scan16_kernel": "scan", "ivf_list_kernel": "scan",
+    "ivf_list4_kernel": "scan", "approx_kernel": "prefilter_approx", "band_kernel": "prefilter_band",
+    "resolve_kernel": "prefilter_resolve", "fused_fallback_kernel": "prefilter_fallback",
+    "assign16_kernel": "kmeans_assign16", "assign_exact_rows": "kmeans_exact_rows", "assign_kernel": "kmeans_assign",
+    "list_walk_kernel": "kmeans_update",
     "select_kernel": "select", "filter_kernel": "filter", "dbscan_core": "dbscan_core", "dbscan_edges": "dbscan_edges",
     "refine_kernel": "refine", "medoid_score": "medoid_score",
 }
@@ -48,13 +52,13 @@ def _counter(db_path, counter):
     return out
 
 
-def pmc(fetch_db, write_db, passes, out_json):
+def pmc(fetch_db, write_db, passes, out_json, cmd="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"):
     fetch = _counter(fetch_db, "FETCH_SIZE")
     write = _counter(write_db, "WRITE_SIZE")
-    res = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py "
-                    f"--steps 3 --warmup 1 --no-cpu-baseline` ({passes} passes of the hot path incl. the per-stage timing pass); "
-                    "figures are PER STEP (one pass over 1,000,000 spectra) and per launch. Counters are KiB; FETCH_SIZE is "
-                    "doubled as MI355X_MICROARCH.md prescribes for gfx950."}
+    res = {"_note": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `{cmd}` "
+                    f"({passes} passes of the hot path: priming, warmup, timed steps, the per-stage timing pass and the "
+                    "host-to-host steps); figures are PER STEP (one pass over 1,000,000 spectra) and per launch. Counters are KiB; "
+                    "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950."}
     for key in fetch:
         launches, fb = fetch[key]
         wb = write.get(key, [0, 0.0])[1]
@@ -71,4 +75,4 @@ if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
+        pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5], *sys.argv[6:7])
