@@ -54,10 +54,13 @@ __global__ void probe_hist_kernel(const int32_t* __restrict__ probes, int np, co
 
 // tiles of a list = 32-row slices of the LIST (each streams all queries probing the list); a list
 // nobody probes needs none
+// ... restricted to the lists with lo < rows <= hi (the short lists take the one-wave kernel, the others the 4-wave one)
 __global__ void list_tiles_kernel(const int32_t* __restrict__ cnt, const int64_t* __restrict__ list_off, int64_t n,
-                                  int shift, int32_t* __restrict__ tiles) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        tiles[i] = cnt[i] > 0 ? (int32_t)((list_off[i + 1] - list_off[i] + (1 << shift) - 1) >> shift) : 0;
+                                  int shift, int64_t lo, int64_t hi, int32_t* __restrict__ tiles) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rows = list_off[i + 1] - list_off[i];
+        tiles[i] = (cnt[i] > 0 && rows > lo && rows <= hi) ? (int32_t)((rows + (1 << shift) - 1) >> shift) : 0;
+    }
 }
 
 // inv_q[e] = query position, inv_dest[e] = where that query's sims for this list start
@@ -399,14 +402,24 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     // fine-scan tiles: groups of four 32-row list slices for the 4-wave shared-stream kernel (ivf_fine.hip)
     static const bool single_wave = getenv("FALCON_FINE_SINGLEWAVE") != nullptr;      // the one-wave-per-slice form (A/B runs)
     const int group_shift = single_wave ? 5 : 7;
+    // Hybrid (opt-in, FALCON_FINE_SHORT_ROWS = r): lists of <= r rows -- which fill at most r / 32 of the 4-wave kernel's waves
+    // while its 100 kB of stream buffers keep a second workgroup off the CU -- take the one-wave kernel (no LDS, four independent
+    // workgroups per CU), the longer ones the shared-stream kernel.  Measured at 10 M spectra: fine scan 173.2 ms (off),
+    // 174.5 (r = 64), 192.6 (r = 96): the idle waves are not what bounds the kernel; kept for A/B runs only.
+    static const int64_t short_rows = [] {
+        const char* e = getenv("FALCON_FINE_SHORT_ROWS");
+        return e ? (int64_t)atoll(e) : (int64_t)0;
+    }();
+    const bool hybrid = !single_wave && short_rows > 0;
     // ---- inverted probe table (list -> queries probing it) ------------------------------------
     const int64_t TL = ivf->total_lists;
     const int64_t n_pairs_max = ivf->n * (int64_t)np;
     int32_t *cnt = nullptr, *inv_q = nullptr;
     int64_t *inv_off = nullptr, *inv_dest = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_INVCNT, sizeof(int32_t) * (size_t)(3 * TL + 3) + sizeof(int64_t) * (size_t)(2 * TL + 4), (void**)&inv_off));
+    FAL_TRY(ctx->reserve(SLOT_INVCNT, sizeof(int32_t) * (size_t)(3 * TL + 3) + sizeof(int64_t) * (size_t)(3 * TL + 6), (void**)&inv_off));
     int64_t* ltile_off = inv_off + (TL + 2);
-    cnt = reinterpret_cast<int32_t*>(ltile_off + (TL + 2));
+    int64_t* stile_off = ltile_off + (TL + 2);            // tiles of the short lists (one-wave kernel)
+    cnt = reinterpret_cast<int32_t*>(stile_off + (TL + 2));
     int32_t* cursor = cnt + (TL + 1);
     int32_t* ltiles = cursor + (TL + 1);
     FAL_TRY(ctx->reserve(SLOT_INV, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)n_pairs_max + 64, (void**)&inv_dest));
@@ -418,18 +431,25 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         hipLaunchKernelGGL(probe_hist_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
                            ivf_tiles, cnt);
         FAL_TRY(device_scan_i32(ctx, cnt, TL, inv_off, SLOT_MISC2));
-        hipLaunchKernelGGL(list_tiles_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024)), dim3(256), 0, st,
-                           cnt, ivf->list_off, TL, group_shift, ltiles);
+        const dim3 tg((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024));
+        hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, group_shift,
+                           hybrid ? short_rows : (int64_t)0, (int64_t)1 << 40, ltiles);
         FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
+        if (hybrid) {
+            hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, 5, (int64_t)0, short_rows, ltiles);
+            FAL_TRY(device_scan_i32(ctx, ltiles, TL, stile_off, SLOT_MISC2));
+        }
         hipLaunchKernelGGL(probe_scatter_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
                            ivf_tiles, ivf->list_off, q_sim_off, inv_off, cursor, inv_q, inv_dest);
     }
     FAL_CHECK_HIP(hipGetLastError());
     // per-tile sims prefix and per-list tile prefix back to the host to cut bucket-sized batches
-    std::vector<int64_t> qoff((size_t)ivf_tiles + 1), lt_host((size_t)TL + 1);
+    std::vector<int64_t> qoff((size_t)ivf_tiles + 1), lt_host((size_t)TL + 1), st_host(hybrid ? (size_t)TL + 1 : 0);
     FAL_CHECK_HIP(hipMemcpy2DAsync(qoff.data(), sizeof(int64_t), q_sim_off, 32 * sizeof(int64_t), sizeof(int64_t),
                                    (size_t)ivf_tiles + 1, hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipMemcpyAsync(lt_host.data(), ltile_off, sizeof(int64_t) * (size_t)(TL + 1), hipMemcpyDeviceToHost, st));
+    if (hybrid)
+        FAL_CHECK_HIP(hipMemcpyAsync(st_host.data(), stile_off, sizeof(int64_t) * (size_t)(TL + 1), hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipStreamSynchronize(st));
     // batches of whole IVF buckets (every list of a bucket touches queries all over the bucket)
     struct IvfBatch { size_t j0, j1; };
@@ -464,6 +484,13 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
         la.sims = sims; la.sims_base = base; la.sink = sims + need_fine;
         FAL_TRY(launch_list_scan(ctx, la));
+        if (hybrid) {                                            // the short lists of the same buckets
+            la.ltile_off = stile_off;
+            la.group_shift = 5;
+            la.tile_begin = st_host[(size_t)L0];
+            la.n_tiles_max = st_host[(size_t)L1] - st_host[(size_t)L0];
+            FAL_TRY(launch_list_scan(ctx, la));
+        }
         SelectArgs sa{};
         sa.sims = sims; sa.sims_base = base; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size(); sa.tile_begin = t0;

@@ -120,3 +120,39 @@ def test_main_with_rescore_option(tmp_path):
     for lab in outs.values():
         assert len(lab) == 1500 and np.array_equal(np.unique(lab), np.arange(lab.max() + 1))
     assert len(np.unique(outs["rescored"])) != len(np.unique(outs["plain"])) or not np.array_equal(outs["rescored"], outs["plain"])
+
+
+def test_main_hierarchical_clustering_option(tmp_path):
+    """`--clustering hierarchical --linkage average` (the snapshot's own clustering, cluster.py:283-290, on the re-scored graph)
+    through main(): same clustering as the oracle's run of those stages; a linkage with the default DBSCAN is refused."""
+    from falcon_amd import synth
+    from falcon_amd.falcon import main
+    from falcon_amd.ms_io import ms_io
+    d = synth.generate(3000, seed=33, mz_lo=500.0, mz_hi=515.0)
+    specs = []
+    for i in range(3000):
+        a, b = d["indptr"][i], d["indptr"][i + 1]
+        specs.append({"identifier": f"scan={i}", "precursor_mz": float(d["precursor_mz"][i]),
+                      "precursor_charge": int(d["precursor_charge"][i]), "retention_time": float(d["retention_time"][i]),
+                      "mz": d["mz"][a:b].astype(np.float64), "intensity": d["intensity"][a:b]})
+    mgf = str(tmp_path / "in.mgf")
+    ms_io.write_spectra(mgf, specs)
+    out = str(tmp_path / "res")
+    base = [mgf, out, "--eps", "0.35", "--remove_precursor_tol", "0.0", "--min_intensity", "0.0", "--min_matched_peaks", "4",
+            "--work_dir", str(tmp_path / "work")]
+    with pytest.raises(ValueError, match="only applies to the hierarchical"):
+        main(base + ["--linkage", "average"])
+    assert main(base + ["--overwrite", "--clustering", "hierarchical", "--linkage", "average"]) == 0
+    lines = open(out + ".csv").read().splitlines()
+    assert "# clustering = hierarchical" in lines and "# linkage = average" in lines
+    body = [l.split(",") for l in lines if not l.startswith("#")][1:]
+    lab = np.array([int(r[5]) for r in body])
+    charge = np.array([int(r[2]) for r in body])
+    for c in (2, 3):
+        sel = synth.select_charge(d, c)
+        ref, _ = fo.generate_clusters(sel["mz"], sel["intensity"], sel["indptr"], sel["precursor_mz"], None, eps=0.35,
+                                      clustering="hierarchical", linkage="average", min_matches=4)
+        got = lab[sel["rows"]]
+        pairs = np.unique(np.stack([ref, got]), axis=1)
+        assert pairs.shape[1] == len(np.unique(ref)) == len(np.unique(got))          # the same partition
+    assert (np.bincount(lab) > 1).sum() > 30

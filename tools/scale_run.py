@@ -6,12 +6,12 @@ N = int(sys.argv[1]); scan = sys.argv[2] if len(sys.argv) > 2 else "f32"
 n_probe = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"
 low_dim = int(sys.argv[5]) if len(sys.argv) > 5 else 400
-t = time.time(); data = synth.generate(N); print(f"generated {N} in {time.time()-t:.1f}s", flush=True)
 ctx = dv.Context(0); pipe = ClusterPipeline(ctx)
+t = time.time(); data = synth.generate_device(N, ctx.tdev); print(f"generated {N} in {time.time()-t:.1f}s", flush=True)
 p = AnnParams(scan=scan, n_probe=n_probe, dtype=dtype, low_dim=low_dim)
 parts = []
 for ch in (2, 3):
-    c = synth.select_charge(data, ch)
+    c = synth.select_charge_device(data, ch)
     parts.append(SpectrumDataset(*[ctx.to_dev(c[k], torch.float32) for k in ("precursor_mz", "retention_time", "mz", "intensity")], ctx.to_dev(c["indptr"], torch.int64)))
 del data
 for rep in range(2):
