@@ -46,6 +46,7 @@ _SIGNATURES = {
     "fal_ivf_build_x16": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, P(c_void_p)], c_int),
     "fal_ivf_attach_f16": ([c_void_p, c_void_p, c_int], c_int),
     "fal_ivf_attach_prefilter": ([c_void_p, c_void_p], c_int),
+    "fal_ivf_attach_prefilter_ex": ([c_void_p, c_void_p, c_int], c_int),
     "fal_ivf_destroy": ([c_void_p], c_int),
     "fal_ivf_total_lists": ([c_void_p, P(c_int64)], c_int),
     "fal_ivf_export": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),

@@ -44,6 +44,9 @@ class AnnParams:
                                   # refinement, fused.hip); results are bit-identical with and without it.  Off by default:
                                   # at BASELINE configs[1]'s bucket sizes (<= ~1,100 rows) it is on par with the staged
                                   # scan + select, it pays on larger flat buckets
+    ivf_prefilter: bool = True    # float32 buckets with an index: fine scan on the f16 matrix cores to 16-bit keys, the k-th best
+                                  # key of every query bracketed from them, exact float32 work only inside the precursor
+                                  # window and where it decides the k-th key (ivf16.hip); bit-identical neighbour lists
     kmeans_prefilter: bool = True # IVF buckets with <= 128 lists: k-means assignment on the f16 matrix cores, rows whose two
                                   # best centroids are closer than the float16 error bound re-evaluated exactly in float32
                                   # (assign16.hip): the index is identical, the build several times faster
@@ -150,6 +153,7 @@ class ClusterPipeline:
         vec = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
                                      p.hash_seed, True, dt)
         X = X16 = Xpre = Xkm = None
+        which = 0
         if p.dtype == "f16":
             X16 = vec("f16")
         elif p.scan == "f16x3":
@@ -158,11 +162,16 @@ class ClusterPipeline:
                 X = vec("f32")              # k-means, coarse quantiser and IVF fine scan stay exact fp32
         else:
             X = vec("f32")
-            if p.prefilter and not keep_intermediates and p.low_dim in (64, 128, 256, 400) and bool((n_list == 1).any()):
-                Xpre = vec("f16")
-            if p.kmeans_prefilter and p.low_dim in (64, 128, 256, 400) and bool(((n_list > 1) & (n_list <= 128)).any()):
-                Xkm = Xpre if Xpre is not None else vec("f16")
-        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre, Xkm=Xkm)
+            ok16 = p.low_dim in (64, 128, 256, 400)
+            if p.prefilter and not keep_intermediates and ok16 and bool((n_list == 1).any()):
+                which |= 1
+            if p.ivf_prefilter and not keep_intermediates and ok16 and bool((n_list > 1).any()):
+                which |= 2
+            if p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 128)).any()):
+                Xkm = vec("f16")
+            if which:
+                Xpre = Xkm if Xkm is not None else vec("f16")
+        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre, Xkm=Xkm, prefilter_which=max(which, 1))
         if keep_intermediates:
             sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
             nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,
@@ -196,7 +205,7 @@ class ClusterPipeline:
             # production: a9..a12 fused, counts stay on the device, one synchronisation
             labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
                                                     precursor_tol_mode, rt_tol, order, linkage=hier)
-            last = dict(nb_idx=nb_idx, nb_dist=nb_dist, nb_count=st["nb_count"], order=order)   # the sparse graph (exchange)
+            last = dict(nb_idx=nb_idx, nb_dist=nb_dist, nb_count=st["nb_count"], order=order, n_list=st["n_list"])   # the sparse graph (exchange)
             index.close()
         return labels, medoids, last
 

@@ -48,11 +48,27 @@ struct FusedArgs {
     int32_t* fb_count;
     int fb_cap;
     int dbg;                     // FALCON_FUSED_DBG: experiment bits (results invalid when set)
+    // IVF buckets (ivf16.hip): the candidates of a query are the rows of its probed lists; thr / gmem_* come from
+    // select16_kernel instead of approx_kernel
+    int ivf;                     // 1: jobs32 are IVF buckets (c_row0 = global id of the bucket's list 0)
+    const int32_t* assign;       // [n] bucket-local list of every sorted row
+    const int32_t* pos_of_row;   // [n] sorted row -> list-order position
+    const int32_t* probes;       // [n, n_probe] by list-order position (-1 = none)
+    int n_probe;
+    int mask_words;              // 32-bit words of one query's probe mask (>= max n_list / 32)
+    const float* Xl;             // rows in list order (exact fallback)
+    const int64_t* list_off;     // [total_lists + 1]
+    const int32_t* perm;         // [n] list-order position -> sorted row
 };
 
 bool fused_supports(int d);
 // n_rows = rows of the index (the hand-off buffers are indexed by sorted row); list_tiles* = tiles of the longest XCD list
 int launch_fused(fal_ctx* ctx, const FusedArgs& a, int d, int64_t n_rows, int64_t list_tiles128, int64_t list_tiles32,
                  int max_nc);
+// IVF buckets: hand-off buffers and the fallback list (before select16_kernel runs), then the exact tail --
+// band_kernel over the precursor windows (candidates outside the query's probed lists masked out), resolve_kernel, and the
+// exact fallback over the probed lists.  max_cand = upper bound of the candidates of one query.
+int fused_prepare(fal_ctx* ctx, FusedArgs* a, int64_t n_rows);
+int launch_fused_ivf_tail(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32, int64_t max_cand);
 
 }  // namespace fal

@@ -398,12 +398,15 @@ __global__ __launch_bounds__(256, 2) void approx_kernel(FusedArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // band_kernel: one wave = 32 queries of one bucket; exact similarities of the precursor window on the fp32 matrix cores
 // ------------------------------------------------------------------------------------------------------------
-template <int DH4>
+// IVF = true (ivf16.hip): the bucket has an index; a window candidate only counts if its list is one of the query's probed
+// lists (a bit mask per query in LDS, built from the probe table), thresholds come from select16_kernel for every query
+template <int DH4, bool IVF>
 __global__ __launch_bounds__(64, 1) void band_kernel(FusedArgs a) {
     constexpr int D = DH4 * 8, DH = D / 2;
     constexpr int kStride = FAL_FUSED_KEEP + 1;               // dwords per query row of the kept lists (odd: conflict-free)
     __shared__ uint32_t kept_u[32 * kStride];
     __shared__ uint32_t kept_id[32 * kStride];
+    extern __shared__ uint32_t pmask[];                       // IVF: [32][mask_words] probed lists of the tile's queries
     int ji, lt;
     if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
@@ -412,9 +415,22 @@ __global__ __launch_bounds__(64, 1) void band_kernel(FusedArgs a) {
     const int64_t row0 = job.q_row0;
     const int qbase = 32 * lt;
     const int nqw = min(32, nc - qbase);
-    const bool need_thr = nc > a.k;
+    const bool need_thr = IVF || nc > a.k;
     const int dh4 = DH4;
     const float* X = a.X;
+    const int W = a.mask_words;
+    if constexpr (IVF) {
+        for (int e = threadIdx.x; e < 32 * W; e += 64) pmask[e] = 0u;
+        __syncthreads();
+        if (r < nqw) {
+            const int64_t p = a.pos_of_row[row0 + qbase + r];
+            for (int j = h; j < a.n_probe; j += 2) {
+                const int l = a.probes[p * a.n_probe + j];
+                if (l >= 0) atomicOr(&pmask[r * W + (l >> 5)], 1u << (l & 31));
+            }
+        }
+        __syncthreads();
+    }
     float qf[DH4 * 4];
     load_half_row<DH4>(qf, X + (row0 + qbase + min(r, nqw - 1)) * D + (int64_t)h * DH, dh4);
     const float* pm = a.pmz + row0;
@@ -480,11 +496,13 @@ __global__ __launch_bounds__(64, 1) void band_kernel(FusedArgs a) {
         const float* nxt = crow(c0 + 32);
         // candidate metadata of this lane's 16 rows: issued before the MFMA chain, used after it
         float nmz[16], nrt[16];
+        int nls[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cc = min(c0 + rowoff16(i) + 4 * h, nc - 1);
             nmz[i] = pm[cc];
             nrt[i] = use_rt ? rtp[cc] : 0.f;
+            nls[i] = IVF ? a.assign[row0 + cc] : 0;
         }
         const f32x16 acc = cs.template dot<false>(qf, cur, nxt, dh4, [] {});
         cur = nxt;
@@ -497,6 +515,7 @@ __global__ __launch_bounds__(64, 1) void band_kernel(FusedArgs a) {
             bool ok = fabsf(x) <= tol_f;
             if (use_rt) ok = ok && fabsf(qrt - nrt[i]) <= rt_f;
             ok = ok && c < whi && qvalid && c != qbase + ql;
+            if constexpr (IVF) ok = ok && ((pmask[ql * W + (nls[i] >> 5)] >> (nls[i] & 31)) & 1u) != 0u;
             if (ok && s >= Lq) {                             // below L: certainly not among the k best
                 const bool amb = s <= Uq;                    // inside [L, U]: decided exactly by resolve_kernel
                 if (kc < kKeepHalf) {
@@ -545,7 +564,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const int nc = job.nc, k = a.k;
     const int64_t row0 = job.q_row0;
     const int nqw = min(32, nc - 32 * lt);
-    const bool need_thr = nc > k;
+    const bool need_thr = a.ivf || nc > k;
     for (int ql = w; ql < nqw; ql += 4) {
         const int64_t row = row0 + 32 * lt + ql;
         // every load of the common path is issued before the first use (one memory round trip, not four)
@@ -661,6 +680,56 @@ __global__ __launch_bounds__(64) void fused_fallback_kernel(FusedArgs a, SelectA
     }
 }
 
+// the same for a query of an IVF bucket: the exact similarities of the rows of its probed lists, in the order of the staged
+// path's sims segment (probe order, list order inside), then the staged path's MODE_IVF selection
+__global__ __launch_bounds__(64) void ivf_fallback_kernel(FusedArgs a, SelectArgs sa, float* __restrict__ scratch,
+                                                          int64_t scratch_stride, int d) {
+    __shared__ uint32_t sel_u[kSelBuf];
+    __shared__ uint32_t sel_id[kSelBuf];
+    __shared__ int64_t seg_off[FAL_MAX_N_PROBE + 1];
+    __shared__ int64_t seg_src[FAL_MAX_N_PROBE];
+    const int lane = threadIdx.x;
+    const int total = min(*a.fb_count, a.fb_cap);
+    float* row_s = scratch + (int64_t)blockIdx.x * scratch_stride;
+    const int np = a.n_probe;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int64_t row = a.fb_list[2 * t];
+        const DenseJob job = a.jobs32[a.fb_list[2 * t + 1]];
+        const int32_t* pr = a.probes + (int64_t)a.pos_of_row[row] * np;
+        if (lane == 0) {
+            int64_t off = 0;
+            for (int j = 0; j < np; ++j) {
+                const int32_t l = pr[j];
+                seg_off[j] = off;
+                seg_src[j] = 0;
+                if (l >= 0) {
+                    const int64_t b = a.list_off[job.c_row0 + l], e = a.list_off[job.c_row0 + l + 1];
+                    seg_src[j] = b;
+                    off += e - b;
+                }
+            }
+            seg_off[np] = off;
+        }
+        __syncthreads();
+        const int64_t nc = min<int64_t>(seg_off[np], scratch_stride - (int64_t)kSimsSlack);
+        const float* qp = a.X + row * d;
+        for (int j = 0; j < np; ++j) {
+            const int64_t o = seg_off[j], len = min<int64_t>(seg_off[j + 1], nc) - o;
+            for (int64_t i = lane; i < len; i += 64) row_s[o + i] = exact_dot(qp, a.Xl + (seg_src[j] + i) * d, d);
+        }
+        __threadfence();
+        __syncthreads();
+        SelQuery qy{row_s, nc, 0};
+        int carry;
+        if (nc <= 128) carry = select_rounds<MODE_IVF, 2>(sa, qy, sa.k, lane, sel_u, sel_id, seg_off, seg_src);
+        else if (nc <= 256) carry = select_rounds<MODE_IVF, 4>(sa, qy, sa.k, lane, sel_u, sel_id, seg_off, seg_src);
+        else if (nc <= 512) carry = select_rounds<MODE_IVF, 8>(sa, qy, sa.k, lane, sel_u, sel_id, seg_off, seg_src);
+        else carry = select_rounds<MODE_IVF, 16>(sa, qy, sa.k, lane, sel_u, sel_id, seg_off, seg_src);
+        filter_sort_store(sa, sel_u, sel_id, sel_u + FAL_MAX_K_ANN, sel_id + FAL_MAX_K_ANN, carry, row, lane);
+        __syncthreads();
+    }
+}
+
 // largest float32 y >= 0 with (double)y * scale <= tol (-1 when there is none): the float32 form of the tolerance tests
 static float float_le_bound(double tol, double scale) {
     if (!(tol >= 0.0)) return -1.f;
@@ -676,16 +745,12 @@ static float float_le_bound(double tol, double scale) {
     return y;
 }
 
-int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int64_t list_tiles128, int64_t list_tiles32,
-                 int max_nc) {
-    if (a_in.n_jobs32 <= 0 || list_tiles32 <= 0) return FAL_OK;
-    FusedArgs a = a_in;
+int fused_prepare(fal_ctx* ctx, FusedArgs* ap, int64_t n_rows) {
+    FusedArgs& a = *ap;
     {
         const char* e = getenv("FALCON_FUSED_DBG");
         a.dbg = e ? atoi(e) : 0;
     }
-    FAL_REQUIRE(list_tiles32 * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
-    FAL_REQUIRE(max_nc < 65536, FAL_EUNSUPPORTED, "fused scan: buckets must hold fewer than 65,536 rows");
     a.tol_f = float_le_bound(a.tol, a.is_da ? 1.0 : 1e6);
     a.rt_f = float_le_bound(a.rt_tol, 1.0);
     // hand-off buffers, indexed by sorted row
@@ -699,20 +764,73 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
     a.gkept_id = a.gkept_u + n_rows * FAL_FUSED_KEEP;
     a.gkcnt = reinterpret_cast<int32_t*>(a.gkept_id + n_rows * FAL_FUSED_KEEP);
     ctx->counters[6] = (int64_t)(uintptr_t)hand;            // (debug tools read the hand-off buffers)
-    ctx->counters[7] = n_rows;
-    // fallback list + its scratch rows
-    const int fb_grid = ctx->num_cus * 16;
-    const int64_t stride = (((int64_t)max_nc + 63) & ~63ll) + (int64_t)kSimsSlack;
+    // fallback list
     int32_t* fb = nullptr;
-    float* scratch = nullptr;
     const int fb_cap = 1 << 22;
     FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(2 * fb_cap + 16), (void**)&fb));
-    FAL_TRY(ctx->reserve(SLOT_FUSED2, sizeof(float) * (size_t)fb_grid * (size_t)stride, (void**)&scratch));
     a.fb_count = fb;
     ctx->counters[7] = (int64_t)(uintptr_t)fb;              // (debug tools: fallback count + reason counters)
     a.fb_list = fb + 16;
     a.fb_cap = fb_cap;
     FAL_CHECK_HIP(hipMemsetAsync(fb, 0, sizeof(int32_t) * 16, ctx->stream));
+    if (!ctx->fb_host) {
+        FAL_CHECK_HIP(hipHostMalloc((void**)&ctx->fb_host, 64, hipHostMallocDefault));
+        memset(ctx->fb_host, 0, 64);
+    }
+    return FAL_OK;
+}
+
+int launch_fused_ivf_tail(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32, int64_t max_cand) {
+    if (a.n_jobs32 <= 0 || list_tiles32 <= 0) return FAL_OK;
+    FAL_REQUIRE(list_tiles32 * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
+    const int steps = d / 16;
+    {
+        StageScope ts(ctx, ST_SCAN);
+        dim3 grid((unsigned)(list_tiles32 * 8)), block(64);
+        const size_t lds = sizeof(uint32_t) * 32 * (size_t)a.mask_words;
+        switch (steps) {
+            case 4: hipLaunchKernelGGL((band_kernel<8, true>), grid, block, lds, ctx->stream, a); break;
+            case 8: hipLaunchKernelGGL((band_kernel<16, true>), grid, block, lds, ctx->stream, a); break;
+            case 16: hipLaunchKernelGGL((band_kernel<32, true>), grid, block, lds, ctx->stream, a); break;
+            case 25: hipLaunchKernelGGL((band_kernel<50, true>), grid, block, lds, ctx->stream, a); break;
+            default:
+                set_error("IVF prefilter: low_dim %d has no instantiation (64, 128, 256, 400)", d);
+                return FAL_EUNSUPPORTED;
+        }
+        FAL_CHECK_HIP(hipGetLastError());
+    }
+    StageScope ts(ctx, ST_SELECT);
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
+    FAL_CHECK_HIP(hipGetLastError());
+    // exact fallback over the probed lists
+    const int64_t stride = ((max_cand + 63) & ~63ll) + (int64_t)kSimsSlack;
+    const int fb_grid = (int)std::max<int64_t>(64, std::min<int64_t>(ctx->num_cus * 16, ((int64_t)1 << 28) / stride));
+    float* scratch = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_FUSED2, sizeof(float) * (size_t)fb_grid * (size_t)stride, (void**)&scratch));
+    SelectArgs sa{};
+    sa.k = a.k;
+    sa.n_probe = a.n_probe; sa.perm = a.perm;
+    sa.f_pmz = a.pmz; sa.f_rt = a.rt; sa.f_tol = a.tol; sa.f_rt_tol = a.rt_tol; sa.f_is_da = a.is_da;
+    sa.f_keep = a.keep; sa.nb_idx = a.nb_idx; sa.nb_dist = a.nb_dist; sa.nb_count = a.nb_count;
+    hipLaunchKernelGGL(ivf_fallback_kernel, dim3((unsigned)fb_grid), dim3(64), 0, ctx->stream, a, sa, scratch, stride, d);
+    FAL_CHECK_HIP(hipGetLastError());
+    FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 2, a.fb_count, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return FAL_OK;
+}
+
+int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int64_t list_tiles128, int64_t list_tiles32,
+                 int max_nc) {
+    if (a_in.n_jobs32 <= 0 || list_tiles32 <= 0) return FAL_OK;
+    FusedArgs a = a_in;
+    FAL_REQUIRE(list_tiles32 * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
+    FAL_REQUIRE(max_nc < 65536, FAL_EUNSUPPORTED, "fused scan: buckets must hold fewer than 65,536 rows");
+    FAL_TRY(fused_prepare(ctx, &a, n_rows));
+    int32_t* fb = a.fb_count;
+    // scratch rows of the fallback
+    const int fb_grid = ctx->num_cus * 16;
+    const int64_t stride = (((int64_t)max_nc + 63) & ~63ll) + (int64_t)kSimsSlack;
+    float* scratch = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_FUSED2, sizeof(float) * (size_t)fb_grid * (size_t)stride, (void**)&scratch));
     const int steps = d / 16;
     static const bool split = getenv("FALCON_FUSED_SPLIT_TIMERS") != nullptr;
     if (split) { ctx->stage_reset(ST_BUILD); ctx->stage_reset(ST_FILTER); }
@@ -744,10 +862,10 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
         StageScope ts(ctx, ST_SCAN);
         dim3 grid((unsigned)(list_tiles32 * 8)), block(64);
         switch (steps) {
-            case 4: hipLaunchKernelGGL((band_kernel<8>), grid, block, 0, ctx->stream, a); break;
-            case 8: hipLaunchKernelGGL((band_kernel<16>), grid, block, 0, ctx->stream, a); break;
-            case 16: hipLaunchKernelGGL((band_kernel<32>), grid, block, 0, ctx->stream, a); break;
-            case 25: hipLaunchKernelGGL((band_kernel<50>), grid, block, 0, ctx->stream, a); break;
+            case 4: hipLaunchKernelGGL((band_kernel<8, false>), grid, block, 0, ctx->stream, a); break;
+            case 8: hipLaunchKernelGGL((band_kernel<16, false>), grid, block, 0, ctx->stream, a); break;
+            case 16: hipLaunchKernelGGL((band_kernel<32, false>), grid, block, 0, ctx->stream, a); break;
+            case 25: hipLaunchKernelGGL((band_kernel<50, false>), grid, block, 0, ctx->stream, a); break;
             default: return FAL_EUNSUPPORTED;
         }
         FAL_CHECK_HIP(hipGetLastError());
@@ -767,7 +885,6 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
         FAL_CHECK_HIP(hipGetLastError());
     }
     // the number of fallback queries of this call: fal_ctx_counter(5) after a sync (pinned target: truly asynchronous)
-    if (!ctx->fb_host) FAL_CHECK_HIP(hipHostMalloc((void**)&ctx->fb_host, 64, hipHostMallocDefault));
     FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host, fb, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     return FAL_OK;
 }

@@ -11,6 +11,7 @@
 #include "common.h"
 #include "scan.h"
 #include "ivf.h"
+#include "ivf16.h"
 
 namespace fal {
 
@@ -212,7 +213,8 @@ extern "C" {
 
 int fal_ivf_destroy(fal_ivf* ivf) {
     if (!ivf) return FAL_OK;
-    void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev};
+    void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
+                    ivf->Xl16, ivf->pos_of_row};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -233,10 +235,21 @@ int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes) {
     return FAL_OK;
 }
 
-int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16) {
+int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16) { return fal_ivf_attach_prefilter_ex(ivf, X16, 1); }
+
+int fal_ivf_attach_prefilter_ex(fal_ivf* ivf, const void* X16, int which) {
     FAL_REQUIRE(ivf && X16, FAL_EINVAL, "fal_ivf_attach_prefilter: NULL argument");
     FAL_REQUIRE(ivf->X, FAL_EINVAL, "fal_ivf_attach_prefilter: the index has no float32 rows to refine with");
-    ivf->Xpre = X16;
+    FAL_REQUIRE(which >= 1 && which <= 3, FAL_EINVAL, "fal_ivf_attach_prefilter_ex: which must be 1 (flat buckets), 2 (IVF buckets) or 3");
+    if (which & 1) ivf->Xpre = X16;
+    if ((which & 2) && ivf->n_ivf_buckets > 0 && !ivf->Xl16) {
+        FAL_REQUIRE(ivf16_supports(ivf->d), FAL_EUNSUPPORTED,
+                    "fal_ivf_attach_prefilter_ex: the IVF prefilter is instantiated for low_dim 64, 128, 256, 400 (got %d)", ivf->d);
+        fal_ctx* ctx = ivf->ctx;
+        FAL_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)ivf->n * ivf->d, &ivf->Xl16));
+        FAL_TRY(ctx->pool_alloc(sizeof(int32_t) * (size_t)ivf->n, (void**)&ivf->pos_of_row));
+        FAL_TRY(launch_gather16(ctx, X16, ivf->perm, ivf->n, ivf->d, ivf->Xl16, ivf->pos_of_row));
+    }
     return FAL_OK;
 }
 

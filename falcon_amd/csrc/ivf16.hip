@@ -1,0 +1,407 @@
+// a7 + a8 for IVF buckets with a float16 prefilter: the fine scan on the f16 matrix cores, the exact work only where it
+// decides something.  Output BIT-IDENTICAL to the staged path (ivf_fine.hip + select_kernel<MODE_IVF, true>).
+//
+// The staged path computes the exact float32 similarity of every (query, probed-list row) pair on the fp32 matrix cores
+// (16 passes per k-pair: the dominant cost at 10 M spectra) and selects the k_ann best per query.  What the neighbour lists
+// need is (i) the exact similarities of the few candidates inside the query's precursor window and (ii) the k_ann-th best
+// key of the query, to decide which of them are among the k_ann best.  So:
+//
+//   list16_kernel   list-major like ivf_list4_kernel -- a 4-wave workgroup keeps up to 128 rows of ONE list resident, the
+//      queries probing the list stream through LDS (global_load_lds, double-buffered) -- but on float16 copies of the rows
+//      with v_mfma_f32_32x32x16_f16 (1/16 of the matrix-pipe cycles).  Every approximate similarity leaves as a 16-bit
+//      fixed-point key (round(v * 65535): half the bytes of a float, finer than float16 above 0.016) into the query's
+//      segment, laid out exactly like the staged path's sims.
+//   select16_kernel   one wave per query: all keys of the query in registers, the k_ann-th largest key T~ by a bitwise search
+//      with ballot counts; |key / 65535 - exact| <= e(T~) (bound below) puts the exact k_ann-th best value inside
+//      [T~ - e, T~ + e].  Out: the thresholds, how many keys lie certainly above, and the few candidates within 2e of T~
+//      ("members": the only ones whose exact value can decide the k_ann-th key).
+//   band_kernel<., IVF> / resolve_kernel / ivf_fallback_kernel (fused.hip)   exact similarities of the precursor window on the
+//      fp32 matrix cores (candidates outside the query's probed lists masked out), ambiguous candidates against the exact
+//      k_ann-th key, sort, neighbour lists; queries the hand-off cannot hold take the exact fallback.
+//
+// Error bound: |approx - exact| <= 1.3e-3 * approx + 2e-6 (fused.hip), the key adds 0.5 / 65535 + rounding < 7.7e-6:
+//   |key / 65535 - exact| <= e(v) = 1.3e-3 * v + 1.2e-5.
+// With T~ the k-th largest key value: at least k candidates have exact >= T~ - e(T~) and at least N - k + 1 have
+// exact <= T~ + e(T~), so the exact k-th best value lies in [L, U] = [T~ - e, T~ + e]; a key above T~ + 2e (+ the growth of e
+// over that distance, one key unit of slack) is certainly above U, one below T~ - 2e certainly below L.
+//
+// Reference: README.md:107-113, 137-142 (n_probe lists per query, n_neighbors_ann neighbours, precursor filter); faiss
+// IndexIVFFlat is a dependency of the reference, not in the snapshot.
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+#include "common.h"
+#include "scan.h"
+#include "ivf.h"
+#include "fused.h"
+#include "ivf16.h"
+
+namespace fal {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define FAL_GLDS16(gptr, lptr)                                                                        \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ uint16_t key16(float v) {
+    return (uint16_t)__float2uint_rn(__builtin_amdgcn_fmed3f(v, 0.f, 1.f) * 65535.f);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// list16_kernel: tile = (one inverted list, 128 of its rows); see ivf_list4_kernel for the structure
+// ------------------------------------------------------------------------------------------------------------
+template <int STEPS>
+__global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
+    constexpr int D = STEPS * 16, DH = D / 2;
+    constexpr int NB = STEPS < 4 ? STEPS : 4;             // LDS operand reads in flight ahead of the MFMAs
+    __shared__ uint4 sbuf0[STEPS * 64];                   // [step][lane]: MFMA-operand order, conflict-free 16-byte reads
+    __shared__ uint4 sbuf1[STEPS * 64];
+    const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
+    const int64_t lt = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd) return;
+    const int64_t t = a.tile_begin + lt;
+    if (t >= a.ltile_off[a.list_end]) return;
+    int64_t lo = a.list_begin, hi = a.list_end - 1;       // last list with ltile_off <= t
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (a.ltile_off[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int64_t L = lo;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int slice = 4 * (int)(t - a.ltile_off[L]) + w;  // this wave's 32-row slice of the list
+    const int64_t l_row0 = a.list_off[L];
+    const int l_rows = (int)(a.list_off[L + 1] - l_row0);
+    const int nrow = min(32, l_rows - 32 * slice);        // rows of this slice (<= 0: the wave only helps loading)
+    const int64_t e0 = a.inv_off[L];
+    const int nq = (int)(a.inv_off[L + 1] - e0);          // queries probing the list
+    if (nq <= 0 || l_rows <= 0) return;
+    const bool active = nrow > 0;
+
+    half8 q[STEPS];                                        // the resident operand: list row 32*slice + r, k-half h
+    {
+        const int64_t rr = l_row0 + min(32 * slice + min(r, max(nrow, 1) - 1), l_rows - 1);
+        const half8* src = reinterpret_cast<const half8*>(a.Xl16 + rr * D + h * DH);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) q[s] = src[s];
+    }
+    const int pos = 32 * slice + r;                        // position inside the list = offset inside a query's segment
+    const bool rvalid = active && r < nrow;
+
+    auto q_row = [&](int c0) -> int32_t { return a.inv_q[e0 + min(c0 + r, nq - 1)]; };
+    auto q_dest = [&](int c0) -> int64_t { return a.inv_dest[e0 + min(c0 + r, nq - 1)]; };
+    // the first USE of a prefetched value must sit behind the next barrier (ivf_list4_kernel)
+    auto pin = [](int32_t& x, int64_t& y) { asm volatile("" : "+v"(x), "+v"(y)); };
+    auto issue = [&](int32_t row, uint4* buf) {
+        const uint4* rowp = reinterpret_cast<const uint4*>(a.Xl16 + (int64_t)row * D + h * DH);
+#pragma unroll
+        for (int jj = 0; jj < (STEPS + 3) / 4; ++jj) {
+            const int j = 4 * jj + w;
+            if (j < STEPS) FAL_GLDS16(rowp + j, buf + j * 64);
+        }
+    };
+    f32x16 prev;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) prev[i] = 0.f;
+    int prev_c0 = 0;
+    uint32_t dest_prev = (uint32_t)(q_dest(0) - a.keys_base);
+    // D[query][list row]: lane = list row (column), registers = 16 streamed queries; every store instruction writes 32
+    // consecutive keys of ONE query's segment for this list
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qr = mfma32_row(i, h);
+            const uint32_t dest = (uint32_t)__shfl((int)dest_prev, qr, 64);      // lane qr holds query prev_c0 + qr
+            uint16_t* p = (rvalid && prev_c0 + qr < nq) ? a.keys + dest + pos : a.sink + lane;
+            *p = key16(prev[i]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x040, 16, 0);
+    };
+    auto compute = [&](const uint4* buf, int c0) {
+        constexpr int kMid = STEPS / 2;
+        const half8* sb = reinterpret_cast<const half8*>(buf) + lane;
+        half8 ring[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) ring[j] = sb[j * 64];
+        __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);      // the whole ring in front of the first MFMA (fused.hip)
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const half8 ch = ring[s % NB];
+            if (s + NB < STEPS) ring[s % NB] = sb[(s + NB) * 64];
+            // streamed queries are the A operand, the resident list rows B: D[query][list row]
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, q[s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (s == kMid) epilogue();
+        }
+        asm volatile("s_nop 15" : "+a"(acc));              // MFMA -> accumulator read behind a taken branch (simtile.h)
+        prev = acc;
+        prev_c0 = c0;
+    };
+
+    issue(q_row(0), sbuf0);
+    int32_t row_next = q_row(32);
+    int64_t dest_raw = q_dest(0);            // of the chunk whose epilogue runs next
+    for (int c0 = 0; c0 < nq; c0 += 64) {
+        {
+            __syncthreads();      // chunk c0 has landed; sbuf1 is free again
+            pin(row_next, dest_raw);
+            if (c0 + 32 < nq) issue(row_next, sbuf1);
+            dest_prev = (uint32_t)(dest_raw - a.keys_base);
+            row_next = q_row(c0 + 64);
+            dest_raw = q_dest(c0);
+            if (active) compute(sbuf0, c0);
+        }
+        if (c0 + 32 >= nq) break;
+        {
+            __syncthreads();
+            pin(row_next, dest_raw);
+            if (c0 + 64 < nq) issue(row_next, sbuf0);
+            dest_prev = (uint32_t)(dest_raw - a.keys_base);
+            row_next = q_row(c0 + 96);
+            dest_raw = q_dest(c0 + 32);
+            if (active) compute(sbuf1, c0 + 32);
+        }
+    }
+    if (active) {
+        dest_prev = (uint32_t)(dest_raw - a.keys_base);
+        epilogue();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// select16_kernel: one wave per query (4 per workgroup)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wcount(bool p) { return __popcll(__ballot(p)); }
+
+struct Sel16Out {
+    uint32_t T;          // k-th largest key + 1
+    int delta_e, delta;  // e and the member half-width, in key units
+    int n_hi;            // keys above T + delta
+    int n_mem;           // keys within delta of T
+};
+
+template <int R>
+__device__ __forceinline__ void select16_body(const Select16Args& a, const uint16_t* __restrict__ row, int nc, int k, int lane,
+                                              const int32_t* seg_off, const int64_t* seg_src, int64_t out_row, int64_t row0) {
+    uint32_t u[R];
+    {
+        const uint16_t* rl = row + lane;
+        uint16_t raw[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) raw[i] = rl[i * 64];           // unclamped: the buffer has kSimsSlack floats of slack
+#pragma unroll
+        for (int i = 0; i < R; ++i) u[i] = (i * 64 + lane < nc) ? (uint32_t)raw[i] + 1u : 0u;
+    }
+    // largest T with count(key >= T) >= k; on an early exit (a threshold that splits off exactly k keys) the k-th largest
+    // key itself is the smallest key >= T
+    uint32_t T = 0;
+    bool early = false;
+    for (int bit = 16; bit >= 0; --bit) {
+        const uint32_t c = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) cnt += wcount(u[i] >= c);
+        if (cnt >= k) T = c;
+        if (cnt == k) {
+            early = true;
+            break;
+        }
+    }
+    if (early) {
+        uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < R; ++i) m = min(m, u[i] >= T ? u[i] : 0xFFFFFFFFu);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        T = m;
+    }
+    const float Tv = (float)(T - 1u) * (1.f / 65535.f);
+    const float e = 1.3e-3f * Tv + 1.2e-5f;
+    const int delta_e = (int)ceilf(e * 65535.f) + 1;
+    const int delta = 2 * delta_e + 2;
+    int n_hi = 0, n_mem = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        n_hi += wcount(u[i] > T + (uint32_t)delta);
+        const int df = (int)u[i] - (int)T;
+        n_mem += wcount(u[i] != 0u && df <= delta && df >= -delta);
+    }
+    QThr t;
+    t.T = Tv;
+    t.L = ((float)(T - 1u) - (float)delta_e) * (1.f / 65535.f);
+    t.U = ((float)(T - 1u) + (float)delta_e) * (1.f / 65535.f);
+    t.eps = 0.5f * ((float)delta + 0.5f) * (1.f / 65535.f);     // resolve_kernel: members are |v - T| <= 2 eps
+    t.bstar = 1 << 30;                                           // (no histogram bins here: nothing "above the bin")
+    t.nabove = n_hi;
+    t.flags = 0;
+    if (n_mem > FAL_FUSED_MEM) {
+        t.flags = 2;                                             // e.g. hundreds of identical spectra: exact fallback
+        n_mem = 0;
+    }
+    t.mc = min(n_mem, FAL_FUSED_MEM / 2) | (max(n_mem - FAL_FUSED_MEM / 2, 0) << 16);
+    if (lane == 0) a.thr[out_row] = t;
+    if (n_mem == 0) return;
+    float* gv = a.gmem_v + out_row * FAL_FUSED_MEM;
+    uint32_t* gi = a.gmem_id + out_row * FAL_FUSED_MEM;
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        const int df = (int)u[i] - (int)T;
+        const bool in = u[i] != 0u && df <= delta && df >= -delta;
+        const unsigned long long mask = __ballot(in);
+        if (mask) {                                              // wave-uniform
+            if (in) {
+                const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                const int pp = i * 64 + lane;
+                int lo = 0, hi = a.n_probe - 1;                  // last segment with seg_off <= pp
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
+                }
+                const uint32_t id = (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])];
+                gv[slot] = (float)(u[i] - 1u) * (1.f / 65535.f);
+                gi[slot] = id - (uint32_t)row0;
+            }
+            base += __popcll(mask);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
+    __shared__ int32_t seg_off_all[4][FAL_MAX_N_PROBE + 1];
+    __shared__ int64_t seg_src_all[4][FAL_MAX_N_PROBE];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int32_t* seg_off = seg_off_all[w];
+    int64_t* seg_src = seg_src_all[w];
+    const int64_t tl = blockIdx.x >> 3;
+    const int64_t t = a.tile_begin + tl;
+    const int ql = (int)((blockIdx.x & 7) << 2) + w;
+    const DenseJob job = a.jobs[a.tile_job[tl]];
+    const int lt = (int)(t - job.tile0);
+    if (32 * lt + ql >= job.nq) return;                     // (whole wave; no workgroup barriers below)
+    const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;   // query position in list order
+    const int np = a.n_probe, k = a.k;
+    const int32_t* pr = a.probes + p * np;
+    const int64_t lbase = job.c_row0;                        // global id of the bucket's list 0
+    int64_t run = 0;
+    for (int j0 = 0; j0 < np; j0 += 64) {                    // stream offset of every probed list: wave prefix sum
+        const int j = j0 + lane;
+        const int32_t l = j < np ? pr[j] : -1;
+        int64_t b = 0, e = 0;
+        if (l >= 0) {
+            b = a.list_off[lbase + l];
+            e = a.list_off[lbase + l + 1];
+        }
+        const int len = (int)(e - b);
+        int incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (j < np) {
+            seg_off[j] = (int32_t)(run + incl - len);
+            seg_src[j] = b;
+        }
+        run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) seg_off[np] = (int32_t)run;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int nc = (int)run;
+    const int64_t out_row = a.perm[p];
+    if (nc <= k) {                                           // every candidate is among the k best
+        if (lane == 0) {
+            QThr t0;
+            t0.L = t0.U = -INFINITY;
+            t0.T = 0.f; t0.eps = 0.f; t0.bstar = 1 << 30; t0.nabove = 0; t0.mc = 0; t0.flags = 0;
+            a.thr[out_row] = t0;
+        }
+        return;
+    }
+    const uint16_t* row = a.keys + (a.q_sim_off[32 * t + ql] - a.keys_base);
+    const int64_t row0 = job.q_row0;                         // the bucket's first sorted row (== first list-order position)
+    if (nc <= 512) select16_body<8>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
+    else if (nc <= 1024) select16_body<16>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
+    else if (nc <= 1536) select16_body<24>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
+    else if (nc <= 2048) select16_body<32>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
+    else if (nc <= 4096) select16_body<64>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
+    else if (lane == 0) {                                    // more keys than the registers hold: exact fallback
+        QThr t0;
+        t0.L = t0.U = -INFINITY;
+        t0.T = 0.f; t0.eps = 0.f; t0.bstar = 1 << 30; t0.nabove = 0; t0.mc = 0; t0.flags = 2;
+        a.thr[out_row] = t0;
+    }
+}
+
+__global__ void tile_job16_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t tile_begin, int64_t n_tiles,
+                                  int32_t* __restrict__ tile_job) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n_tiles) tile_job[i] = find_job(jobs, n_jobs, tile_begin + i);
+}
+
+// Xl16[p] = X16[perm[p]], pos_of_row[perm[p]] = p   (one wave per row, 16 B per lane)
+__global__ __launch_bounds__(256) void gather_rows16_kernel(const __half* __restrict__ X16, const int32_t* __restrict__ perm,
+                                                            int64_t n, int d, __half* __restrict__ out,
+                                                            int32_t* __restrict__ pos_of_row) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = blockIdx.x * 4ll + (threadIdx.x >> 6); p < n; p += (int64_t)gridDim.x * 4) {
+        const int64_t src = perm[p];
+        const uint4* s = reinterpret_cast<const uint4*>(X16 + src * d);
+        uint4* o = reinterpret_cast<uint4*>(out + p * d);
+        for (int e = lane; e < d / 8; e += 64) o[e] = s[e];
+        if (lane == 0) pos_of_row[src] = (int32_t)p;
+    }
+}
+
+bool ivf16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
+
+int launch_gather16(fal_ctx* ctx, const void* X16, const int32_t* perm, int64_t n, int d, void* out, int32_t* pos_of_row) {
+    if (n <= 0) return FAL_OK;
+    StageScope ts(ctx, ST_BUILD);
+    hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), ctx->num_cus * 16)), dim3(256), 0,
+                       ctx->stream, reinterpret_cast<const __half*>(X16), perm, n, d, reinterpret_cast<__half*>(out), pos_of_row);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+int launch_list16(fal_ctx* ctx, const List16Args& a) {
+    if (a.n_tiles_max <= 0) return FAL_OK;
+    const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
+    FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
+    dim3 grid((unsigned)(per_xcd * 8)), block(256);
+    StageScope ts(ctx, ST_SCAN);
+    switch (a.d / 16) {
+        case 4: hipLaunchKernelGGL((list16_kernel<4>), grid, block, 0, ctx->stream, a); break;
+        case 8: hipLaunchKernelGGL((list16_kernel<8>), grid, block, 0, ctx->stream, a); break;
+        case 16: hipLaunchKernelGGL((list16_kernel<16>), grid, block, 0, ctx->stream, a); break;
+        case 25: hipLaunchKernelGGL((list16_kernel<25>), grid, block, 0, ctx->stream, a); break;
+        default:
+            set_error("IVF prefilter: low_dim %d has no instantiation (64, 128, 256, 400)", a.d);
+            return FAL_EUNSUPPORTED;
+    }
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+int launch_select16(fal_ctx* ctx, const Select16Args& a_in, int64_t n_tiles) {
+    if (n_tiles <= 0) return FAL_OK;
+    Select16Args a = a_in;
+    int32_t* tj = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)std::max<int64_t>(n_tiles, 1 << 16), (void**)&tj));
+    StageScope ts(ctx, ST_SELECT);
+    hipLaunchKernelGGL(tile_job16_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
+                       a.tile_begin, n_tiles, tj);
+    a.tile_job = tj;
+    FAL_REQUIRE(n_tiles * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
+    hipLaunchKernelGGL(select16_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+}  // namespace fal

@@ -13,6 +13,7 @@
 #include "ivf.h"
 #include "util.h"
 #include "fused.h"
+#include "ivf16.h"
 
 namespace fal {
 
@@ -136,6 +137,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     ctx->stage_reset(ST_COARSE);
     ctx->stage_reset(ST_SCAN);
     ctx->stage_reset(ST_SELECT);
+    if (ctx->fb_host) ctx->fb_host[0] = ctx->fb_host[2] = 0;      // fallback queries of this call (fal_ctx_counter 5)
     const size_t cap = sims_capacity_floats();
 
     // ---- job tables ------------------------------------------------------------------------
@@ -472,6 +474,56 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     ctx->counters[2] += (int64_t)ivf_batches.size();
     ctx->counters[3] = std::max<int64_t>(ctx->counters[3], (int64_t)(sizeof(float) * need_fine));
     FAL_REQUIRE(need_fine + kSimsSlack < ((size_t)1 << 32), FAL_EUNSUPPORTED, "sims batch too large (lower FALCON_SIMS_MB)");
+    // ---- C'. fine scan with the float16 prefilter (ivf16.hip): f16-MFMA scan to 16-bit keys, k-th key per query, exact tail
+    static const bool no_ivf16 = getenv("FALCON_NO_IVF16") != nullptr;
+    if (nf && ivf->Xl16 && ivf->pos_of_row && ivf->X && ivf16_supports(d) && !no_ivf16 && group_shift == 7 && !hybrid) {
+        // the IVF buckets in sorted-row order, 32-query tiles, sorted by decreasing size and dealt to the 8 XCD lists
+        std::vector<size_t> ord(coarse.size());
+        for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) { return coarse[x].nq > coarse[y].nq; });
+        std::vector<DenseJob> j32(coarse.size());
+        int64_t xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (size_t j = 0; j < ord.size(); ++j) {
+            const DenseJob& cj = coarse[ord[j]];
+            const int x = (int)(j & 7);
+            j32[j] = {cj.q_row0, cj.c_row0, 0, 0, cj.nq, cj.nq, xt32[x]};
+            xt32[x] += ceil_div(cj.nq, 32);
+        }
+        DenseJob* jd = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_JOBS3, sizeof(DenseJob) * j32.size(), (void**)&jd));
+        FAL_TRY(ctx->upload(jd, j32.data(), sizeof(DenseJob) * j32.size()));
+        FusedArgs fa{};
+        fa.X = ivf->X; fa.jobs32 = jd; fa.n_jobs32 = (int)j32.size();
+        fa.k = k_ann; fa.pmz = nf->pmz; fa.rt = nf->rt; fa.tol = nf->tol; fa.rt_tol = nf->rt_tol; fa.is_da = nf->is_da;
+        fa.keep = nf->keep; fa.nb_idx = nf->nb_idx; fa.nb_dist = nf->nb_dist; fa.nb_count = nf->nb_count;
+        fa.ivf = 1; fa.assign = ivf->assign; fa.pos_of_row = ivf->pos_of_row; fa.probes = probes; fa.n_probe = np;
+        fa.mask_words = (max_n_list + 31) / 32; fa.Xl = ivf->Xl; fa.list_off = ivf->list_off; fa.perm = ivf->perm;
+        FAL_TRY(fused_prepare(ctx, &fa, ivf->n));
+        uint16_t* keys = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(uint16_t) * (need_fine + 2 * kSimsSlack), (void**)&keys));
+        int64_t max_cand = 0;
+        for (int64_t t = 0; t < ivf_tiles; ++t) max_cand = std::max(max_cand, qoff[(size_t)t + 1] - qoff[(size_t)t]);
+        for (const IvfBatch& bt : ivf_batches) {
+            const DenseJob &first = coarse[bt.j0], &last = coarse[bt.j1 - 1];
+            const int64_t t0 = first.tile0, t1 = last.tile0 + ceil_div(last.nq, 32);
+            const int64_t L0 = first.c_row0, L1 = last.c_row0 + last.nc;
+            const int64_t base = qoff[(size_t)t0];
+            List16Args la{};
+            la.Xl16 = reinterpret_cast<const __half*>(ivf->Xl16); la.d = d; la.list_off = ivf->list_off; la.inv_off = inv_off;
+            la.ltile_off = ltile_off; la.inv_q = inv_q; la.inv_dest = inv_dest; la.list_begin = L0; la.list_end = L1;
+            la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
+            la.keys = keys; la.keys_base = base; la.sink = keys + need_fine;
+            FAL_TRY(launch_list16(ctx, la));
+            Select16Args sa{};
+            sa.keys = keys; sa.keys_base = base; sa.k = k_ann; sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size();
+            sa.tile_begin = t0; sa.n_probe = np; sa.probes = probes; sa.list_off = ivf->list_off; sa.q_sim_off = q_sim_off;
+            sa.perm = ivf->perm; sa.thr = fa.thr; sa.gmem_v = fa.gmem_v; sa.gmem_id = fa.gmem_id;
+            FAL_TRY(launch_select16(ctx, sa, t1 - t0));
+        }
+        FAL_TRY(launch_fused_ivf_tail(ctx, fa, d, *std::max_element(xt32, xt32 + 8), max_cand));
+        FAL_CHECK_HIP(hipStreamSynchronize(st));
+        return FAL_OK;
+    }
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (need_fine + kSimsSlack), (void**)&sims));
     for (const IvfBatch& bt : ivf_batches) {
         const DenseJob &first = coarse[bt.j0], &last = coarse[bt.j1 - 1];

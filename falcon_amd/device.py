@@ -114,10 +114,11 @@ class Context:
 
     # ------------------------------------------------------------------ a6 / a7
     def ivf_build(self, X, bucket_off: np.ndarray, n_list: np.ndarray, kmeans_iters: int = 10,
-                  X16=None, Xpre=None, Xkm=None) -> "IvfIndex":
+                  X16=None, Xpre=None, Xkm=None, prefilter_which: int = 1) -> "IvfIndex":
         """X: float32 [n, d] (may be None when every bucket is flat and X16 is given);
         X16: optional float16 [n, d] (plain rows) or [n, 2, d] (hi/lo split) for the f16 flat scan;
         Xpre: optional float16 [n, d] copy of X used only as the prefilter of `search_neighbors` (exact results);
+        prefilter_which: where Xpre is used: 1 = flat buckets (fused.hip), 2 = buckets with an index (ivf16.hip), 3 = both;
         Xkm: optional float16 [n, d] copy of X used as the prefilter of the k-means assignment (identical index)."""
         torch = _torch()
         if X is not None:
@@ -142,7 +143,7 @@ class Context:
             index.X16 = X16
         if Xpre is not None:
             assert Xpre.dtype == torch.float16 and Xpre.is_contiguous() and Xpre.device == self.tdev and Xpre.shape == (n, d)
-            check(self.lib.fal_ivf_attach_prefilter(h, self._p(Xpre)), "fal_ivf_attach_prefilter")
+            check(self.lib.fal_ivf_attach_prefilter_ex(h, self._p(Xpre), int(prefilter_which)), "fal_ivf_attach_prefilter_ex")
             index.Xpre = Xpre
         return index
 

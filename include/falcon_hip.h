@@ -138,6 +138,13 @@ int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes);
  * [n, candidates] similarity matrix never exists in HBM.  low_dim in {64, 128, 256, 400}; other sizes
  * ignore the prefilter.  fal_ivf_search_topk never uses it.  The buffer is borrowed. ------------ [dev] */
 int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16);
+/* The same with a choice of where the prefilter is used: which & 1 = flat buckets (as above), which & 2 = buckets
+ * with an index: their fine scan runs on the f16 matrix cores over a float16 copy of the rows in list order
+ * (made here, owned by the index; X16 itself is only read during this call for that part), the k-th best key
+ * of every query is bracketed from 16-bit keys, and the exact float32 work is limited to the precursor window
+ * and to the candidates that can decide the k-th key.  BIT-IDENTICAL neighbour lists.  Reference: faiss
+ * IndexIVFFlat.search as called by falcon/cluster/cluster.py:212-225 (dependency, not in the snapshot). [dev] */
+int fal_ivf_attach_prefilter_ex(fal_ivf* ivf, const void* X16, int which);
 int fal_ivf_destroy(fal_ivf* ivf);
 int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists);
 /* Copy the index out for inspection (any pointer may be NULL): centroids

@@ -1,0 +1,104 @@
+"""The IVF fine scan with the float16 prefilter (ivf16.hip: f16-MFMA list scan to 16-bit keys, k-th key per query from the keys,
+exact float32 refinement of the precursor window, exact fallback) must give BIT-IDENTICAL neighbour lists to the staged path
+(`fal_ivf_search_topk` -> `fal_filter_neighbors`: fp32-MFMA fine scan + wavefront select), which test_gpu_search.py /
+test_gpu_regimes.py pin to the oracle."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_search import unit_vectors
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from falcon_amd.device import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _staged_and_prefiltered(ctx, X, off, nl, mz, rt, n_probe, k_ann, keep, tol, mode, rt_tol):
+    import torch
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    mz_d = torch.from_numpy(mz).to(ctx.tdev)
+    rt_d = None if rt is None else torch.from_numpy(rt).to(ctx.tdev)
+    plain = ctx.ivf_build(Xd, off, nl)
+    sim, idx = plain.search(n_probe, k_ann)
+    e_idx, e_dist = ctx.filter_neighbors(sim, idx, mz_d, rt_d, tol, mode, rt_tol, keep)
+    pre = ctx.ivf_build(Xd, off, nl, Xpre=Xd.to(torch.float16).contiguous(), prefilter_which=2)
+    g_idx, g_dist = pre.search_neighbors(n_probe, k_ann, mz_d, rt_d, tol, mode, rt_tol, keep)
+    cnt = pre.nb_count.cpu().numpy()
+    ctx.sync()
+    n_fallback = ctx.counter(5)
+    e_idx, e_dist, g_idx, g_dist = (t.cpu().numpy() for t in (e_idx, e_dist, g_idx, g_dist))
+    bad = np.flatnonzero((g_idx != e_idx).any(1) | (g_dist.view(np.uint32) != e_dist.view(np.uint32)).any(1))
+    assert len(bad) == 0, (len(bad), bad[:10], g_idx[bad[0]][:12], e_idx[bad[0]][:12], g_dist[bad[0]][:6], e_dist[bad[0]][:6])
+    assert np.array_equal(cnt, (e_idx >= 0).sum(1))
+    return e_idx, n_fallback
+
+
+def _buckets(sizes, d, seed, mz0=500.0, width=1.0):
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(off[-1])
+    X = unit_vectors(n, d, seed, noise=0.35)
+    rng = np.random.default_rng(seed + 1)
+    mz = np.concatenate([np.sort(mz0 + b + width * rng.random(s)) for b, s in enumerate(sizes)]).astype(np.float32)
+    rt = (rng.random(n) * 100).astype(np.float32)
+    return off, X, mz, rt
+
+
+@pytest.mark.parametrize("d,n_probe,k_ann,keep,tol,mode,rt_tol", [
+    (400, 16, 128, 64, 20.0, "ppm", None),        # the production setting (BASELINE configs[2] regime)
+    (400, 16, 128, 64, 20.0, "ppm", 30.0),        # + retention time tolerance
+    (400, 8, 32, 8, 60.0, "ppm", None),           # small k: the threshold cuts deep into the window
+    (400, 16, 128, 64, 0.05, "Da", None),         # Da: wide windows
+    (400, 32, 200, 100, 20.0, "ppm", None),       # k_ann > 128, more probes
+    (64, 16, 64, 16, 20.0, "ppm", None), (128, 16, 128, 64, 20.0, "ppm", None), (256, 12, 100, 50, 20.0, "ppm", None),
+])
+def test_ivf_prefilter_neighbours_bit_identical_to_the_staged_path(ctx, d, n_probe, k_ann, keep, tol, mode, rt_tol):
+    sizes = [6000, 300, 2500, 9000, 40, 1300]
+    nl = np.array([64, 1, 32, 128, 1, 16], np.int32)          # flat buckets in between take the staged flat path
+    off, X, mz, rt = _buckets(sizes, d, 31)
+    X[off[3] + 10:off[3] + 16] = X[off[3] + 10]               # exact duplicates -> exact ties
+    e_idx, n_fb = _staged_and_prefiltered(ctx, X, off, nl, mz, rt if rt_tol is not None else None, n_probe, k_ann, keep,
+                                          tol, mode, rt_tol)
+    assert (e_idx >= 0).sum() > off[-1] // 8
+    assert n_fb < 0.05 * off[-1], n_fb                        # the prefiltered path did the work, not the fallback
+
+
+def test_ivf_prefilter_handles_ties_zero_rows_and_few_candidates(ctx):
+    """hundreds of identical spectra (more members around the k-th key than the hand-off holds), all-zero rows (every key 0),
+    near-duplicates, and a bucket whose lists hold fewer than k_ann candidates per query: still bit-identical"""
+    sizes = [5000, 700, 3000]
+    nl = np.array([64, 32, 32], np.int32)                     # 700 rows in 32 lists, 16 probed: ~350 candidates; k_ann 400 below
+    off, X, mz, _ = _buckets(sizes, 400, 41, mz0=600.0, width=0.02)
+    X[100:420] = X[100]                                       # 320 identical rows
+    X[500:560] = 0                                            # empty spectra
+    base = X[off[2]].copy()
+    for i in range(200):                                      # near-duplicates: dense similarities just below 1
+        v = base.copy()
+        v[(7 * i) % 400] += 1e-3 * (i + 1)
+        X[off[2] + 1 + i] = v / np.linalg.norm(v)
+    _, n_fb = _staged_and_prefiltered(ctx, X, off, nl, mz, None, 16, 128, 64, 20.0, "ppm", None)
+    assert n_fb > 100
+    _staged_and_prefiltered(ctx, X, off, nl, mz, None, 16, 250, 64, 20.0, "ppm", None)
+
+
+def test_pipeline_with_and_without_ivf_prefilter_is_identical(ctx):
+    """whole path on synthetic spectra dense enough for IVF buckets: the prefilter changes nothing but the time"""
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    d = synth.select_charge(synth.generate(60000, seed=11, mz_lo=600.0, mz_hi=603.0), 2)
+    ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+    pipe = ClusterPipeline(ctx)
+    outs = []
+    for pre in (True, False):
+        p = AnnParams(ivf_prefilter=pre)
+        lab, med = pipe.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, p)
+        assert int(pipe.last["n_list"].max()) > 1
+        outs.append((lab.cpu().numpy(), med.cpu().numpy(), pipe.last["nb_idx"].cpu().numpy(),
+                     pipe.last["nb_dist"].cpu().numpy().view(np.uint32), ctx.counter(5)))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+    assert outs[0][4] < 0.02 * len(ds)                        # few queries needed the exact fallback
