@@ -555,6 +555,8 @@ __device__ __forceinline__ void push_fallback(const FusedArgs& a, int64_t row, i
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void resolve_kernel(FusedArgs a, int d) {
     __shared__ uint32_t s_u_all[4 * 64];
     __shared__ uint32_t s_lo_all[4 * 64];
+    __shared__ int32_t seg_off_all[4][FAL_MAX_N_PROBE + 1];      // IVF: key-stream offset / first position of every probed list
+    __shared__ int64_t seg_src_all[4][FAL_MAX_N_PROBE];
     int ji, lt;
     if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
@@ -586,7 +588,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             const int m0 = t.mc & 0xFFFF, m1 = t.mc >> 16;
             const bool have = lane < kMemHalf ? lane < m0 : (lane - kMemHalf) < m1;
             const float v = have ? a.gmem_v[row * FAL_FUSED_MEM + lane] : 0.f;
-            const uint32_t mid = have ? a.gmem_id[row * FAL_FUSED_MEM + lane] : 0u;
+            uint32_t mid = have ? a.gmem_id[row * FAL_FUSED_MEM + lane] : 0u;
+            if (a.ivf) {
+                // select16_kernel handed the members over as positions in the query's key stream (probe order, list order
+                // inside): stream offsets of the probed lists by a wave prefix sum, then position -> list row -> sorted row
+                int32_t* seg_off = seg_off_all[w];
+                int64_t* seg_src = seg_src_all[w];
+                const int np = a.n_probe;
+                const int32_t* pr = a.probes + (int64_t)a.pos_of_row[row] * np;
+                int run = 0;
+                for (int j0 = 0; j0 < np; j0 += 64) {
+                    const int j = j0 + lane;
+                    const int32_t l = j < np ? pr[j] : -1;
+                    int64_t b = 0, e = 0;
+                    if (l >= 0) {
+                        b = a.list_off[job.c_row0 + l];
+                        e = a.list_off[job.c_row0 + l + 1];
+                    }
+                    const int len = (int)(e - b);
+                    int incl = len;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += o;
+                    }
+                    if (j < np) {
+                        seg_off[j] = run + incl - len;
+                        seg_src[j] = b;
+                    }
+                    run += __shfl(incl, 63, 64);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (have) {
+                    const int pp = (int)mid;
+                    int lo = 0, hi = np - 1;                     // last probe slot with seg_off <= pp
+                    while (lo < hi) {
+                        const int md = (lo + hi + 1) >> 1;
+                        if (seg_off[md] <= pp) lo = md; else hi = md - 1;
+                    }
+                    mid = (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])] - (uint32_t)row0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
             const bool inE = have && fabsf(v - t.T) <= 2.f * t.eps;
             const int n_bin_above = __popcll(__ballot(have && (int)bin_of(v) > t.bstar));
             const int n_hi = __popcll(__ballot(have && v > t.T + 2.f * t.eps));

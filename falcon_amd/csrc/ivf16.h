@@ -31,14 +31,15 @@ struct Select16Args {
     int n_jobs;
     int64_t tile_begin;
     const int32_t* tile_job;     // (filled by launch_select16)
-    int n_probe;
-    const int32_t* probes;
-    const int64_t* list_off;
     const int64_t* q_sim_off;
     const int32_t* perm;
     QThr* thr;                   // hand-off (fused.h), by sorted row
-    float* gmem_v;
-    uint32_t* gmem_id;
+    float* gmem_v;               // members: approximate value ...
+    uint32_t* gmem_id;           // ... and position in the query's key stream (resolve_kernel: -> row where needed)
+    int64_t n_tiles;             // (filled by launch_select16)
+    int32_t* big_count;          // queries with more than 2,048 keys: second pass with 64 keys per lane
+    int32_t* big_list;
+    int big_cap;
 };
 
 bool ivf16_supports(int d);

@@ -14,7 +14,7 @@
 //   select16_kernel   one wave per query: all keys of the query in registers, the k_ann-th largest key T~ by a bitwise search
 //      with ballot counts; |key / 65535 - exact| <= e(T~) (bound below) puts the exact k_ann-th best value inside
 //      [T~ - e, T~ + e].  Out: the thresholds, how many keys lie certainly above, and the few candidates within 2e of T~
-//      ("members": the only ones whose exact value can decide the k_ann-th key).
+//      ("members": the only ones whose exact value can decide the k_ann-th key), as positions in the query's key stream.
 //   band_kernel<., IVF> / resolve_kernel / ivf_fallback_kernel (fused.hip)   exact similarities of the precursor window on the
 //      fp32 matrix cores (candidates outside the query's probed lists masked out), ambiguous candidates against the exact
 //      k_ann-th key, sort, neighbour lists; queries the hand-off cannot hold take the exact fallback.
@@ -178,16 +178,15 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wcount(bool p) { return __popcll(__ballot(p)); }
 
-struct Sel16Out {
-    uint32_t T;          // k-th largest key + 1
-    int delta_e, delta;  // e and the member half-width, in key units
-    int n_hi;            // keys above T + delta
-    int n_mem;           // keys within delta of T
-};
-
+// One query: its keys sit in registers (R per lane), u = key + 1 (0 = no key).
+//  1. T = the k-th largest u (bitwise search, ballot counts);  e = bound of |key / 65535 - exact| around T, in key units
+//  2. thresholds for the exact tail: [L, U] holds the exact k-th best similarity; n_hi = keys certainly above U
+//  3. "members": the keys within 2e of T, as (value, stream position) -- resolve_kernel turns the positions into rows for the
+//     few queries that turn out to have an ambiguous window candidate (no probe table / list offsets / perm gathers here: the
+//     kernel is bound by the latency of its dependent loads)
 template <int R>
 __device__ __forceinline__ void select16_body(const Select16Args& a, const uint16_t* __restrict__ row, int nc, int k, int lane,
-                                              const int32_t* seg_off, const int64_t* seg_src, int64_t out_row, int64_t row0) {
+                                              int64_t out_row) {
     uint32_t u[R];
     {
         const uint16_t* rl = row + lane;
@@ -197,7 +196,7 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
 #pragma unroll
         for (int i = 0; i < R; ++i) u[i] = (i * 64 + lane < nc) ? (uint32_t)raw[i] + 1u : 0u;
     }
-    // largest T with count(key >= T) >= k; on an early exit (a threshold that splits off exactly k keys) the k-th largest
+    // largest T with count(u >= T) >= k; on an early exit (a threshold that splits off exactly k keys) the k-th largest
     // key itself is the smallest key >= T
     uint32_t T = 0;
     bool early = false;
@@ -257,85 +256,64 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
         if (mask) {                                              // wave-uniform
             if (in) {
                 const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-                const int pp = i * 64 + lane;
-                int lo = 0, hi = a.n_probe - 1;                  // last segment with seg_off <= pp
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (seg_off[mid] <= pp) lo = mid; else hi = mid - 1;
-                }
-                const uint32_t id = (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])];
                 gv[slot] = (float)(u[i] - 1u) * (1.f / 65535.f);
-                gi[slot] = id - (uint32_t)row0;
+                gi[slot] = (uint32_t)(i * 64 + lane);            // stream position (resolve_kernel: -> row)
             }
             base += __popcll(mask);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
-    __shared__ int32_t seg_off_all[4][FAL_MAX_N_PROBE + 1];
-    __shared__ int64_t seg_src_all[4][FAL_MAX_N_PROBE];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int32_t* seg_off = seg_off_all[w];
-    int64_t* seg_src = seg_src_all[w];
-    const int64_t tl = blockIdx.x >> 3;
-    const int64_t t = a.tile_begin + tl;
-    const int ql = (int)((blockIdx.x & 7) << 2) + w;
-    const DenseJob job = a.jobs[a.tile_job[tl]];
-    const int lt = (int)(t - job.tile0);
-    if (32 * lt + ql >= job.nq) return;                     // (whole wave; no workgroup barriers below)
-    const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;   // query position in list order
-    const int np = a.n_probe, k = a.k;
-    const int32_t* pr = a.probes + p * np;
-    const int64_t lbase = job.c_row0;                        // global id of the bucket's list 0
-    int64_t run = 0;
-    for (int j0 = 0; j0 < np; j0 += 64) {                    // stream offset of every probed list: wave prefix sum
-        const int j = j0 + lane;
-        const int32_t l = j < np ? pr[j] : -1;
-        int64_t b = 0, e = 0;
-        if (l >= 0) {
-            b = a.list_off[lbase + l];
-            e = a.list_off[lbase + l + 1];
-        }
-        const int len = (int)(e - b);
-        int incl = len;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
-        if (j < np) {
-            seg_off[j] = (int32_t)(run + incl - len);
-            seg_src[j] = b;
-        }
-        run += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) seg_off[np] = (int32_t)run;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const int nc = (int)run;
-    const int64_t out_row = a.perm[p];
-    if (nc <= k) {                                           // every candidate is among the k best
-        if (lane == 0) {
-            QThr t0;
-            t0.L = t0.U = -INFINITY;
-            t0.T = 0.f; t0.eps = 0.f; t0.bstar = 1 << 30; t0.nabove = 0; t0.mc = 0; t0.flags = 0;
-            a.thr[out_row] = t0;
-        }
-        return;
-    }
-    const uint16_t* row = a.keys + (a.q_sim_off[32 * t + ql] - a.keys_base);
-    const int64_t row0 = job.q_row0;                         // the bucket's first sorted row (== first list-order position)
-    if (nc <= 512) select16_body<8>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
-    else if (nc <= 1024) select16_body<16>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
-    else if (nc <= 1536) select16_body<24>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
-    else if (nc <= 2048) select16_body<32>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
-    else if (nc <= 4096) select16_body<64>(a, row, nc, k, lane, seg_off, seg_src, out_row, row0);
-    else if (lane == 0) {                                    // more keys than the registers hold: exact fallback
-        QThr t0;
+__device__ __forceinline__ void select16_trivial(const Select16Args& a, int64_t out_row, int flags, int lane) {
+    if (lane == 0) {
+        QThr t0{};
         t0.L = t0.U = -INFINITY;
-        t0.T = 0.f; t0.eps = 0.f; t0.bstar = 1 << 30; t0.nabove = 0; t0.mc = 0; t0.flags = 2;
+        t0.bstar = 1 << 30;
+        t0.flags = flags;
         a.thr[out_row] = t0;
+    }
+}
+
+// BIG = false: one wave per query slot of the launch's tiles; queries with more keys than 32 per lane are appended to
+// a.big_list.  BIG = true: the listed queries, 64 keys per lane (more than 4,096 keys: exact fallback)
+template <bool BIG>
+__global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_big = BIG ? min(*a.big_count, a.big_cap) : 0;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + w;; item += (int64_t)gridDim.x * 4) {
+        int64_t slot;
+        if (BIG) {
+            if (item >= n_big) return;
+            slot = a.big_list[item];
+        } else {
+            slot = 32 * a.tile_begin + item;
+            if (item >= 32 * a.n_tiles) return;
+        }
+        const int64_t o0 = a.q_sim_off[slot], o1 = a.q_sim_off[slot + 1];
+        const int nc = (int)(o1 - o0);
+        if (nc > 0) {                                            // (0: padding slot of a bucket's last tile)
+            const int64_t t = slot >> 5;
+            const DenseJob job = a.jobs[a.tile_job[t - a.tile_begin]];
+            const int64_t p = job.q_row0 + 32 * (t - job.tile0) + (slot & 31);      // query position in list order
+            const int64_t out_row = a.perm[p];
+            const uint16_t* row = a.keys + (o0 - a.keys_base);
+            const int k = a.k;
+            if (nc <= k) select16_trivial(a, out_row, 0, lane);  // every candidate is among the k best
+            else if (!BIG) {
+                if (nc <= 512) select16_body<8>(a, row, nc, k, lane, out_row);
+                else if (nc <= 1024) select16_body<16>(a, row, nc, k, lane, out_row);
+                else if (nc <= 1536) select16_body<24>(a, row, nc, k, lane, out_row);
+                else if (nc <= 2048) select16_body<32>(a, row, nc, k, lane, out_row);
+                else if (lane == 0) {
+                    const int at = atomicAdd(a.big_count, 1);
+                    if (at < a.big_cap) a.big_list[at] = (int32_t)slot;
+                }
+            } else {
+                if (nc <= 4096) select16_body<64>(a, row, nc, k, lane, out_row);
+                else select16_trivial(a, out_row, 2, lane);      // more keys than the registers hold: exact fallback
+            }
+        }
+        if (!BIG) return;
     }
 }
 
@@ -392,14 +370,21 @@ int launch_list16(fal_ctx* ctx, const List16Args& a) {
 int launch_select16(fal_ctx* ctx, const Select16Args& a_in, int64_t n_tiles) {
     if (n_tiles <= 0) return FAL_OK;
     Select16Args a = a_in;
+    a.n_tiles = n_tiles;
+    // tile -> job table, then the list of queries with more than 2,048 keys (count in front)
     int32_t* tj = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)std::max<int64_t>(n_tiles, 1 << 16), (void**)&tj));
+    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(n_tiles, 1 << 16) + 32 * n_tiles + 64), (void**)&tj));
+    a.big_count = tj + std::max<int64_t>(n_tiles, 1 << 16);
+    a.big_list = a.big_count + 16;
+    a.big_cap = (int)std::min<int64_t>(32 * n_tiles, INT32_MAX);
+    FAL_REQUIRE(n_tiles * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
     StageScope ts(ctx, ST_SELECT);
+    FAL_CHECK_HIP(hipMemsetAsync(a.big_count, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(tile_job16_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
                        a.tile_begin, n_tiles, tj);
     a.tile_job = tj;
-    FAL_REQUIRE(n_tiles * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
-    hipLaunchKernelGGL(select16_kernel, dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((select16_kernel<false>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL((select16_kernel<true>), dim3((unsigned)(ctx->num_cus * 4)), dim3(256), 0, ctx->stream, a);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

@@ -516,7 +516,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             FAL_TRY(launch_list16(ctx, la));
             Select16Args sa{};
             sa.keys = keys; sa.keys_base = base; sa.k = k_ann; sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size();
-            sa.tile_begin = t0; sa.n_probe = np; sa.probes = probes; sa.list_off = ivf->list_off; sa.q_sim_off = q_sim_off;
+            sa.tile_begin = t0; sa.q_sim_off = q_sim_off;
             sa.perm = ivf->perm; sa.thr = fa.thr; sa.gmem_v = fa.gmem_v; sa.gmem_id = fa.gmem_id;
             FAL_TRY(launch_select16(ctx, sa, t1 - t0));
         }
