@@ -5,6 +5,7 @@
 #include <math.h>
 #include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <stdlib.h>
 #include "common.h"
 #include "ivf.h"
 #include "util.h"
@@ -158,13 +159,16 @@ int fal_sort_by_precursor(fal_ctx* ctx, const float* precursor_mz, int64_t n, in
     const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
     hipLaunchKernelGGL(iota_i64_kernel, dim3(grid), dim3(256), 0, ctx->stream, iota, n);
     size_t bytes = 0;
-    // LSD radix sort is stable: equal m/z keep dataset order (the oracle sorts with kind="stable")
-    FAL_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, precursor_mz, mz_sorted_out, iota, order_out, (size_t)n, 0, 32,
-                                            ctx->stream));
+    // LSD radix sort is stable: equal m/z keep dataset order (the oracle sorts with kind="stable").  rocprim's default takes its
+    // merge sort below 1 M keys (~20 launches; 0.173 ms for the 700 k keys of a BASELINE configs[1] partition); with the limit
+    // at 128 k keys the Onesweep radix passes (histogram + scan + 4 passes) run instead: 0.129 ms (tools/sort_ab.py)
+    using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 131072>;
     void* tmp = nullptr;
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, precursor_mz, mz_sorted_out, iota, order_out, (size_t)n, 0,
+                                                        32, ctx->stream));
     FAL_TRY(ctx->reserve(SLOT_SORT2, bytes, &tmp));
-    FAL_CHECK_HIP(rocprim::radix_sort_pairs(tmp, bytes, precursor_mz, mz_sorted_out, iota, order_out, (size_t)n, 0, 32,
-                                            ctx->stream));
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, precursor_mz, mz_sorted_out, iota, order_out, (size_t)n, 0, 32,
+                                                        ctx->stream));
     return FAL_OK;
 }
 
