@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "f16"], default="f32", help="vector dtype (f16 = BASELINE config 5)")
     ap.add_argument("--prefilter", action="store_true",
                     help="flat buckets: top-k kept on chip (f16-MFMA prefilter + exact float32 window, fused.hip; same results)")
+    ap.add_argument("--no-ivf-prefilter", action="store_true",
+                    help="buckets with an index: exact fp32-MFMA fine scan of every probed pair instead of the f16-MFMA prefilter + "
+                         "exact float32 refinement (ivf16.hip; same results)")
     ap.add_argument("--rescore", action="store_true",
                     help="re-score the neighbours with the matched-peak cosine before DBSCAN (SURVEY 8f-4; not the headline)")
     ap.add_argument("--generator", choices=["device", "numpy"], default="device",
@@ -155,7 +158,8 @@ def main():
     def params(**kw):
         base = dict(eps=args.eps, low_dim=args.low_dim, n_probe=args.n_probe, n_neighbors=args.n_neighbors,
                     n_neighbors_ann=args.n_neighbors_ann, mz_interval=args.mz_interval, scan=args.scan, dtype=args.dtype,
-                    rescore=args.rescore, min_matches=6 if args.rescore else 0, prefilter=args.prefilter)
+                    rescore=args.rescore, min_matches=6 if args.rescore else 0, prefilter=args.prefilter,
+                    ivf_prefilter=not args.no_ivf_prefilter)
         base.update(kw)
         return AnnParams(**base)
 
@@ -373,6 +377,13 @@ def main():
                            "note": "2*d*n_list flop per row and pass, 11 passes; computed on the f16 matrix cores (float16 prefilter) "
                                    "with exact float32 re-evaluation of close calls: not fp32-MFMA work, the index is identical"},
                 "coarse": {"ms": sc["stage_ms"]["coarse"], "tflops": sc["coarse_tflops"]},
+                "fine_scan": ("float16 rows scanned on the f16 matrix cores (config 5 vectors)" if name == "f16" else
+                              ("exact fp32-MFMA scan of every probed pair + wavefront select" if args.no_ivf_prefilter else
+                               "f16-MFMA list scan to 16-bit keys + k-th key per query (stage scan/select), exact fp32-MFMA "
+                               "similarities of the precursor window + exact resolution of the k-th key: bit-identical to the "
+                               "exact scan (tests/test_gpu_ivf16.py); the TFLOP/s above count the algorithmic 2*d flop per probed "
+                               "pair, most of which run as float16")),
+                "prefilter_fallback_rows": int(ctx.counter(5)),
             })
         del big
         torch.cuda.empty_cache()

@@ -50,14 +50,25 @@ __device__ __forceinline__ uint16_t key16(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// list16_kernel: tile = (one inverted list, 128 of its rows); see ivf_list4_kernel for the structure
+// list16_kernel: tile = (one inverted list, 128 of its rows); see ivf_list4_kernel for the structure.  The kernel is bound by
+// the latency of the gathered query rows (a chunk of 32 rows = 0.33 us of matrix work, an L2 / HBM round trip is 1-2 us), so
+// THREE stream buffers: the DMA of chunk c + 2 is issued while chunk c is computed.  vmcnt is an in-order counter and hipcc
+// answers any VMEM instruction it cannot count with vmcnt(0), so the loop's memory traffic is spelled out:
+//   * per step and wave exactly 1 metadata DMA (row ids | destinations of chunk c + 3, into an 8-slot LDS ring), 7 row DMAs
+//     (pieces padded: a duplicate re-writes the same bytes; chunks past the end re-load the last rows) and 16 key stores;
+//   * DMAs and waits are inline asm (the compiler never sees a load result it would have to wait for): before the barrier of
+//     step c + 1, vmcnt(23) -- everything but step c's row DMAs and stores -- has retired chunk c + 1 and the metadata of c + 3.
 // ------------------------------------------------------------------------------------------------------------
 template <int STEPS>
 __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
     constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int NB = STEPS < 4 ? STEPS : 4;             // LDS operand reads in flight ahead of the MFMAs
+    constexpr int kPieces = (STEPS + 3) / 4;              // row DMAs per wave and chunk
+    static_assert(kPieces == 7 || STEPS != 25, "the waits below count 7 row DMAs per step at low_dim 400");
     __shared__ uint4 sbuf0[STEPS * 64];                   // [step][lane]: MFMA-operand order, conflict-free 16-byte reads
     __shared__ uint4 sbuf1[STEPS * 64];
+    __shared__ uint4 sbuf2[STEPS * 64];
+    __shared__ int32_t meta[8][64];                       // per chunk: [0, 32) row of query r, [32, 64) its destination (low dword)
     const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
     const int64_t lt = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= per_xcd) return;
@@ -69,7 +80,8 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
         if (a.ltile_off[mid] <= t) lo = mid; else hi = mid - 1;
     }
     const int64_t L = lo;
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slice = 4 * (int)(t - a.ltile_off[L]) + w;  // this wave's 32-row slice of the list
     const int64_t l_row0 = a.list_off[L];
     const int l_rows = (int)(a.list_off[L + 1] - l_row0);
@@ -88,37 +100,48 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
     }
     const int pos = 32 * slice + r;                        // position inside the list = offset inside a query's segment
     const bool rvalid = active && r < nrow;
+    const uint32_t base_lo = (uint32_t)a.keys_base;
 
-    auto q_row = [&](int c0) -> int32_t { return a.inv_q[e0 + min(c0 + r, nq - 1)]; };
-    auto q_dest = [&](int c0) -> int64_t { return a.inv_dest[e0 + min(c0 + r, nq - 1)]; };
-    // the first USE of a prefetched value must sit behind the next barrier (ivf_list4_kernel)
-    auto pin = [](int32_t& x, int64_t& y) { asm volatile("" : "+v"(x), "+v"(y)); };
-    auto issue = [&](int32_t row, uint4* buf) {
+    auto lds_addr = [](const void* p) -> uint32_t {
+        return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
+    };
+    // metadata of chunk c (queries c*32 + r): lanes of the lower half fetch the row id, the upper half the destination
+    auto issue_meta = [&](int c) {
+        const int64_t e = e0 + min(32 * c + r, nq - 1);
+        const void* g = h ? (const void*)(a.inv_dest + e) : (const void*)(a.inv_q + e);
+        const uint32_t l = lds_addr(&meta[c & 7][0]);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+    };
+    auto issue_rows = [&](int c, const uint4* buf) {
+        const int32_t row = meta[c & 7][r];
         const uint4* rowp = reinterpret_cast<const uint4*>(a.Xl16 + (int64_t)row * D + h * DH);
+        const uint32_t lb = lds_addr(buf);
 #pragma unroll
-        for (int jj = 0; jj < (STEPS + 3) / 4; ++jj) {
-            const int j = 4 * jj + w;
-            if (j < STEPS) FAL_GLDS16(rowp + j, buf + j * 64);
+        for (int jj = 0; jj < kPieces; ++jj) {
+            const int j = min(4 * jj + w, STEPS - 1);      // (padded: the same number of pieces in every wave)
+            const void* g = rowp + j;
+            const uint32_t l = lb + (uint32_t)j * 1024u;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
         }
     };
     f32x16 prev;
 #pragma unroll
     for (int i = 0; i < 16; ++i) prev[i] = 0.f;
-    int prev_c0 = 0;
-    uint32_t dest_prev = (uint32_t)(q_dest(0) - a.keys_base);
+    int prev_c = 0;                                        // chunk whose results sit in `prev`
     // D[query][list row]: lane = list row (column), registers = 16 streamed queries; every store instruction writes 32
     // consecutive keys of ONE query's segment for this list
     auto epilogue = [&]() {
+        const int32_t* md = &meta[prev_c & 7][32 + 4 * h];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int qr = mfma32_row(i, h);
-            const uint32_t dest = (uint32_t)__shfl((int)dest_prev, qr, 64);      // lane qr holds query prev_c0 + qr
-            uint16_t* p = (rvalid && prev_c0 + qr < nq) ? a.keys + dest + pos : a.sink + lane;
+            const int q0 = (i & 3) + 8 * (i >> 2);
+            const uint32_t dest = (uint32_t)md[q0] - base_lo;
+            uint16_t* p = (rvalid && 32 * prev_c + q0 + 4 * h < nq) ? a.keys + dest + pos : a.sink + lane;
             *p = key16(prev[i]);
         }
         __builtin_amdgcn_sched_group_barrier(0x040, 16, 0);
     };
-    auto compute = [&](const uint4* buf, int c0) {
+    auto compute = [&](const uint4* buf, int c) {
         constexpr int kMid = STEPS / 2;
         const half8* sb = reinterpret_cast<const half8*>(buf) + lane;
         half8 ring[NB];
@@ -140,37 +163,41 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
         }
         asm volatile("s_nop 15" : "+a"(acc));              // MFMA -> accumulator read behind a taken branch (simtile.h)
         prev = acc;
-        prev_c0 = c0;
+        prev_c = c;
     };
-
-    issue(q_row(0), sbuf0);
-    int32_t row_next = q_row(32);
-    int64_t dest_raw = q_dest(0);            // of the chunk whose epilogue runs next
-    for (int c0 = 0; c0 < nq; c0 += 64) {
-        {
-            __syncthreads();      // chunk c0 has landed; sbuf1 is free again
-            pin(row_next, dest_raw);
-            if (c0 + 32 < nq) issue(row_next, sbuf1);
-            dest_prev = (uint32_t)(dest_raw - a.keys_base);
-            row_next = q_row(c0 + 64);
-            dest_raw = q_dest(c0);
-            if (active) compute(sbuf0, c0);
-        }
-        if (c0 + 32 >= nq) break;
-        {
-            __syncthreads();
-            pin(row_next, dest_raw);
-            if (c0 + 64 < nq) issue(row_next, sbuf0);
-            dest_prev = (uint32_t)(dest_raw - a.keys_base);
-            row_next = q_row(c0 + 96);
-            dest_raw = q_dest(c0 + 32);
-            if (active) compute(sbuf1, c0 + 32);
-        }
+    // step c: chunk c (in CUR) is computed; the row DMA of chunk c + 2 goes to FILL (free since the barrier: its last reader
+    // was the computation of chunk c - 1), the metadata DMA of chunk c + 3 to the ring
+#define FAL_STEP(CUR, FILL, C)                                                                             \
+    {                                                                                                      \
+        if (active) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");                                      \
+        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                              \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        asm volatile("" ::: "memory");                                                                     \
+        issue_meta((C) + 3);                                                                               \
+        issue_rows((C) + 2, FILL);                                                                         \
+        if (active) compute(CUR, C);                                                                       \
     }
-    if (active) {
-        dest_prev = (uint32_t)(dest_raw - a.keys_base);
-        epilogue();
+    issue_meta(0);
+    issue_meta(1);
+    issue_meta(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_rows(0, sbuf0);
+    issue_rows(1, sbuf1);
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");       // chunk 0 has landed (the first step's own wait is a no-op)
+    const int n_chunks = (nq + 31) >> 5;
+    for (int c = 0;; c += 3) {
+        FAL_STEP(sbuf0, sbuf2, c)
+        if (c + 1 >= n_chunks) break;
+        FAL_STEP(sbuf1, sbuf0, c + 1)
+        if (c + 2 >= n_chunks) break;
+        FAL_STEP(sbuf2, sbuf1, c + 2)
+        if (c + 3 >= n_chunks) break;
     }
+#undef FAL_STEP
+    // (outstanding DMAs target this workgroup's LDS: the hardware holds the allocation until they retire)
+    if (active) epilogue();
 }
 
 // ------------------------------------------------------------------------------------------------------------
