@@ -21,6 +21,7 @@ struct List16Args {              // cf. ListScanArgs (scan.h); tiles = groups of
     uint16_t* keys;              // round(approximate similarity * 65535)
     int64_t keys_base;
     uint16_t* sink;              // >= 64 entries of scratch for masked stores
+    int64_t n_rows;              // rows of Xl16 (row ids read past a list's end are clamped)
 };
 
 struct Select16Args {

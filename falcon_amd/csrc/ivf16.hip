@@ -50,25 +50,28 @@ __device__ __forceinline__ uint16_t key16(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// list16_kernel: tile = (one inverted list, 128 of its rows); see ivf_list4_kernel for the structure.  The kernel is bound by
-// the latency of the gathered query rows (a chunk of 32 rows = 0.33 us of matrix work, an L2 / HBM round trip is 1-2 us), so
-// THREE stream buffers: the DMA of chunk c + 2 is issued while chunk c is computed.  vmcnt is an in-order counter and hipcc
-// answers any VMEM instruction it cannot count with vmcnt(0), so the loop's memory traffic is spelled out:
-//   * per step and wave exactly 1 metadata DMA (row ids | destinations of chunk c + 3, into an 8-slot LDS ring), 7 row DMAs
-//     (pieces padded: a duplicate re-writes the same bytes; chunks past the end re-load the last rows) and 16 key stores;
-//   * DMAs and waits are inline asm (the compiler never sees a load result it would have to wait for): before the barrier of
-//     step c + 1, vmcnt(23) -- everything but step c's row DMAs and stores -- has retired chunk c + 1 and the metadata of c + 3.
+// list16_kernel: tile = (one inverted list, 128 of its rows); see ivf_list4_kernel for the structure.  Two things bound the
+// first version of this kernel, both in the gather of the streamed query rows (a chunk of 32 rows = 0.33 us of matrix work):
+//   * request count: with a row per lane, a DMA instruction touched 64 different cache lines for 16 bytes each (the other
+//     pieces of a line only hit if it survived in the 32 kB L1 until the step that wanted them; with ~100 kB of chunks in
+//     flight per CU it did not).  Now ONE ROW PER INSTRUCTION: lanes 0 .. d/8-1 fetch the row's consecutive 16-byte pieces
+//     (800 B = 6.25 lines), the row lands row-major in LDS, rows padded to 2d + 16 bytes (conflict-free b128 operand reads);
+//   * latency: THREE stream buffers, the DMA of chunk c + 2 is issued while chunk c is computed.  vmcnt is an in-order counter
+//     and hipcc answers any VMEM instruction it cannot count with vmcnt(0), so the loop's memory traffic is spelled out: per
+//     step and wave exactly 1 metadata DMA (row ids and destinations of chunk c + 3, into an 8-slot LDS ring), 8 row DMAs and
+//     16 key stores; DMAs and waits in inline asm (the compiler never sees a load result it would have to wait for); before
+//     the barrier of step c + 1, vmcnt(24) -- everything but step c's row DMAs and stores -- has retired chunk c + 1 and the
+//     metadata of chunk c + 3.
 // ------------------------------------------------------------------------------------------------------------
 template <int STEPS>
 __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
     constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int NB = STEPS < 4 ? STEPS : 4;             // LDS operand reads in flight ahead of the MFMAs
-    constexpr int kPieces = (STEPS + 3) / 4;              // row DMAs per wave and chunk
-    static_assert(kPieces == 7 || STEPS != 25, "the waits below count 7 row DMAs per step at low_dim 400");
-    __shared__ uint4 sbuf0[STEPS * 64];                   // [step][lane]: MFMA-operand order, conflict-free 16-byte reads
-    __shared__ uint4 sbuf1[STEPS * 64];
-    __shared__ uint4 sbuf2[STEPS * 64];
-    __shared__ int32_t meta[8][64];                       // per chunk: [0, 32) row of query r, [32, 64) its destination (low dword)
+    constexpr int RS = D * 2 + 16;                        // LDS row stride in bytes
+    __shared__ __attribute__((aligned(16))) unsigned char sbuf0[32 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char sbuf1[32 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char sbuf2[32 * RS];
+    __shared__ int32_t meta[8][64];                       // per chunk: [32, 64) destination (low dword) of query r ([0, 32): its row)
     const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
     const int64_t lt = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= per_xcd) return;
@@ -112,16 +115,22 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
         const uint32_t l = lds_addr(&meta[c & 7][0]);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");
     };
-    auto issue_rows = [&](int c, const uint4* buf) {
-        const int32_t row = meta[c & 7][r];
-        const uint4* rowp = reinterpret_cast<const uint4*>(a.Xl16 + (int64_t)row * D + h * DH);
+    // rows of a chunk served by this wave: 8w .. 8w + 7; their ids come from the metadata ring (landed a step ago), one
+    // v_readlane each.  Chunks past the end re-load the last rows (their metadata is clamped); ids are clamped to valid rows.
+    const uint32_t row_max = (uint32_t)(a.n_rows - 1);
+    auto issue_rows = [&](int c, const unsigned char* buf) {
         const uint32_t lb = lds_addr(buf);
+        const int32_t ids = meta[c & 7][r];
+        uint32_t rows[8];
 #pragma unroll
-        for (int jj = 0; jj < kPieces; ++jj) {
-            const int j = min(4 * jj + w, STEPS - 1);      // (padded: the same number of pieces in every wave)
-            const void* g = rowp + j;
-            const uint32_t l = lb + (uint32_t)j * 1024u;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+        for (int i = 0; i < 8; ++i) rows[i] = min((uint32_t)__builtin_amdgcn_readlane(ids, 8 * w + i), row_max);
+        if (lane < D / 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const void* g = reinterpret_cast<const uint4*>(a.Xl16 + (int64_t)rows[i] * D) + lane;
+                const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lb + (uint32_t)(8 * w + i) * (uint32_t)RS));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+            }
         }
     };
     f32x16 prev;
@@ -141,12 +150,12 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
         }
         __builtin_amdgcn_sched_group_barrier(0x040, 16, 0);
     };
-    auto compute = [&](const uint4* buf, int c) {
+    auto compute = [&](const unsigned char* buf, int c) {
         constexpr int kMid = STEPS / 2;
-        const half8* sb = reinterpret_cast<const half8*>(buf) + lane;
+        const unsigned char* sb = buf + r * RS + h * (DH * 2);
         half8 ring[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) ring[j] = sb[j * 64];
+        for (int j = 0; j < NB; ++j) ring[j] = *reinterpret_cast<const half8*>(sb + j * 16);
         __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);      // the whole ring in front of the first MFMA (fused.hip)
         f32x16 acc;
 #pragma unroll
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const half8 ch = ring[s % NB];
-            if (s + NB < STEPS) ring[s % NB] = sb[(s + NB) * 64];
+            if (s + NB < STEPS) ring[s % NB] = *reinterpret_cast<const half8*>(sb + (s + NB) * 16);
             // streamed queries are the A operand, the resident list rows B: D[query][list row]
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, q[s], acc, 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -169,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
     // was the computation of chunk c - 1), the metadata DMA of chunk c + 3 to the ring
 #define FAL_STEP(CUR, FILL, C)                                                                             \
     {                                                                                                      \
-        if (active) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");                                      \
-        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                              \
+        if (active) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                      \
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                              \
         __builtin_amdgcn_s_barrier();                                                                      \
         asm volatile("" ::: "memory");                                                                     \
         issue_meta((C) + 3);                                                                               \
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
     asm volatile("" ::: "memory");
     issue_rows(0, sbuf0);
     issue_rows(1, sbuf1);
-    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");       // chunk 0 has landed (the first step's own wait is a no-op)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // chunk 0 has landed (the first step's own wait is a no-op)
     const int n_chunks = (nq + 31) >> 5;
     for (int c = 0;; c += 3) {
         FAL_STEP(sbuf0, sbuf2, c)

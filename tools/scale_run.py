@@ -14,14 +14,15 @@ for ch in (2, 3):
     c = synth.select_charge_device(data, ch)
     parts.append(SpectrumDataset(*[ctx.to_dev(c[k], torch.float32) for k in ("precursor_mz", "retention_time", "mz", "intensity")], ctx.to_dev(c["indptr"], torch.int64)))
 del data
-for rep in range(2):
+REPS = 4
+for rep in range(REPS):
     torch.cuda.synchronize(); t = time.time()
-    if rep == 1: ctx.enable_timing(True)
+    if rep == REPS - 1: ctx.enable_timing(True)
     tot = 0; st = {}
     for ds in parts:
         labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, 2**15, p)
         tot += int(medoids.numel())
-        if rep == 1:
+        if rep == REPS - 1:
             for k in ("vectorize", "build", "coarse", "scan", "select", "filter", "dbscan", "tail"):
                 st[k] = st.get(k, 0) + ctx.stage_ms(k)[0]
             st["pairs"] = st.get("pairs", 0) + ctx.counter(0); st["coarse_pairs"] = st.get("coarse_pairs", 0) + ctx.counter(1)
