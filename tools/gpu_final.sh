@@ -22,3 +22,6 @@ j=json.load(open('gpurun_out/r2_bench_1M_under_rocprof.json')); print('rocprof r
 j=json.load(open('gpurun_out/r2_bench_2ranks_gloo_one_gpu.json')); print('2 ranks', j['value'], j['ms_per_step'])
 PY
 grep "dense_kernel<50, 0>" $O/r2_bench_1M_kernel_stats.csv | cut -c1-60,170-260
+# 10 M float32 (the IVF regime): kernel trace + HBM traffic of three passes
+bash tools/prof10m.sh 10000000 > $O/prof10m.txt 2>&1; cp /tmp/k.csv $O/r2_10M_f32_kernel_stats.csv; grep "ms total" $O/prof10m.txt | head -16
+bash tools/pmc10m.sh 10000000 > $O/r2_10M_f32_pmc_hbm_traffic.txt 2>&1; tail -20 $O/r2_10M_f32_pmc_hbm_traffic.txt
