@@ -122,6 +122,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the 10 M-spectra configurations of the `configs` array")
     ap.add_argument("--configs-spectra", type=int, default=10_000_000)
+    ap.add_argument("--partitions", choices=["auto", "concurrent", "pipelined"], default="auto",
+                    help="how the two charge partitions of a step are scheduled: concurrent = a host thread + HIP stream + context "
+                         "each (PartitionRunner; the reference clusters its blocks on a thread pool, cluster.py:115-136), pipelined = "
+                         "one stream, the next partition's sort under the current scan (ClusterPipeline.run_many); auto = concurrent "
+                         "on one GPU for the headline workload, pipelined for the 10 M configurations and for N > 1")
     ap.add_argument("--serial", action="store_true",
                     help="run the charge partitions strictly one after the other (default: software-pipelined, "
                          "ClusterPipeline.run_many)")
@@ -203,9 +208,15 @@ def main():
                 | {"pairs": ctx.counter(0), "coarse_pairs": ctx.counter(1), "issued": ctx.counter(4),
                    "scan_launches": ctx.counter(2), "sims_bytes": ctx.counter(3), "n": n})
 
+    concurrent = {"on": False}
+    runner = None
+
     def step(parts, run_args, collect=None):
         """one pass of the hot path over the dataset; `collect` != None: serial, per-stage timing, no exchange"""
-        if collect is None and not args.serial:
+        if collect is None and not args.serial and concurrent["on"]:
+            outs = runner.run(parts, *run_args)                                   # partitions on concurrent streams
+            lasts = [dict(pp.last) for pp in runner.last_pipes]
+        elif collect is None and not args.serial:
             outs = pipe.run_many(parts, *run_args, shard=shard)                   # partitions software-pipelined
             lasts = pipe.lasts
         else:
@@ -300,6 +311,10 @@ def main():
         ctx.enable_timing(False)
         return stages
 
+    if args.partitions == "concurrent" or (args.partitions == "auto" and world == 1 and not exchanging and not args.serial):
+        from falcon_amd.cluster.cluster import PartitionRunner
+        runner = PartitionRunner(local_rank, 2)
+        concurrent["on"] = True
     dt = timed(parts, run_args, args.steps, args.warmup)
     stages = staged(parts, run_args)
 
@@ -346,6 +361,8 @@ def main():
     if world == 1 and not args.no_configs and rank == 0:
         del parts
         torch.cuda.empty_cache()
+        if args.partitions == "auto":
+            concurrent["on"] = False          # 10 M spectra: two concurrent partitions lose (2.4x slower; tools/concurrent_parts.py)
         big = make_parts(args.configs_spectra)
         for name, kw in (("f32", dict(low_dim=400, dtype="f32", scan="f32")),
                          ("f16", dict(low_dim=800, dtype="f16", scan="f32"))):
@@ -445,7 +462,9 @@ def main():
                        "generator": f"falcon_amd.synth ({args.generator}; SURVEY 8d recipe, seed 42)",
                        "exchange": (args.exchange + " (CSR all-gatherv of neighbour lists + labels + rows, overlapped with "
                                     "the next step)") if exchanging else "none",
-                       "partitions": "serial" if args.serial else "software-pipelined (ClusterPipeline.run_many)",
+                       "partitions": ("serial" if args.serial else
+                                      "concurrent: a host thread + HIP stream + context per charge partition (PartitionRunner)"
+                                      if runner is not None else "software-pipelined (ClusterPipeline.run_many)"),
                        "parallelism": (f"precursor buckets of the one dataset dealt to {world} GPUs (LPT), no data-path "
                                        "collective, one all-gatherv") if world > 1 else "1 GPU",
                        "note": ("weak scaling keeps the spectra per GPU fixed; the dataset's precursor range does not grow, so "
