@@ -24,17 +24,24 @@ __global__ void probe_totals_kernel(const int32_t* __restrict__ probes, int np, 
                                     int64_t* __restrict__ totals) {
     const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t t = g >> 5;
-    if (t >= n_tiles) return;
-    const DenseJob job = jobs[find_job(jobs, n_jobs, t)];
-    const int lt = (int)(t - job.tile0), ql = (int)(g & 31);
-    if (32 * lt + ql >= job.nq) return;
-    const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;
     int64_t tot = 0;
-    for (int j = 0; j < np; ++j) {
-        const int l = probes[p * np + j];
-        if (l >= 0) tot += list_off[job.c_row0 + l + 1] - list_off[job.c_row0 + l];
+    if (t < n_tiles) {
+        const DenseJob job = jobs[find_job(jobs, n_jobs, t)];
+        const int lt = (int)(t - job.tile0), ql = (int)(g & 31);
+        if (32 * lt + ql < job.nq) {
+            const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;
+            for (int j = 0; j < np; ++j) {
+                const int l = probes[p * np + j];
+                if (l >= 0) tot += list_off[job.c_row0 + l + 1] - list_off[job.c_row0 + l];
+            }
+            totals[g] = tot;      // slot g = 32 * tile + lane (tile order, padded)
+        }
     }
-    totals[g] = tot;      // slot g = 32 * tile + lane (tile order, padded)
+    // the largest candidate count of the launch, behind the padded slots (one atomic per wave)
+    int64_t m = tot;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (int64_t)__shfl_xor((long long)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(reinterpret_cast<unsigned long long*>(totals + 32 * n_tiles + 1), (unsigned long long)m);
 }
 
 // ---- inverted probe table: for every list, the queries that probe it ---------------------------
@@ -417,8 +424,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * (size_t)ivf->n * np, (void**)&probe_sim));
     const int64_t n_slots = ivf_tiles * 32;
     FAL_TRY(ctx->reserve(SLOT_QOFF, sizeof(int64_t) * (size_t)(n_slots + 1), (void**)&q_sim_off));
-    FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (size_t)(n_slots + 1), (void**)&totals));
-    FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(n_slots + 1), st));
+    FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (size_t)(n_slots + 2), (void**)&totals));
+    FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(n_slots + 2), st));
     for (size_t bi = 0; bi + 1 < coarse_cuts.size(); ++bi) {
         const int64_t t0 = coarse_cuts[bi], t1 = coarse_cuts[bi + 1];
         const int64_t base = obase_of_tile(coarse, t0);
@@ -491,6 +498,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     FAL_CHECK_HIP(hipMemcpyAsync(lt_host.data(), ltile_off, sizeof(int64_t) * (size_t)(TL + 1), hipMemcpyDeviceToHost, st));
     if (hybrid)
         FAL_CHECK_HIP(hipMemcpyAsync(st_host.data(), stile_off, sizeof(int64_t) * (size_t)(TL + 1), hipMemcpyDeviceToHost, st));
+    int64_t max_total = 0;                                   // the most candidates any query has
+    FAL_CHECK_HIP(hipMemcpyAsync(&max_total, totals + n_slots + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipStreamSynchronize(st));
     // batches of whole IVF buckets (every list of a bucket touches queries all over the bucket)
     struct IvfBatch { size_t j0, j1; };
@@ -515,7 +524,10 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     FAL_REQUIRE(need_fine + kSimsSlack < ((size_t)1 << 32), FAL_EUNSUPPORTED, "sims batch too large (lower FALCON_SIMS_MB)");
     // ---- C'. fine scan with the float16 prefilter (ivf16.hip): f16-MFMA scan to 16-bit keys, k-th key per query, exact tail
     static const bool no_ivf16 = getenv("FALCON_NO_IVF16") != nullptr;
-    if (nf && ivf->Xl16 && ivf->pos_of_row && ivf->X && ivf16_supports(d) && !no_ivf16 && group_shift == 7 && !hybrid) {
+    // (select16_kernel holds at most 4,096 keys of a query in registers; coarser indexes keep the exact staged scan rather
+    // than sending every query through the exact fallback)
+    if (nf && ivf->Xl16 && ivf->pos_of_row && ivf->X && ivf16_supports(d) && !no_ivf16 && group_shift == 7 && !hybrid &&
+        max_total <= 4096) {
         // the IVF buckets in sorted-row order, 32-query tiles, sorted by decreasing size and dealt to the 8 XCD lists
         std::vector<size_t> ord(coarse.size());
         for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;

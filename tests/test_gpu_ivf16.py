@@ -85,6 +85,18 @@ def test_ivf_prefilter_handles_ties_zero_rows_and_few_candidates(ctx):
     _staged_and_prefiltered(ctx, X, off, nl, mz, None, 16, 250, 64, 20.0, "ppm", None)
 
 
+def test_ivf_prefilter_long_lists_take_the_second_pass_or_the_staged_scan(ctx):
+    """coarse indexes: ~300 rows per list.  8 probes = ~2,400 keys per query (select16's second pass with 64 keys per lane);
+    16 probes = ~4,800 keys, more than select16 holds in registers: the search keeps the exact staged scan for such an index."""
+    sizes = [9600, 2000]
+    nl = np.array([32, 16], np.int32)
+    off, X, mz, _ = _buckets(sizes, 128, 53)
+    _, n_fb = _staged_and_prefiltered(ctx, X, off, nl, mz, None, 8, 64, 32, 20.0, "ppm", None)
+    assert n_fb < 500
+    _, n_fb = _staged_and_prefiltered(ctx, X, off, nl, mz, None, 16, 64, 32, 20.0, "ppm", None)
+    assert n_fb == 0
+
+
 def test_pipeline_with_and_without_ivf_prefilter_is_identical(ctx):
     """whole path on synthetic spectra dense enough for IVF buckets: the prefilter changes nothing but the time"""
     from falcon_amd import synth
