@@ -7,8 +7,10 @@
 //      centroids on the f16 matrix cores (float32 accumulation, 1/16 of the fp32 cycles): best and runner-up per row.
 //      |approx - exact| <= eps(v) = 1.3e-3 v + 2e-6 (bound derived in fused.hip): if runner-up < best - 2.2 eps(best) the
 //      approximate winner IS the exact arg-max and is written; otherwise the row goes to a list;
-//   2. assign_exact_rows_kernel: the listed rows (a few per cent) against all their centroids by the exact k-ordered
-//      fmaf chain (VALU, bit-identical to the matrix-core chain), arg-max with ties -> lowest id.
+//   2. the listed rows (a few per cent) by the exact k-ordered fmaf chain (VALU, bit-identical to the matrix-core chain), arg-max
+//      with ties -> lowest id: assign_exact_pairs_kernel for rows with at most one contender (approximate value within the
+//      bound of the best) per 32-centroid group -- almost all of them: just the contenders, four lanes per row --,
+//      assign_exact_rows_kernel against all centroids for the rest.
 // The assignment -- and with it every centroid, list and search result -- is IDENTICAL to the exact kernels'
 // (tests/test_gpu_search.py builds both and compares bit for bit).  Reference: README.md:132-136 (Faiss IVF train / add).
 #include <hip/hip_fp16.h>
@@ -40,9 +42,11 @@ struct Assign16Args {
     const AssignJob* jobs;   // (row segment) x (ALL lists of the bucket, <= 128)
     int64_t n_jobs;
     int32_t* assign;         // [n]
-    int32_t* amb_list;       // (row, job) pairs left to the exact kernel
-    int32_t* amb_count;
+    int32_t* amb_list;       // (row, job) pairs left to the exact kernel over ALL centroids
+    int32_t* amb_count;      // [0] entries of amb_list, [1] entries of pair_list
     int amb_cap;
+    int32_t* pair_list;      // (row, job, <= 4 contender ids packed in bytes, 0xFF = none): rows with one contender per
+                             // 32-centroid group at most -- the exact kernel evaluates just those
 };
 
 __device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
@@ -111,13 +115,37 @@ __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
         }
         const int64_t row = job.row0 + c0 + lane;
         const float eps = kA16EpsRel * best + kA16EpsAbs;
-        if (second < best - 2.2f * eps) {
+        const float thr = best - 2.2f * eps;
+        if (second < thr) {
             a.assign[row] = job.id_base + bid;
-        } else {                                                     // too close to call in float16: exact re-evaluation
-            const int at = atomicAdd(a.amb_count, 1);
-            if (at < a.amb_cap) {
-                a.amb_list[2 * at] = (int32_t)row;
-                a.amb_list[2 * at + 1] = (int32_t)ji;
+        } else {
+            // too close to call in float16: exact re-evaluation of the contenders -- the centroids whose approximate value
+            // reaches thr.  A 32-centroid group whose runner-up stays below thr contributes its best only; if a runner-up
+            // reaches thr too, the group's other members are unknown here: all centroids are re-evaluated
+            uint32_t packed = 0xFFFFFFFFu;
+            bool full = false;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const float b = r_best[par][ww][lane], s2 = r_second[par][ww][lane];
+                if (b >= thr) packed = (packed & ~(0xFFu << (8 * ww))) | ((uint32_t)r_id[par][ww][lane] << (8 * ww));
+                full = full || s2 >= thr;
+            }
+            if (!full) {
+                const int at = atomicAdd(a.amb_count + 1, 1);
+                if (at < a.amb_cap) {
+                    a.pair_list[3 * at] = (int32_t)row;
+                    a.pair_list[3 * at + 1] = (int32_t)ji;
+                    a.pair_list[3 * at + 2] = (int32_t)packed;
+                } else {
+                    full = true;
+                }
+            }
+            if (full) {
+                const int at = atomicAdd(a.amb_count, 1);
+                if (at < a.amb_cap) {
+                    a.amb_list[2 * at] = (int32_t)row;
+                    a.amb_list[2 * at + 1] = (int32_t)ji;
+                }
             }
         }
     };
@@ -218,6 +246,34 @@ __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, c
     }
 }
 
+// the rows with at most one contender per 32-centroid group: four lanes per row, one exact chain each
+__global__ __launch_bounds__(256) void assign_exact_pairs_kernel(Assign16Args a, const float* __restrict__ X, const float* __restrict__ Cn,
+                                                                 int d) {
+    const int total = min(a.amb_count[1], a.amb_cap);
+    const int slot = threadIdx.x & 3;
+    for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 2; e < (((int64_t)total + 15) & ~15ll);
+         e += ((int64_t)gridDim.x * blockDim.x) >> 2) {
+        const bool live = e < total;
+        const int64_t row = live ? a.pair_list[3 * e] : 0;
+        const AssignJob job = a.jobs[live ? a.pair_list[3 * e + 1] : 0];
+        const uint32_t packed = live ? (uint32_t)a.pair_list[3 * e + 2] : 0xFFFFFFFFu;
+        int bid = (int)((packed >> (8 * slot)) & 0xFFu);
+        float best = -INFINITY;
+        if (bid != 0xFF) best = exact_dot(X + row * d, Cn + (job.cent0 + bid) * d, d);
+        else bid = 0x7fffffff;
+#pragma unroll
+        for (int off = 1; off <= 2; off <<= 1) {                    // (ties -> lowest id)
+            const float ob = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bid, off, 64);
+            if (ob > best || (ob == best && oi < bid)) {
+                best = ob;
+                bid = oi;
+            }
+        }
+        if (live && slot == 0) a.assign[row] = job.id_base + bid;
+    }
+}
+
 bool assign16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
 
 int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
@@ -235,9 +291,10 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     if (n_jobs <= 0) return FAL_OK;
     int32_t* amb = nullptr;
     const int amb_cap = 1 << 24;
-    FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(2 * amb_cap + 16), (void**)&amb));
+    FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(5 * (size_t)amb_cap + 16), (void**)&amb));
     FAL_CHECK_HIP(hipMemsetAsync(amb, 0, sizeof(int32_t) * 16, ctx->stream));
-    Assign16Args a{reinterpret_cast<const __half*>(X16), reinterpret_cast<const __half*>(C16), jobs, n_jobs, assign, amb + 16, amb, amb_cap};
+    Assign16Args a{reinterpret_cast<const __half*>(X16), reinterpret_cast<const __half*>(C16), jobs, n_jobs, assign, amb + 16, amb, amb_cap,
+                   amb + 16 + 2 * (size_t)amb_cap};
     const int64_t per_xcd = (n_jobs + 7) / 8;
     StageScope ts(ctx, stage);
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
@@ -248,6 +305,7 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
         case 25: hipLaunchKernelGGL((assign16_kernel<25>), grid, block, 0, ctx->stream, a); break;
         default: set_error("assign16: low_dim %d has no instantiation", d); return FAL_EUNSUPPORTED;
     }
+    hipLaunchKernelGGL(assign_exact_pairs_kernel, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, ctx->stream, a, X, Cn, d);
     hipLaunchKernelGGL(assign_exact_rows_kernel, dim3((unsigned)(ctx->num_cus * 16)), dim3(64), 0, ctx->stream, a, X, Cn, d);
     FAL_CHECK_HIP(hipGetLastError());
     if (!ctx->fb_host) FAL_CHECK_HIP(hipHostMalloc((void**)&ctx->fb_host, 64, hipHostMallocDefault));
