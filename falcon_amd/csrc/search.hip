@@ -97,6 +97,22 @@ __global__ void probe_scatter_kernel(const int32_t* __restrict__ probes, int np,
     }
 }
 
+// entries per list (the histogram of the probe table), one workgroup per bucket with the counters in LDS
+__global__ __launch_bounds__(1024) void probe_hist_bucket_kernel(const int32_t* __restrict__ probes, int np,
+                                                                 const DenseJob* __restrict__ jobs, int32_t* __restrict__ cnt) {
+    extern __shared__ int32_t hist[];
+    const DenseJob job = jobs[blockIdx.x];
+    const int nl = job.nc;
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int64_t e = threadIdx.x; e < (int64_t)job.nq * np; e += blockDim.x) {
+        const int l = probes[job.q_row0 * np + e];
+        if (l >= 0) atomicAdd(&hist[l], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) cnt[job.c_row0 + i] = hist[i];
+}
+
 // The same table with every list's entries in ASCENDING QUERY ORDER (to within one chunk of 1,024 queries): one workgroup per
 // bucket walks the bucket's queries chunk by chunk, cursors in LDS.  The fine-scan kernels stream a list's queries in table
 // order; the ~64 lists of a bucket that run concurrently on an XCD then sweep the bucket's rows together and share them in L2
@@ -471,8 +487,13 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     {
         StageScope ts(ctx, ST_COARSE);
         const unsigned pg = (unsigned)ceil_div(n_slots, 256);
-        hipLaunchKernelGGL(probe_hist_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
-                           ivf_tiles, cnt);
+        static const bool unordered_hist = getenv("FALCON_PROBE_TABLE_UNORDERED") != nullptr;
+        if (max_n_list <= 16384 && !unordered_hist)
+            hipLaunchKernelGGL(probe_hist_bucket_kernel, dim3((unsigned)coarse.size()), dim3(1024), sizeof(int32_t) * (size_t)max_n_list,
+                               st, probes, np, coarse_dev, cnt);
+        else
+            hipLaunchKernelGGL(probe_hist_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
+                               ivf_tiles, cnt);
         FAL_TRY(device_scan_i32(ctx, cnt, TL, inv_off, SLOT_MISC2));
         const dim3 tg((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024));
         hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, group_shift,
