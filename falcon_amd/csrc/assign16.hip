@@ -47,11 +47,13 @@ struct Assign16Args {
     int amb_cap;
     int32_t* pair_list;      // (row, job, <= 4 contender ids packed in bytes, 0xFF = none): rows with one contender per
                              // 32-centroid group at most -- the exact kernel evaluates just those
+    uint16_t* ckeys;         // optional [n, 128]: round(approximate similarity * 65535) of every (row, centroid) pair -- the final
+                             // pass leaves them for the coarse quantiser of the search (coarse16.hip)
 };
 
 __device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
 
-template <int STEPS>
+template <int STEPS, bool KEYS>
 __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
     constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int RB16 = D / 8;
@@ -171,6 +173,20 @@ __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        if constexpr (KEYS) {                                        // (the final pass; four keys per 8-byte store, no branch: rows
+            //  past the segment re-write the last row's keys with the same values)
+            uint16_t* kp = a.ckeys + (job.row0 + min(c0 + r, nr - 1)) * (int64_t)kAssignGroup + 32 * w + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t lo2 = 0, hi2 = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const uint32_t key = __float2uint_rn(__builtin_amdgcn_fmed3f(acc[4 * g + x], 0.f, 1.f) * 65535.f);
+                    if (x < 2) lo2 |= key << (16 * x); else hi2 |= key << (16 * (x - 2));
+                }
+                *reinterpret_cast<uint2*>(kp + 8 * g) = make_uint2(lo2, hi2);
+            }
+        }
         // this lane's row against its 16 centroids (of the wave's 32): best, runner-up
         float best = -INFINITY, second = -INFINITY;
         int bid = 0x7fffffff;
@@ -287,22 +303,28 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
 
 // jobs: device table of `n_jobs` jobs, each covering ALL (<= 128) lists of its bucket
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
-                    const AssignJob* jobs, int64_t n_jobs, int32_t* assign) {
+                    const AssignJob* jobs, int64_t n_jobs, int32_t* assign, uint16_t* ckeys) {
     if (n_jobs <= 0) return FAL_OK;
     int32_t* amb = nullptr;
     const int amb_cap = 1 << 24;
     FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(5 * (size_t)amb_cap + 16), (void**)&amb));
     FAL_CHECK_HIP(hipMemsetAsync(amb, 0, sizeof(int32_t) * 16, ctx->stream));
     Assign16Args a{reinterpret_cast<const __half*>(X16), reinterpret_cast<const __half*>(C16), jobs, n_jobs, assign, amb + 16, amb, amb_cap,
-                   amb + 16 + 2 * (size_t)amb_cap};
+                   amb + 16 + 2 * (size_t)amb_cap, ckeys};
     const int64_t per_xcd = (n_jobs + 7) / 8;
     StageScope ts(ctx, stage);
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
     switch (d / 16) {
-        case 4: hipLaunchKernelGGL((assign16_kernel<4>), grid, block, 0, ctx->stream, a); break;
-        case 8: hipLaunchKernelGGL((assign16_kernel<8>), grid, block, 0, ctx->stream, a); break;
-        case 16: hipLaunchKernelGGL((assign16_kernel<16>), grid, block, 0, ctx->stream, a); break;
-        case 25: hipLaunchKernelGGL((assign16_kernel<25>), grid, block, 0, ctx->stream, a); break;
+#define FAL_LAUNCH_A16(S)                                                                                  \
+    do {                                                                                                   \
+        if (ckeys) hipLaunchKernelGGL((assign16_kernel<S, true>), grid, block, 0, ctx->stream, a);         \
+        else hipLaunchKernelGGL((assign16_kernel<S, false>), grid, block, 0, ctx->stream, a);              \
+    } while (0)
+        case 4: FAL_LAUNCH_A16(4); break;
+        case 8: FAL_LAUNCH_A16(8); break;
+        case 16: FAL_LAUNCH_A16(16); break;
+        case 25: FAL_LAUNCH_A16(25); break;
+#undef FAL_LAUNCH_A16
         default: set_error("assign16: low_dim %d has no instantiation", d); return FAL_EUNSUPPORTED;
     }
     hipLaunchKernelGGL(assign_exact_pairs_kernel, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, ctx->stream, a, X, Cn, d);

@@ -1,0 +1,24 @@
+// Internal interface of coarse16.hip: the coarse quantiser of the search from the 16-bit keys of the final k-means pass.
+#pragma once
+#include "common.h"
+#include "simtile.h"
+
+namespace fal {
+
+struct Coarse16Args {
+    const uint16_t* ckeys;       // [n, 128] by sorted row
+    const float* X;              // [n, d] float32 rows, sorted order (exact re-evaluation of close calls)
+    const float* C;              // [total_lists, d] centroids
+    int d;
+    const DenseJob* jobs;        // IVF tile table (q_row0 = first list-order position of the bucket, c_row0 = its list 0, nc = n_list)
+    int n_jobs;
+    int64_t n_tiles;
+    const int32_t* tile_job;     // (filled by launch_coarse16)
+    const int32_t* perm;         // [n] list-order position -> sorted row
+    int np;                      // probes per query
+    int32_t* probes;             // [n, np] by list-order position: the chosen bucket-local lists in ascending id, -1 behind them
+};
+
+int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a);
+
+}  // namespace fal

@@ -1,0 +1,164 @@
+// a7 coarse quantiser from the keys the index build left behind.
+//
+// The final k-means pass (assign16.hip) already computes every (row, centroid) similarity of a bucket on the f16 matrix cores
+// -- against the FINAL centroids, which is exactly what the coarse quantiser of the search needs.  It leaves them as 16-bit
+// keys round(v * 65535) ([n, 128] by sorted row).  Here: the n_probe best centroids of every query from those keys, exact where
+// it matters.  With T~ the n_probe-th largest key and |key / 65535 - exact| <= e(v) = 1.3e-3 v + 1.2e-5 (ivf16.hip), a key above
+// T~ + 2e is certainly among the n_probe best, one below T~ - 2e certainly not; the keys in between ("members") decide the
+// rest.  If there are exactly as many members as open places they all are in; otherwise (two centroids about equally far: a
+// few per cent of the queries) the members are re-evaluated by the exact k-ordered fmaf chain and ranked by (similarity
+// descending, list id ascending) -- the order of the staged coarse scan + select.  The probe SET is identical to the staged
+// path's; its order inside a query is by list id (nothing depends on it: every consumer reads the same table).
+//
+// 16 lanes per query (8 keys each), 4 queries per wave: the counts of the bitwise threshold search are 16-bit slices of one
+// ballot.  Replaces a [n, n_list] fp32-MFMA scan + a wavefront select (13 + 6 ms at 10 M spectra).
+//
+// Reference: README.md:107-113 (n_probe lists per query); faiss IndexIVFFlat's quantizer->search is a dependency of the
+// reference, not in the snapshot.
+#include <math.h>
+#include <algorithm>
+#include "common.h"
+#include "scan.h"
+#include "ivf.h"
+#include "coarse16.h"
+
+namespace fal {
+
+constexpr int kCoarseMem = 128;          // members a query can hold (every key, in the worst case)
+
+__global__ __launch_bounds__(256) void coarse16_kernel(Coarse16Args a) {
+    __shared__ float m_val[16][kCoarseMem];
+    __shared__ int32_t m_id[16][kCoarseMem];
+    __shared__ int32_t q_cnt[16];
+    __shared__ int64_t q_row[16], q_cbase[16];
+    const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, sub = lane & 15, qw = tid >> 4;
+    const int64_t g = (int64_t)blockIdx.x * 16 + qw;                 // tile-order slot of this 16-lane group's query
+    const int64_t t = g >> 5;
+    const int ql = (int)(g & 31);
+    bool live = t < a.n_tiles;
+    DenseJob job{};
+    if (live) job = a.jobs[a.tile_job[t]];
+    const int lt = (int)(t - job.tile0);
+    live = live && 32 * lt + ql < job.nq;
+    const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;
+    const int64_t row = live ? a.perm[p] : 0;
+    const int nl = live ? job.nc : 0;
+    const int np = a.np;
+    uint32_t u[8];
+    {
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (live) raw = *reinterpret_cast<const uint4*>(a.ckeys + row * (int64_t)kAssignGroup + sub * 8);
+        const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = (sub * 8 + j < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
+    }
+    const int want = min(np, nl);                                     // probes of this query
+    const int sh = 16 * grp;
+    auto gcount = [&](bool pred) -> int { return __popc((uint32_t)(__ballot(pred) >> sh) & 0xFFFFu); };
+    // T = the want-th largest key of the group (largest T with count(u >= T) >= want)
+    uint32_t T = 0;
+    for (int bit = 16; bit >= 0; --bit) {
+        const uint32_t c = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt += gcount(u[j] >= c);
+        if (cnt >= want && want > 0) T = c;
+    }
+    const float Tv = (float)(max(T, 1u) - 1u) * (1.f / 65535.f);
+    const float e = 1.3e-3f * Tv + 1.2e-5f;
+    const int delta = 2 * ((int)ceilf(e * 65535.f) + 1) + 2;
+    int n_hi = 0, n_mem = 0;
+    bool hi[8], mem[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int df = (int)u[j] - (int)T;
+        hi[j] = u[j] != 0u && df > delta;
+        mem[j] = u[j] != 0u && df <= delta && df >= -delta;
+        n_hi += gcount(hi[j]);
+        n_mem += gcount(mem[j]);
+    }
+    const int need = want - n_hi;                                     // places left for the members (1 .. n_mem when want > 0)
+    const bool ambiguous = want > 0 && n_mem > need;
+    // Exact values for the members of the ambiguous queries.  A chain is serial (400 dependent fmaf), so the members of all 16
+    // queries of the workgroup are pooled: item i of the pool goes to thread i -- normally they all fit the first wave, and
+    // the other three do not run a chain at all (one per wave for two or three busy lanes was most of this kernel's time).
+    if (sub == 0) {
+        q_cnt[qw] = ambiguous ? n_mem : 0;
+        q_row[qw] = row;
+        q_cbase[qw] = job.c_row0;
+    }
+    {
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t gm = (uint32_t)(__ballot(mem[j] && ambiguous) >> sh) & 0xFFFFu;
+            if (mem[j] && ambiguous) m_id[qw][base + __popc(gm & ((1u << sub) - 1u))] = sub * 8 + j;
+            base += __popc(gm);
+        }
+    }
+    __syncthreads();
+    {
+        int off[17];
+        off[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) off[k + 1] = off[k] + q_cnt[k];
+        for (int i = tid; i < off[16]; i += 256) {
+            int k = 0;
+#pragma unroll
+            for (int kk = 1; kk < 16; ++kk) k = off[kk] <= i ? kk : k;
+            const int m = i - off[k];
+            m_val[k][m] = exact_dot(a.X + q_row[k] * a.d, a.C + (q_cbase[k] + m_id[k][m]) * (int64_t)a.d, a.d);
+        }
+    }
+    __syncthreads();
+    if (ambiguous) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (!mem[j]) continue;
+            const int me = sub * 8 + j;
+            float mine = 0.f;
+            for (int i = 0; i < n_mem; ++i) mine = m_id[qw][i] == me ? m_val[qw][i] : mine;
+            int rank = 0;
+            for (int i = 0; i < n_mem; ++i) {
+                const float v = m_val[qw][i];
+                const int id = m_id[qw][i];
+                rank += (v > mine || (v == mine && id < me)) ? 1 : 0;
+            }
+            mem[j] = rank < need;
+        }
+    }
+    // the probe table row: chosen lists in ascending id, -1 behind them
+    int32_t* out = a.probes + p * np;
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool in = live && want > 0 && (hi[j] || mem[j]);
+        const uint32_t gm = (uint32_t)(__ballot(in) >> sh) & 0xFFFFu;
+        if (in) out[base + __popc(gm & ((1u << sub) - 1u))] = sub * 8 + j;
+        base += __popc(gm);
+    }
+    if (live)
+        for (int i = want + sub; i < np; i += 16) out[i] = -1;
+}
+
+__global__ void tile_job_c16_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t n_tiles, int32_t* __restrict__ tile_job) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n_tiles) tile_job[i] = find_job(jobs, n_jobs, i);
+}
+
+int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
+    if (a_in.n_tiles <= 0) return FAL_OK;
+    Coarse16Args a = a_in;
+    int32_t* tj = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)std::max<int64_t>(a.n_tiles, 1 << 16), (void**)&tj));
+    StageScope ts(ctx, ST_COARSE);
+    hipLaunchKernelGGL(tile_job_c16_kernel, dim3((unsigned)ceil_div(a.n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
+                       a.n_tiles, tj);
+    a.tile_job = tj;
+    FAL_REQUIRE(a.n_tiles * 2 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one coarse launch");
+    hipLaunchKernelGGL(coarse16_kernel, dim3((unsigned)(a.n_tiles * 2)), dim3(256), 0, ctx->stream, a);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+}  // namespace fal

@@ -214,7 +214,7 @@ extern "C" {
 int fal_ivf_destroy(fal_ivf* ivf) {
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
-                    ivf->Xl16, ivf->pos_of_row};
+                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -424,7 +424,12 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                     StageScope ts(ctx, ST_BUILD);
                     B_TRY(launch_cvt_f16(ctx, ivf->centroids, C16, total * low_dim));
                 }
-                B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, (int64_t)hjobs.size(), ivf->assign));
+                // the final pass leaves its approximate similarities behind for the coarse quantiser (coarse16.hip)
+                static const bool no_ckeys = getenv("FALCON_NO_COARSE16") != nullptr;
+                if (it == kmeans_iters && !no_ckeys && djobs.empty() && ajobs.empty())
+                    B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kAssignGroup, (void**)&ivf->ckeys));
+                B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, (int64_t)hjobs.size(), ivf->assign,
+                                      it == kmeans_iters ? ivf->ckeys : nullptr));
             }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,

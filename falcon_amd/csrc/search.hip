@@ -14,6 +14,7 @@
 #include "util.h"
 #include "fused.h"
 #include "ivf16.h"
+#include "coarse16.h"
 
 namespace fal {
 
@@ -442,7 +443,14 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     FAL_TRY(ctx->reserve(SLOT_QOFF, sizeof(int64_t) * (size_t)(n_slots + 1), (void**)&q_sim_off));
     FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (size_t)(n_slots + 2), (void**)&totals));
     FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(n_slots + 2), st));
-    for (size_t bi = 0; bi + 1 < coarse_cuts.size(); ++bi) {
+    // the final k-means pass left the (row, centroid) similarities behind as 16-bit keys: no second scan (coarse16.hip)
+    static const bool no_c16 = getenv("FALCON_NO_COARSE16") != nullptr;
+    const bool from_keys = ivf->ckeys != nullptr && ivf->X != nullptr && !no_c16;
+    if (from_keys) {
+        Coarse16Args ca{ivf->ckeys, ivf->X, ivf->centroids, d, coarse_dev, (int)coarse.size(), ivf_tiles, nullptr, ivf->perm, np, probes};
+        FAL_TRY(launch_coarse16(ctx, ca));
+    }
+    for (size_t bi = 0; !from_keys && bi + 1 < coarse_cuts.size(); ++bi) {
         const int64_t t0 = coarse_cuts[bi], t1 = coarse_cuts[bi + 1];
         const int64_t base = obase_of_tile(coarse, t0);
         FAL_TRY(launch_dense(ctx, ST_COARSE, EPI_STORE, ivf->Xl, ivf->centroids, d, coarse_dev, (int)coarse.size(), t0,

@@ -97,6 +97,31 @@ def test_ivf_prefilter_long_lists_take_the_second_pass_or_the_staged_scan(ctx):
     assert n_fb == 0
 
 
+@pytest.mark.parametrize("d,n_probe", [(400, 16), (400, 3), (128, 8), (64, 1)])
+def test_coarse_quantiser_from_the_build_keys_gives_the_same_search(ctx, d, n_probe):
+    """an index built with the float16 k-means prefilter keeps the final pass's (row, centroid) similarities as 16-bit keys and
+    its search takes the n_probe lists from them (coarse16.hip) instead of scanning again: same top-k, bit for bit -- with
+    identical centroids (exact ties between lists) and all-zero rows in the data"""
+    import torch
+    sizes = [6000, 300, 2500, 9000, 1300]
+    nl = np.array([64, 1, 32, 128, 16], np.int32)
+    off, X, mz, rt = _buckets(sizes, d, 61)
+    X[off[3]:off[3] + 9000:70] = X[off[3]]                    # the k-means seeds of bucket 3 (every 70th row): identical centroids
+    X[off[0] + 5:off[0] + 40] = 0
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    plain = ctx.ivf_build(Xd, off, nl, kmeans_iters=3)
+    keyed = ctx.ivf_build(Xd, off, nl, kmeans_iters=3, Xkm=Xd.to(torch.float16).contiguous())
+    s0, i0 = plain.search(n_probe, 64)
+    s1, i1 = keyed.search(n_probe, 64)
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    mz_d = torch.from_numpy(mz).to(ctx.tdev)
+    n0 = plain.search_neighbors(n_probe, 64, mz_d, None, 20.0, "ppm", None, 32)
+    pre = ctx.ivf_build(Xd, off, nl, kmeans_iters=3, Xkm=Xd.to(torch.float16).contiguous(), Xpre=Xd.to(torch.float16).contiguous(),
+                        prefilter_which=2)
+    n1 = pre.search_neighbors(n_probe, 64, mz_d, None, 20.0, "ppm", None, 32)
+    assert torch.equal(n0[0], n1[0]) and torch.equal(n0[1].view(torch.int32), n1[1].view(torch.int32))
+
+
 def test_pipeline_with_and_without_ivf_prefilter_is_identical(ctx):
     """whole path on synthetic spectra dense enough for IVF buckets: the prefilter changes nothing but the time"""
     from falcon_amd import synth
