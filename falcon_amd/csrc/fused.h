@@ -56,7 +56,6 @@ struct FusedArgs {
     const int32_t* probes;       // [n, n_probe] by list-order position (-1 = none)
     int n_probe;
     int mask_words;              // 32-bit words of one query's probe mask (>= max n_list / 32)
-    const float* Xl;             // rows in list order (exact fallback)
     const int64_t* list_off;     // [total_lists + 1]
     const int32_t* perm;         // [n] list-order position -> sorted row
 };

@@ -760,7 +760,8 @@ __global__ __launch_bounds__(64) void ivf_fallback_kernel(FusedArgs a, SelectArg
         const float* qp = a.X + row * d;
         for (int j = 0; j < np; ++j) {
             const int64_t o = seg_off[j], len = min<int64_t>(seg_off[j + 1], nc) - o;
-            for (int64_t i = lane; i < len; i += 64) row_s[o + i] = exact_dot(qp, a.Xl + (seg_src[j] + i) * d, d);
+            for (int64_t i = lane; i < len; i += 64)            // (list-order position -> sorted row: no list-order copy of X needed)
+                row_s[o + i] = exact_dot(qp, a.X + (int64_t)a.perm[seg_src[j] + i] * d, d);
         }
         __threadfence();
         __syncthreads();

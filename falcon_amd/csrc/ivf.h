@@ -12,13 +12,17 @@ enum { SLOT_JOBS = 0, SLOT_SIMS = 1, SLOT_PROBES = 2, SLOT_PROBE_SIM = 3, SLOT_Q
 // out[0..n] = exclusive prefix sums of in[0..n) (out has n + 1 entries)
 int launch_exclusive_scan(fal_ctx* ctx, const int64_t* in, int64_t n, int64_t* out);
 }
+struct fal_ivf;
+namespace fal {
+int ivf_ensure_xl(fal_ctx* ctx, const fal_ivf* ivf);      // Xl = X[perm] (float32 rows in list order), made once on demand
+}
 
 struct fal_ivf {
     fal_ctx* ctx = nullptr;
     int64_t n = 0;
     int d = 0;
     const float* X = nullptr;        // caller's vectors, precursor-sorted rows (borrowed)
-    const float* Xl = nullptr;       // the same rows in (bucket, list, row) order (== X when all flat)
+    const float* Xl = nullptr;       // the same rows in (bucket, list, row) order (== X when all flat; else made on demand: ivf_ensure_xl)
     float* Xl_owned = nullptr;
     const void* X16 = nullptr;       // optional f16 rows (sorted order) for the flat scan: [n, planes, d]
     int x16_planes = 0;

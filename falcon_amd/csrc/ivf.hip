@@ -195,6 +195,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+int ivf_ensure_xl(fal_ctx* ctx, const fal_ivf* civf) {
+    fal_ivf* ivf = const_cast<fal_ivf*>(civf);              // (a cache inside the index handle)
+    if (ivf->Xl != nullptr || ivf->n == 0) return FAL_OK;
+    FAL_REQUIRE(ivf->X != nullptr, FAL_EINVAL, "the index has no float32 rows");
+    FAL_TRY(ctx->pool_alloc(sizeof(float) * (size_t)ivf->n * ivf->d, (void**)&ivf->Xl_owned));
+    StageScope ts(ctx, ST_SCAN);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(ivf->n, 4), ctx->num_cus * 16)), dim3(256), 0,
+                       ctx->stream, ivf->X, ivf->perm, ivf->n, ivf->d, ivf->Xl_owned);
+    FAL_CHECK_HIP(hipGetLastError());
+    ivf->Xl = ivf->Xl_owned;
+    return FAL_OK;
+}
+
 int launch_exclusive_scan(fal_ctx* ctx, const int64_t* in, int64_t n, int64_t* out) {
     hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, in, n, out);
     FAL_CHECK_HIP(hipGetLastError());
@@ -451,11 +464,9 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         hipLaunchKernelGGL(list_walk_kernel<2>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
                            nbk, nullptr, nullptr, ivf->list_off, ivf->perm);
         B_HIP(hipGetLastError());
-        B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * low_dim, (void**)&ivf->Xl_owned));
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), ctx->num_cus * 16)),
-                           dim3(256), 0, st, X, ivf->perm, n, low_dim, ivf->Xl_owned);
-        B_HIP(hipGetLastError());
-        ivf->Xl = ivf->Xl_owned;
+        // the float32 rows in list order are made on demand (fal_ivf_ensure_xl: the staged fine scan and the staged coarse scan read
+        // them; the default path -- coarse quantiser from the build's keys, float16 prefilter -- does not: 16 GB at 10 M spectra)
+        ivf->Xl = nullptr;
     } else {
         hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, ivf->counts, total, ivf->list_off);
         B_HIP(hipGetLastError());

@@ -395,7 +395,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             FAL_TRY(launch_scan16(ctx, ivf->x16_planes, ivf->X16, d, jb, (int)(fb.jm - fb.j0), fb.list_tiles16, buf, 0,
                                   buf + (b ? need_flat : sims_floats)));
         if (fb.j1 > fb.jm)
-            FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->Xl, ivf->Xl, d, flat_dev + fb.jm, (int)(fb.j1 - fb.jm), 0,
+            // (flat buckets keep their rows' positions in list order: the sorted rows serve)
+            FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->X, ivf->X, d, flat_dev + fb.jm, (int)(fb.j1 - fb.jm), 0,
                                  fb.tiles, buf, 0, nullptr, fb.list_tiles32));
         SelectArgs sa{};
         sa.sims = buf; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
@@ -450,6 +451,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         Coarse16Args ca{ivf->ckeys, ivf->X, ivf->centroids, d, coarse_dev, (int)coarse.size(), ivf_tiles, nullptr, ivf->perm, np, probes};
         FAL_TRY(launch_coarse16(ctx, ca));
     }
+    if (!from_keys) FAL_TRY(ivf_ensure_xl(ctx, ivf));
     for (size_t bi = 0; !from_keys && bi + 1 < coarse_cuts.size(); ++bi) {
         const int64_t t0 = coarse_cuts[bi], t1 = coarse_cuts[bi + 1];
         const int64_t base = obase_of_tile(coarse, t0);
@@ -577,7 +579,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         fa.k = k_ann; fa.pmz = nf->pmz; fa.rt = nf->rt; fa.tol = nf->tol; fa.rt_tol = nf->rt_tol; fa.is_da = nf->is_da;
         fa.keep = nf->keep; fa.nb_idx = nf->nb_idx; fa.nb_dist = nf->nb_dist; fa.nb_count = nf->nb_count;
         fa.ivf = 1; fa.assign = ivf->assign; fa.pos_of_row = ivf->pos_of_row; fa.probes = probes; fa.n_probe = np;
-        fa.mask_words = (max_n_list + 31) / 32; fa.Xl = ivf->Xl; fa.list_off = ivf->list_off; fa.perm = ivf->perm;
+        fa.mask_words = (max_n_list + 31) / 32; fa.list_off = ivf->list_off; fa.perm = ivf->perm;
         FAL_TRY(fused_prepare(ctx, &fa, ivf->n));
         uint16_t* keys = nullptr;
         FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(uint16_t) * (need_fine + 2 * kSimsSlack), (void**)&keys));
@@ -605,6 +607,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         return FAL_OK;
     }
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (need_fine + kSimsSlack), (void**)&sims));
+    FAL_TRY(ivf_ensure_xl(ctx, ivf));
     for (const IvfBatch& bt : ivf_batches) {
         const DenseJob &first = coarse[bt.j0], &last = coarse[bt.j1 - 1];
         const int64_t t0 = first.tile0, t1 = last.tile0 + ceil_div(last.nq, 32);
