@@ -347,3 +347,35 @@ def test_pipeline_f16_large_bucket_is_searched_exhaustively(ctx):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert adjusted_rand_score(lab32, lab16) >= 0.99          # same vectors up to float16 rounding
+
+
+def test_partition_runner_concurrent_streams_equal_run(ctx):
+    """the charge partitions on concurrent host threads / HIP streams / contexts (PartitionRunner, what bench.py times at 1 M
+    spectra) give exactly the results of `run` one partition after the other -- flat and IVF buckets, several passes (the
+    runner's contexts and scratch pools are reused), an empty partition in between."""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, PartitionRunner, SpectrumDataset
+    data = synth.generate(40000, seed=17, mz_lo=600.0, mz_hi=606.0)          # dense enough for buckets with an index
+    parts = []
+    for ch in (2, 3):
+        d = synth.select_charge(data, ch)
+        parts.append(SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"]))
+    empty = SpectrumDataset(np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.float32),
+                            np.zeros(0, np.float32), np.zeros(1, np.int64))
+    parts = [parts[0], empty, parts[1]]
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, AnnParams())
+    pipe = ClusterPipeline(ctx)
+    ref = []
+    for ds in parts:
+        lab, med = pipe.run(ds, *args)
+        ref.append((lab.cpu().numpy(), med.cpu().numpy()))
+    assert int(pipe.last["n_list"].max()) > 1
+    runner = PartitionRunner(0, 2)
+    try:
+        for _ in range(3):
+            outs = runner.run(parts, *args)
+            for (lab, med), (rl, rm) in zip(outs, ref):
+                assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm)
+    finally:
+        runner.close()
