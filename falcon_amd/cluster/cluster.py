@@ -161,16 +161,18 @@ class ClusterPipeline:
             if not all_flat:
                 X = vec("f32")              # k-means, coarse quantiser and IVF fine scan stay exact fp32
         else:
-            X = vec("f32")
             ok16 = p.low_dim in (64, 128, 256, 400)
             if p.prefilter and not keep_intermediates and ok16 and bool((n_list == 1).any()):
                 which |= 1
             if p.ivf_prefilter and not keep_intermediates and ok16 and bool((n_list > 1).any()):
                 which |= 2
-            if p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 128)).any()):
-                Xkm = vec("f16")
-            if which:
-                Xpre = Xkm if Xkm is not None else vec("f16")
+            want_km = p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 128)).any())
+            if want_km or which:
+                X, x16 = vec("f32+f16")            # the float16 rounding of the same rows, from the same pass over the peaks
+                Xkm = x16 if want_km else None
+                Xpre = x16 if which else None
+            else:
+                X = vec("f32")
         index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre, Xkm=Xkm, prefilter_which=max(which, 1))
         if keep_intermediates:
             sim, idx = index.search(p.n_probe, p.n_neighbors_ann)

@@ -43,7 +43,7 @@ template <int OUT_F16>
 __global__ __launch_bounds__(64) void vectorize_kernel(
     const float* __restrict__ mz, const float* __restrict__ inten, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out) {
+    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out, void* __restrict__ out2) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t passes = (d + 255) / 256;
     float* acc = reinterpret_cast<float*>(smem);                 // passes*256 floats
@@ -127,7 +127,9 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
                     uint2 pk;
                     pk.x = *reinterpret_cast<uint32_t*>(&a);
                     pk.y = *reinterpret_cast<uint32_t*>(&b);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(out) + r * (int64_t)d + e) = pk;
+                    // OUT_F16 == 3: the float32 row to `out` AND its float16 rounding to `out2` (one pass over the peaks)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(OUT_F16 == 3 ? out2 : out) + r * (int64_t)d + e) = pk;
+                    if (OUT_F16 == 3) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
                 }
@@ -159,15 +161,34 @@ int fal_to_vector_indices(fal_ctx* ctx, const float* mz, int64_t nnz, double min
     return FAL_OK;
 }
 
+static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                          const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2);
+
 int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                   const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                   uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out) {
+    FAL_REQUIRE(out_dtype == FAL_DTYPE_F32 || out_dtype == FAL_DTYPE_F16 || out_dtype == FAL_DTYPE_SPLIT16, FAL_EINVAL,
+                "fal_vectorize: bad out_dtype");
+    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out_dtype, out,
+                          nullptr);
+}
+
+int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                       const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                       uint32_t low_dim, uint32_t seed, int normalize, float* out_f32, void* out_f16) {
+    FAL_REQUIRE(n == 0 || out_f16, FAL_EINVAL, "fal_vectorize_pair: NULL array");
+    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, -3, out_f32,
+                          out_f16);
+}
+
+static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                          const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2) {
     FAL_REQUIRE(ctx, FAL_EINVAL, "fal_vectorize: NULL ctx");
     FAL_REQUIRE(n >= 0 && bin_size > 0 && n_bins > 0, FAL_EINVAL, "fal_vectorize: bad sizes");
     FAL_REQUIRE(low_dim >= 8 && low_dim <= FAL_MAX_LOW_DIM && low_dim % 8 == 0, FAL_EUNSUPPORTED,
                 "fal_vectorize: low_dim must be a multiple of 8 in [8, %d] (got %u)", FAL_MAX_LOW_DIM, low_dim);
-    FAL_REQUIRE(out_dtype == FAL_DTYPE_F32 || out_dtype == FAL_DTYPE_F16 || out_dtype == FAL_DTYPE_SPLIT16, FAL_EINVAL,
-                "fal_vectorize: bad out_dtype");
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(indptr && out, FAL_EINVAL, "fal_vectorize: NULL array");
     ctx->stage_reset(fal::ST_VECTORIZE);
@@ -176,15 +197,18 @@ int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const i
     const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 32);
     {
         fal::StageScope t(ctx, fal::ST_VECTORIZE);
-        if (out_dtype == FAL_DTYPE_SPLIT16)
+        if (out_dtype == -3)
+            hipLaunchKernelGGL(vectorize_kernel<3>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
+        else if (out_dtype == FAL_DTYPE_SPLIT16)
             hipLaunchKernelGGL(vectorize_kernel<2>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
         else if (out_dtype == FAL_DTYPE_F16)
             hipLaunchKernelGGL(vectorize_kernel<1>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
         else
             hipLaunchKernelGGL(vectorize_kernel<0>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
     }
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;

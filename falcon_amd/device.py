@@ -101,6 +101,12 @@ class Context:
         n = indptr.numel() - 1 if row_order is None else row_order.numel()
         f16 = dtype in ("f16", "float16")
         split = dtype == "split16"
+        if dtype == "f32+f16":           # one pass over the peaks, two outputs: float32 rows and their float16 rounding
+            out, out16 = self.empty((n, low_dim), torch.float32), self.empty((n, low_dim), torch.float16)
+            check(self.lib.fal_vectorize_pair(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
+                                              n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
+                                              int(normalize), self._p(out), self._p(out16)), "fal_vectorize_pair")
+            return out, out16
         if split:
             out, code = self.empty((n, 2, low_dim), torch.float16), _lib.FAL_DTYPE_SPLIT16
         else:

@@ -96,6 +96,11 @@ int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity,
                   const int64_t* indptr, const int64_t* row_order, int64_t n,
                   double min_mz, double bin_size, uint32_t n_bins,
                   uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out);
+/* The same with TWO outputs from one pass over the peaks: the float32 rows and their float16 rounding (the copy the
+ * float16 prefilters of the index build and of the search read; same values as fal_vectorize with FAL_DTYPE_F16). [dev] */
+int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                       const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                       uint32_t low_dim, uint32_t seed, int normalize, float* out_f32, void* out_f16);
 
 /* ---- a5  precursor-m/z bucket boundaries: reference cluster.py:159-209
  *          `_get_precursor_mz_splits` over the m/z-SORTED float32 precursor array,

@@ -72,6 +72,21 @@ def test_vectorize_vs_oracle(ctx, low_dim, dtype):
     assert np.all(np.abs(nrm[nz & (nrm > 0)] - 1) < tol)
 
 
+@pytest.mark.parametrize("low_dim", [64, 400, 800])
+def test_vectorize_pair_equals_the_two_single_outputs(ctx, low_dim):
+    """`fal_vectorize_pair`: float32 rows and their float16 rounding from ONE pass over the peaks == the two separate calls,
+    bit for bit, with a row order (gather) and empty spectra in the input"""
+    import torch
+    from falcon_amd import synth
+    d = synth.generate(3000, seed=5)
+    _, start, _ = fo.get_dim(101, 1500, 0.05)
+    order = torch.from_numpy(np.random.default_rng(1).permutation(3000)[:2500].astype(np.int64))
+    args = (d["mz"], d["intensity"], d["indptr"], order, start, 0.05, 27982, low_dim, 0, True)
+    a32, a16 = ctx.vectorize(*args, "f32+f16")
+    b32, b16 = ctx.vectorize(*args, "f32"), ctx.vectorize(*args, "f16")
+    assert torch.equal(a32.view(torch.int32), b32.view(torch.int32)) and torch.equal(a16.view(torch.int16), b16.view(torch.int16))
+
+
 def test_host_helpers(ref_golden):
     from falcon_amd.device import get_dim, hash_lookup
     g = ref_golden
