@@ -17,7 +17,7 @@ def agg(db, counter):
     return d
 f = agg("/tmp/pf/f_results.db", "FETCH_SIZE"); w = agg("/tmp/pw/w_results.db", "WRITE_SIZE")
 rows = sorted(f.items(), key=lambda kv: -(2 * kv[1][1] + w.get(kv[0], [0, 0])[1]))[:18]
-print("kernel".ljust(50), "launches", "fetch GB (x2)", "write GB", " (all launches of the run: 2 passes over 10 M)")
+print("kernel".ljust(50), "launches", "fetch GB (x2)", "write GB", " (all launches of the run: 4 passes over 10 M spectra)")
 for k, (n, fb) in rows:
     print(k.ljust(50), str(n).rjust(8), f"{2 * fb / 1e9:12.2f}", f"{w.get(k, [0, 0])[1] / 1e9:9.2f}")
 PY
