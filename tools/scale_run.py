@@ -6,8 +6,10 @@ N = int(sys.argv[1]); scan = sys.argv[2] if len(sys.argv) > 2 else "f32"
 n_probe = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"
 low_dim = int(sys.argv[5]) if len(sys.argv) > 5 else 400
+mz_lo = float(sys.argv[6]) if len(sys.argv) > 6 else 400.0      # a narrower precursor range = denser buckets (BASELINE configs[3] regime)
+mz_hi = float(sys.argv[7]) if len(sys.argv) > 7 else 1200.0
 ctx = dv.Context(0); pipe = ClusterPipeline(ctx)
-t = time.time(); data = synth.generate_device(N, ctx.tdev); print(f"generated {N} in {time.time()-t:.1f}s", flush=True)
+t = time.time(); data = synth.generate_device(N, ctx.tdev, mz_lo=mz_lo, mz_hi=mz_hi); print(f"generated {N} in {time.time()-t:.1f}s", flush=True)
 p = AnnParams(scan=scan, n_probe=n_probe, dtype=dtype, low_dim=low_dim)
 parts = []
 for ch in (2, 3):
