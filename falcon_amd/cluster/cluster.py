@@ -166,7 +166,7 @@ class ClusterPipeline:
                 which |= 1
             if p.ivf_prefilter and not keep_intermediates and ok16 and bool((n_list > 1).any()):
                 which |= 2
-            want_km = p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 128)).any())
+            want_km = p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 512)).any())
             if want_km or which:
                 X, x16 = vec("f32+f16")            # the float16 rounding of the same rows, from the same pass over the peaks
                 Xkm = x16 if want_km else None

@@ -49,11 +49,19 @@ struct Assign16Args {
                              // 32-centroid group at most -- the exact kernel evaluates just those
     uint16_t* ckeys;         // optional [n, 128]: round(approximate similarity * 65535) of every (row, centroid) pair -- the final
                              // pass leaves them for the coarse quantiser of the search (coarse16.hip)
+    // buckets with more than 128 lists (<= 512): one job per (row segment, group of 128 centroids) leaves the best / runner-up /
+    // best id of its four 32-centroid subgroups per row (PARTIAL), assign16_merge_kernel decides over all subgroups of the row
+    float* part_b;           // [16, n] best value of subgroup sg = 4 * group + wave
+    float* part_s;           // [16, n] its runner-up
+    int32_t* part_id;        // [16, n] bucket-local id of its best
+    int64_t n;               // rows (stride of the partial arrays)
+    const AssignJob* mjobs;  // merge jobs: (row segment) x (ALL lists of the bucket); the exact kernels' entries refer to these
+    int64_t n_mjobs;
 };
 
 __device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
 
-template <int STEPS, bool KEYS>
+template <int STEPS, bool KEYS, bool PARTIAL>
 __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
     constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int RB16 = D / 8;
@@ -100,6 +108,18 @@ __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
     // decision for the 32 rows of a finished chunk: lanes 0..31 of the duty wave combine the four waves' results
     auto decide = [&](int par, int c0) {
         if (lane >= 32 || c0 + lane >= nr) return;
+        if constexpr (PARTIAL) {                                     // this group's four subgroup summaries of the row
+            const int64_t row = job.row0 + c0 + lane;
+            const int g = job.id_base >> 7;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const int64_t at = (int64_t)(4 * g + ww) * a.n + row;
+                a.part_b[at] = r_best[par][ww][lane];
+                a.part_s[at] = r_second[par][ww][lane];
+                a.part_id[at] = job.id_base + r_id[par][ww][lane];
+            }
+            return;
+        }
         float best = -INFINITY, second = -INFINITY;
         int bid = 0x7fffffff;
 #pragma unroll
@@ -124,20 +144,21 @@ __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
             // too close to call in float16: exact re-evaluation of the contenders -- the centroids whose approximate value
             // reaches thr.  A 32-centroid group whose runner-up stays below thr contributes its best only; if a runner-up
             // reaches thr too, the group's other members are unknown here: all centroids are re-evaluated
-            uint32_t packed = 0xFFFFFFFFu;
+            uint32_t pk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};             // four contender ids, 16 bits each (0xFFFF = none)
             bool full = false;
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) {
                 const float b = r_best[par][ww][lane], s2 = r_second[par][ww][lane];
-                if (b >= thr) packed = (packed & ~(0xFFu << (8 * ww))) | ((uint32_t)r_id[par][ww][lane] << (8 * ww));
+                if (b >= thr) pk[ww >> 1] = (pk[ww >> 1] & ~(0xFFFFu << (16 * (ww & 1)))) | ((uint32_t)r_id[par][ww][lane] << (16 * (ww & 1)));
                 full = full || s2 >= thr;
             }
             if (!full) {
                 const int at = atomicAdd(a.amb_count + 1, 1);
                 if (at < a.amb_cap) {
-                    a.pair_list[3 * at] = (int32_t)row;
-                    a.pair_list[3 * at + 1] = (int32_t)ji;
-                    a.pair_list[3 * at + 2] = (int32_t)packed;
+                    a.pair_list[4 * at] = (int32_t)row;
+                    a.pair_list[4 * at + 1] = (int32_t)ji;
+                    a.pair_list[4 * at + 2] = (int32_t)pk[0];
+                    a.pair_list[4 * at + 3] = (int32_t)pk[1];
                 } else {
                     full = true;
                 }
@@ -270,12 +291,12 @@ __global__ __launch_bounds__(256) void assign_exact_pairs_kernel(Assign16Args a,
     for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 2; e < (((int64_t)total + 15) & ~15ll);
          e += ((int64_t)gridDim.x * blockDim.x) >> 2) {
         const bool live = e < total;
-        const int64_t row = live ? a.pair_list[3 * e] : 0;
-        const AssignJob job = a.jobs[live ? a.pair_list[3 * e + 1] : 0];
-        const uint32_t packed = live ? (uint32_t)a.pair_list[3 * e + 2] : 0xFFFFFFFFu;
-        int bid = (int)((packed >> (8 * slot)) & 0xFFu);
+        const int64_t row = live ? a.pair_list[4 * e] : 0;
+        const AssignJob job = a.jobs[live ? a.pair_list[4 * e + 1] : 0];
+        const uint32_t packed = live ? (uint32_t)a.pair_list[4 * e + 2 + (slot >> 1)] : 0xFFFFFFFFu;
+        int bid = (int)((packed >> (16 * (slot & 1))) & 0xFFFFu);
         float best = -INFINITY;
-        if (bid != 0xFF) best = exact_dot(X + row * d, Cn + (job.cent0 + bid) * d, d);
+        if (bid != 0xFFFF) best = exact_dot(X + row * d, Cn + (job.cent0 + bid) * d, d);
         else bid = 0x7fffffff;
 #pragma unroll
         for (int off = 1; off <= 2; off <<= 1) {                    // (ties -> lowest id)
@@ -287,6 +308,73 @@ __global__ __launch_bounds__(256) void assign_exact_pairs_kernel(Assign16Args a,
             }
         }
         if (live && slot == 0) a.assign[row] = job.id_base + bid;
+    }
+}
+
+// buckets with more than 128 lists: the decision over ALL 32-centroid subgroups of a row.  One thread per row of a merge job
+// (row segment x all lists of the bucket): the four best subgroup winners and the largest value among everything else (the
+// other winners and every subgroup's runner-up -- any other centroid of a subgroup lies at or below its runner-up).  Winner
+// certain if everything but the best stays below thr; else the winners that reach thr are the contenders (exact pairs), unless
+// "everything else" reaches thr too: then the contenders cannot be named and all centroids are re-evaluated.
+__global__ __launch_bounds__(256) void assign16_merge_kernel(Assign16Args a, int job_index0) {
+    const int64_t per_xcd = (a.n_mjobs + 7) / 8;
+    const int64_t ji = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || ji >= a.n_mjobs) return;
+    const AssignJob job = a.mjobs[ji];
+    const int nsg = (job.ncent + 31) >> 5;
+    for (int i = threadIdx.x; i < job.nrows; i += blockDim.x) {
+        const int64_t row = job.row0 + i;
+        float tv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int ti[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        float rest = -INFINITY;
+        for (int sg = 0; sg < nsg; ++sg) {
+            const int64_t at = (int64_t)sg * a.n + row;
+            float v = a.part_b[at];
+            int id = a.part_id[at];
+            rest = fmaxf(rest, a.part_s[at]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                            // insert into the sorted four (value desc, id asc)
+                if (v > tv[k] || (v == tv[k] && id < ti[k])) {
+                    const float ov = tv[k];
+                    const int oi = ti[k];
+                    tv[k] = v;
+                    ti[k] = id;
+                    v = ov;
+                    id = oi;
+                }
+            }
+            rest = fmaxf(rest, v);                                   // what fell out of the four
+        }
+        const float eps = kA16EpsRel * tv[0] + kA16EpsAbs;
+        const float thr = tv[0] - 2.2f * eps;
+        if (fmaxf(tv[1], rest) < thr) {
+            a.assign[row] = ti[0];
+        } else if (rest < thr) {
+            uint32_t pk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tv[k] >= thr) pk[k >> 1] = (pk[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | ((uint32_t)ti[k] << (16 * (k & 1)));
+            const int at = atomicAdd(a.amb_count + 1, 1);
+            bool ok = at < a.amb_cap;
+            if (ok) {
+                a.pair_list[4 * at] = (int32_t)row;
+                a.pair_list[4 * at + 1] = (int32_t)(job_index0 + ji);
+                a.pair_list[4 * at + 2] = (int32_t)pk[0];
+                a.pair_list[4 * at + 3] = (int32_t)pk[1];
+            } else {
+                const int at2 = atomicAdd(a.amb_count, 1);
+                if (at2 < a.amb_cap) {
+                    a.amb_list[2 * at2] = (int32_t)row;
+                    a.amb_list[2 * at2 + 1] = (int32_t)(job_index0 + ji);
+                }
+            }
+        } else {
+            const int at = atomicAdd(a.amb_count, 1);
+            if (at < a.amb_cap) {
+                a.amb_list[2 * at] = (int32_t)row;
+                a.amb_list[2 * at + 1] = (int32_t)(job_index0 + ji);
+            }
+        }
     }
 }
 
@@ -302,31 +390,53 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
 }
 
 // jobs: device table of `n_jobs` jobs, each covering ALL (<= 128) lists of its bucket
+// jobs: device table [single jobs (n_single): (row segment) x (ALL <= 128 lists of the bucket)] [merge jobs (n_merge): (row
+// segment) x (all 129..512 lists)] [group jobs (n_group): (row segment) x (128 of those lists), the groups of a segment next
+// to each other]
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
-                    const AssignJob* jobs, int64_t n_jobs, int32_t* assign, uint16_t* ckeys) {
-    if (n_jobs <= 0) return FAL_OK;
+                    const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
+                    uint16_t* ckeys) {
+    if (n_single + n_merge <= 0) return FAL_OK;
     int32_t* amb = nullptr;
     const int amb_cap = 1 << 24;
-    FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(5 * (size_t)amb_cap + 16), (void**)&amb));
+    FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(6 * (size_t)amb_cap + 16), (void**)&amb));
     FAL_CHECK_HIP(hipMemsetAsync(amb, 0, sizeof(int32_t) * 16, ctx->stream));
-    Assign16Args a{reinterpret_cast<const __half*>(X16), reinterpret_cast<const __half*>(C16), jobs, n_jobs, assign, amb + 16, amb, amb_cap,
-                   amb + 16 + 2 * (size_t)amb_cap, ckeys};
-    const int64_t per_xcd = (n_jobs + 7) / 8;
+    Assign16Args a{};
+    a.X16 = reinterpret_cast<const __half*>(X16); a.C16 = reinterpret_cast<const __half*>(C16);
+    a.jobs = jobs; a.n_jobs = n_single; a.assign = assign; a.amb_list = amb + 16; a.amb_count = amb; a.amb_cap = amb_cap;
+    a.pair_list = amb + 16 + 2 * (size_t)amb_cap; a.ckeys = ckeys; a.n = n_rows;
     StageScope ts(ctx, stage);
-    dim3 grid((unsigned)(per_xcd * 8)), block(256);
-    switch (d / 16) {
+    const dim3 block(256);
 #define FAL_LAUNCH_A16(S)                                                                                  \
     do {                                                                                                   \
-        if (ckeys) hipLaunchKernelGGL((assign16_kernel<S, true>), grid, block, 0, ctx->stream, a);         \
-        else hipLaunchKernelGGL((assign16_kernel<S, false>), grid, block, 0, ctx->stream, a);              \
+        if (partial) hipLaunchKernelGGL((assign16_kernel<S, false, true>), grid, block, 0, ctx->stream, a); \
+        else if (ckeys) hipLaunchKernelGGL((assign16_kernel<S, true, false>), grid, block, 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((assign16_kernel<S, false, false>), grid, block, 0, ctx->stream, a);       \
     } while (0)
-        case 4: FAL_LAUNCH_A16(4); break;
-        case 8: FAL_LAUNCH_A16(8); break;
-        case 16: FAL_LAUNCH_A16(16); break;
-        case 25: FAL_LAUNCH_A16(25); break;
-#undef FAL_LAUNCH_A16
-        default: set_error("assign16: low_dim %d has no instantiation", d); return FAL_EUNSUPPORTED;
+    auto run = [&](bool partial) -> int {
+        const dim3 grid((unsigned)(((a.n_jobs + 7) / 8) * 8));
+        switch (d / 16) {
+            case 4: FAL_LAUNCH_A16(4); break;
+            case 8: FAL_LAUNCH_A16(8); break;
+            case 16: FAL_LAUNCH_A16(16); break;
+            case 25: FAL_LAUNCH_A16(25); break;
+            default: set_error("assign16: low_dim %d has no instantiation", d); return FAL_EUNSUPPORTED;
+        }
+        return FAL_OK;
+    };
+    if (n_single > 0) FAL_TRY(run(false));
+    if (n_merge > 0) {
+        float* part = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * 3 * 16 * (size_t)n_rows, (void**)&part));
+        a.part_b = part; a.part_s = part + 16 * n_rows; a.part_id = reinterpret_cast<int32_t*>(part + 32 * n_rows);
+        a.jobs = jobs + n_single + n_merge; a.n_jobs = n_group;
+        FAL_TRY(run(true));
+        a.mjobs = jobs + n_single; a.n_mjobs = n_merge;
+        a.jobs = jobs;                       // the exact kernels' entries index [single | merge] jobs
+        hipLaunchKernelGGL(assign16_merge_kernel, dim3((unsigned)(((n_merge + 7) / 8) * 8)), block, 0, ctx->stream, a, (int)n_single);
     }
+#undef FAL_LAUNCH_A16
+    a.jobs = jobs;
     hipLaunchKernelGGL(assign_exact_pairs_kernel, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, ctx->stream, a, X, Cn, d);
     hipLaunchKernelGGL(assign_exact_rows_kernel, dim3((unsigned)(ctx->num_cus * 16)), dim3(64), 0, ctx->stream, a, X, Cn, d);
     FAL_CHECK_HIP(hipGetLastError());

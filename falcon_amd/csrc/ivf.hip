@@ -390,11 +390,18 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         // buckets with <= 128 lists and float16 rows at hand: the prefiltered assignment (assign16.hip; identical results)
         static const bool no_a16 = getenv("FALCON_NO_ASSIGN16") != nullptr;
         const bool use16 = X16 != nullptr && assign16_supports(low_dim) && !no_a16 && !row_major;
-        std::vector<AssignJob> hjobs;
+        std::vector<AssignJob> hjobs, mjobs, gjobs;    // single-group jobs; merge jobs and their group jobs (129..512 lists)
         for (const BucketDev& b : bk) {
             if (use16 && b.n_list <= kAssignGroup) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg)
                     hjobs.push_back({b.row0 + s0, b.list0, (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0), b.n_list, 0, 0});
+            } else if (use16 && b.n_list <= 4 * kAssignGroup) {
+                for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg) {
+                    const int32_t nr = (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0);
+                    mjobs.push_back({b.row0 + s0, b.list0, nr, b.n_list, 0, 0});
+                    for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)      // the groups of a segment next to each other: they
+                        gjobs.push_back({b.row0 + s0, b.list0 + t0, nr, std::min(kAssignGroup, b.n_list - t0), t0, 0});   // share its rows in L2
+                }
             } else if (!row_major && b.n_list <= 64) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += wseg)
                     for (int t0 = 0; t0 < b.n_list; t0 += 32)
@@ -426,6 +433,9 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         }
         AssignJob* hjobs_dev = nullptr;
         void* C16 = nullptr;
+        const int64_t n_single = (int64_t)hjobs.size(), n_merge = (int64_t)mjobs.size(), n_group = (int64_t)gjobs.size();
+        hjobs.insert(hjobs.end(), mjobs.begin(), mjobs.end());
+        hjobs.insert(hjobs.end(), gjobs.begin(), gjobs.end());
         if (!hjobs.empty()) {
             B_TRY(ctx->reserve(SLOT_INV, sizeof(AssignJob) * hjobs.size(), (void**)&hjobs_dev));
             B_TRY(ctx->upload(hjobs_dev, hjobs.data(), sizeof(AssignJob) * hjobs.size()));
@@ -439,10 +449,10 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 }
                 // the final pass leaves its approximate similarities behind for the coarse quantiser (coarse16.hip)
                 static const bool no_ckeys = getenv("FALCON_NO_COARSE16") != nullptr;
-                if (it == kmeans_iters && !no_ckeys && djobs.empty() && ajobs.empty())
+                if (it == kmeans_iters && !no_ckeys && djobs.empty() && ajobs.empty() && n_merge == 0)
                     B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kAssignGroup, (void**)&ivf->ckeys));
-                B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, (int64_t)hjobs.size(), ivf->assign,
-                                      it == kmeans_iters ? ivf->ckeys : nullptr));
+                B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, n_single, n_merge, n_group, n,
+                                      ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr));
             }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,

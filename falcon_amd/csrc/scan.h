@@ -64,11 +64,13 @@ struct AssignJob {
 // jobs[0, n_jobs): 4-wave jobs (<= 128 centroids each); jobs[n_jobs, n_jobs + n_wave_jobs): one-wave jobs (<= 32 centroids)
 int launch_assign(fal_ctx* ctx, int stage, const float* X, const float* centroids, int d, const AssignJob* jobs, int64_t n_jobs,
                   int64_t n_wave_jobs, int64_t n, unsigned long long* keys, int32_t* assign);
-// Assignment with a float16 prefilter (assign16.hip): jobs cover ALL lists of a bucket (<= 128); identical results
+// Assignment with a float16 prefilter (assign16.hip): buckets with <= 128 lists in one job per row segment, buckets with
+// <= 512 lists in groups of 128 + a merge over the groups; identical results.  Job table layout: see launch_assign16
 bool assign16_supports(int d);
 int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count);
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
-                    const AssignJob* jobs, int64_t n_jobs, int32_t* assign, uint16_t* ckeys = nullptr);
+                    const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
+                    uint16_t* ckeys = nullptr);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order

@@ -199,7 +199,9 @@ def test_search_neighbors_equals_search_then_filter(ctx, k_ann, keep, tol, mode,
 
 
 @pytest.mark.parametrize("sizes,nlists,d", [([3000], [64], 400), ([900, 40, 2500, 9000], [16, 1, 32, 128], 400),
-                                           ([5000, 2100], [100, 33], 128), ([2600], [32], 64)])
+                                           ([5000, 2100], [100, 33], 128), ([2600], [32], 64),
+                                           # more than 128 lists: groups of 128 centroids + a merge over the groups (BASELINE configs[3])
+                                           ([21000, 3000, 11000], [512, 64, 200], 400), ([9000, 5200], [129, 300], 128)])
 def test_ivf_build_with_f16_prefilter_is_identical(ctx, sizes, nlists, d):
     """a6 with the float16 prefilter (assign16.hip: arg-max on the f16 matrix cores, close calls re-evaluated exactly):
     assignments, centroids and lists are bit-identical to the exact build -- and therefore to the oracle's."""
