@@ -47,7 +47,7 @@ class AnnParams:
     ivf_prefilter: bool = True    # float32 buckets with an index: fine scan on the f16 matrix cores to 16-bit keys, the k-th best
                                   # key of every query bracketed from them, exact float32 work only inside the precursor
                                   # window and where it decides the k-th key (ivf16.hip); bit-identical neighbour lists
-    kmeans_prefilter: bool = True # IVF buckets with <= 128 lists: k-means assignment on the f16 matrix cores, rows whose two
+    kmeans_prefilter: bool = True # IVF buckets with <= 512 lists: k-means assignment on the f16 matrix cores, rows whose two
                                   # best centroids are closer than the float16 error bound re-evaluated exactly in float32
                                   # (assign16.hip): the index is identical, the build several times faster
     rescore: bool = False         # re-score the ANN neighbours with the reference's matched-peak cosine

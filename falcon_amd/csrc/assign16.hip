@@ -47,8 +47,8 @@ struct Assign16Args {
     int amb_cap;
     int32_t* pair_list;      // (row, job, <= 4 contender ids packed in bytes, 0xFF = none): rows with one contender per
                              // 32-centroid group at most -- the exact kernel evaluates just those
-    uint16_t* ckeys;         // optional [n, 128]: round(approximate similarity * 65535) of every (row, centroid) pair -- the final
-                             // pass leaves them for the coarse quantiser of the search (coarse16.hip)
+    uint16_t* ckeys;         // optional [n, ckeys_stride]: round(approximate similarity * 65535) of every (row, centroid) pair -- the
+    int ckeys_stride;        // final pass leaves them for the coarse quantiser of the search (coarse16.hip)
     // buckets with more than 128 lists (<= 512): one job per (row segment, group of 128 centroids) leaves the best / runner-up /
     // best id of its four 32-centroid subgroups per row (PARTIAL), assign16_merge_kernel decides over all subgroups of the row
     float* part_b;           // [16, n] best value of subgroup sg = 4 * group + wave
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
         }
         if constexpr (KEYS) {                                        // (the final pass; four keys per 8-byte store, no branch: rows
             //  past the segment re-write the last row's keys with the same values)
-            uint16_t* kp = a.ckeys + (job.row0 + min(c0 + r, nr - 1)) * (int64_t)kAssignGroup + 32 * w + 4 * h;
+            uint16_t* kp = a.ckeys + (job.row0 + min(c0 + r, nr - 1)) * (int64_t)a.ckeys_stride + job.id_base + 32 * w + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint32_t lo2 = 0, hi2 = 0;
@@ -395,7 +395,7 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
 // to each other]
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
-                    uint16_t* ckeys) {
+                    uint16_t* ckeys, int ckeys_stride) {
     if (n_single + n_merge <= 0) return FAL_OK;
     int32_t* amb = nullptr;
     const int amb_cap = 1 << 24;
@@ -404,12 +404,13 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     Assign16Args a{};
     a.X16 = reinterpret_cast<const __half*>(X16); a.C16 = reinterpret_cast<const __half*>(C16);
     a.jobs = jobs; a.n_jobs = n_single; a.assign = assign; a.amb_list = amb + 16; a.amb_count = amb; a.amb_cap = amb_cap;
-    a.pair_list = amb + 16 + 2 * (size_t)amb_cap; a.ckeys = ckeys; a.n = n_rows;
+    a.pair_list = amb + 16 + 2 * (size_t)amb_cap; a.ckeys = ckeys; a.ckeys_stride = ckeys_stride; a.n = n_rows;
     StageScope ts(ctx, stage);
     const dim3 block(256);
 #define FAL_LAUNCH_A16(S)                                                                                  \
     do {                                                                                                   \
-        if (partial) hipLaunchKernelGGL((assign16_kernel<S, false, true>), grid, block, 0, ctx->stream, a); \
+        if (partial && ckeys) hipLaunchKernelGGL((assign16_kernel<S, true, true>), grid, block, 0, ctx->stream, a); \
+        else if (partial) hipLaunchKernelGGL((assign16_kernel<S, false, true>), grid, block, 0, ctx->stream, a); \
         else if (ckeys) hipLaunchKernelGGL((assign16_kernel<S, true, false>), grid, block, 0, ctx->stream, a); \
         else hipLaunchKernelGGL((assign16_kernel<S, false, false>), grid, block, 0, ctx->stream, a);       \
     } while (0)

@@ -6,7 +6,8 @@
 namespace fal {
 
 struct Coarse16Args {
-    const uint16_t* ckeys;       // [n, 128] by sorted row
+    const uint16_t* ckeys;       // [n, stride] by sorted row
+    int stride;                  // 128 x groups (<= 512)
     const float* X;              // [n, d] float32 rows, sorted order (exact re-evaluation of close calls)
     const float* C;              // [total_lists, d] centroids
     int d;

@@ -8,7 +8,7 @@
 // rest.  If there are exactly as many members as open places they all are in; otherwise (two centroids about equally far: a
 // few per cent of the queries) the members are re-evaluated by the exact k-ordered fmaf chain and ranked by (similarity
 // descending, list id ascending) -- the order of the staged coarse scan + select.  The probe SET is identical to the staged
-// path's; its order inside a query is by list id (nothing depends on it: every consumer reads the same table).
+// path's; its order inside a query is arbitrary (nothing depends on it: every consumer reads the same table).
 //
 // 16 lanes per query (8 keys each), 4 queries per wave: the counts of the bitwise threshold search are 16-bit slices of one
 // ballot.  Replaces a [n, n_list] fp32-MFMA scan + a wavefront select (13 + 6 ms at 10 M spectra).
@@ -24,15 +24,17 @@
 
 namespace fal {
 
-constexpr int kCoarseMem = 128;          // members a query can hold (every key, in the worst case)
-
-__global__ __launch_bounds__(256) void coarse16_kernel(Coarse16Args a) {
-    __shared__ float m_val[16][kCoarseMem];
-    __shared__ int32_t m_id[16][kCoarseMem];
-    __shared__ int32_t q_cnt[16];
-    __shared__ int64_t q_row[16], q_cbase[16];
+// KPL keys per lane (8: buckets with <= 128 lists, 32: <= 512), 16 lanes per query, QPW queries per workgroup
+template <int KPL, int QPW>
+__global__ __launch_bounds__(16 * QPW) void coarse16_kernel(Coarse16Args a) {
+    constexpr int kMem = 16 * KPL;                         // members a query can hold (every key, in the worst case)
+    constexpr int kThreads = 16 * QPW;
+    __shared__ float m_val[QPW][kMem];
+    __shared__ int32_t m_id[QPW][kMem];
+    __shared__ int32_t q_cnt[QPW];
+    __shared__ int64_t q_row[QPW], q_cbase[QPW];
     const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, sub = lane & 15, qw = tid >> 4;
-    const int64_t g = (int64_t)blockIdx.x * 16 + qw;                 // tile-order slot of this 16-lane group's query
+    const int64_t g = (int64_t)blockIdx.x * QPW + qw;                // tile-order slot of this 16-lane group's query
     const int64_t t = g >> 5;
     const int ql = (int)(g & 31);
     bool live = t < a.n_tiles;
@@ -44,13 +46,16 @@ __global__ __launch_bounds__(256) void coarse16_kernel(Coarse16Args a) {
     const int64_t row = live ? a.perm[p] : 0;
     const int nl = live ? job.nc : 0;
     const int np = a.np;
-    uint32_t u[8];
-    {
+    // key j of 16-byte piece (16 q + sub) of the row: list id (16 q + sub) * 8 + j -- a group reads 256 contiguous bytes per q
+    uint32_t u[KPL];
+    auto id_of = [&](int x) -> int { return (16 * (x >> 3) + sub) * 8 + (x & 7); };
+#pragma unroll
+    for (int q = 0; q < KPL / 8; ++q) {
         uint4 raw = make_uint4(0, 0, 0, 0);
-        if (live) raw = *reinterpret_cast<const uint4*>(a.ckeys + row * (int64_t)kAssignGroup + sub * 8);
+        if (live && (16 * q + sub) * 8 < nl) raw = *reinterpret_cast<const uint4*>(a.ckeys + row * (int64_t)a.stride + (16 * q + sub) * 8);
         const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = (sub * 8 + j < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
+        for (int j = 0; j < 8; ++j) u[8 * q + j] = (id_of(8 * q + j) < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
     }
     const int want = min(np, nl);                                     // probes of this query
     const int sh = 16 * grp;
@@ -61,27 +66,29 @@ __global__ __launch_bounds__(256) void coarse16_kernel(Coarse16Args a) {
         const uint32_t c = T | (1u << bit);
         int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cnt += gcount(u[j] >= c);
+        for (int j = 0; j < KPL; ++j) cnt += gcount(u[j] >= c);
         if (cnt >= want && want > 0) T = c;
     }
     const float Tv = (float)(max(T, 1u) - 1u) * (1.f / 65535.f);
     const float e = 1.3e-3f * Tv + 1.2e-5f;
     const int delta = 2 * ((int)ceilf(e * 65535.f) + 1) + 2;
     int n_hi = 0, n_mem = 0;
-    bool hi[8], mem[8];
+    uint32_t hi = 0, mem = 0;                                         // bit j: key j of this lane
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < KPL; ++j) {
         const int df = (int)u[j] - (int)T;
-        hi[j] = u[j] != 0u && df > delta;
-        mem[j] = u[j] != 0u && df <= delta && df >= -delta;
-        n_hi += gcount(hi[j]);
-        n_mem += gcount(mem[j]);
+        const bool h1 = u[j] != 0u && df > delta;
+        const bool m1 = u[j] != 0u && df <= delta && df >= -delta;
+        hi |= h1 ? (1u << j) : 0u;
+        mem |= m1 ? (1u << j) : 0u;
+        n_hi += gcount(h1);
+        n_mem += gcount(m1);
     }
     const int need = want - n_hi;                                     // places left for the members (1 .. n_mem when want > 0)
     const bool ambiguous = want > 0 && n_mem > need;
-    // Exact values for the members of the ambiguous queries.  A chain is serial (400 dependent fmaf), so the members of all 16
+    // Exact values for the members of the ambiguous queries.  A chain is serial (400 dependent fmaf), so the members of all
     // queries of the workgroup are pooled: item i of the pool goes to thread i -- normally they all fit the first wave, and
-    // the other three do not run a chain at all (one per wave for two or three busy lanes was most of this kernel's time).
+    // the others do not run a chain at all (one per wave for two or three busy lanes was most of this kernel's time).
     if (sub == 0) {
         q_cnt[qw] = ambiguous ? n_mem : 0;
         q_row[qw] = row;
@@ -90,22 +97,23 @@ __global__ __launch_bounds__(256) void coarse16_kernel(Coarse16Args a) {
     {
         int base = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t gm = (uint32_t)(__ballot(mem[j] && ambiguous) >> sh) & 0xFFFFu;
-            if (mem[j] && ambiguous) m_id[qw][base + __popc(gm & ((1u << sub) - 1u))] = sub * 8 + j;
+        for (int j = 0; j < KPL; ++j) {
+            const bool m1 = ((mem >> j) & 1u) && ambiguous;
+            const uint32_t gm = (uint32_t)(__ballot(m1) >> sh) & 0xFFFFu;
+            if (m1) m_id[qw][base + __popc(gm & ((1u << sub) - 1u))] = id_of(j);
             base += __popc(gm);
         }
     }
     __syncthreads();
     {
-        int off[17];
+        int off[QPW + 1];
         off[0] = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) off[k + 1] = off[k] + q_cnt[k];
-        for (int i = tid; i < off[16]; i += 256) {
+        for (int k = 0; k < QPW; ++k) off[k + 1] = off[k] + q_cnt[k];
+        for (int i = tid; i < off[QPW]; i += kThreads) {
             int k = 0;
 #pragma unroll
-            for (int kk = 1; kk < 16; ++kk) k = off[kk] <= i ? kk : k;
+            for (int kk = 1; kk < QPW; ++kk) k = off[kk] <= i ? kk : k;
             const int m = i - off[k];
             m_val[k][m] = exact_dot(a.X + q_row[k] * a.d, a.C + (q_cbase[k] + m_id[k][m]) * (int64_t)a.d, a.d);
         }
@@ -113,9 +121,9 @@ __global__ __launch_bounds__(256) void coarse16_kernel(Coarse16Args a) {
     __syncthreads();
     if (ambiguous) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (!mem[j]) continue;
-            const int me = sub * 8 + j;
+        for (int j = 0; j < KPL; ++j) {
+            if (!((mem >> j) & 1u)) continue;
+            const int me = id_of(j);
             float mine = 0.f;
             for (int i = 0; i < n_mem; ++i) mine = m_id[qw][i] == me ? m_val[qw][i] : mine;
             int rank = 0;
@@ -124,17 +132,17 @@ __global__ __launch_bounds__(256) void coarse16_kernel(Coarse16Args a) {
                 const int id = m_id[qw][i];
                 rank += (v > mine || (v == mine && id < me)) ? 1 : 0;
             }
-            mem[j] = rank < need;
+            if (rank >= need) mem &= ~(1u << j);
         }
     }
-    // the probe table row: chosen lists in ascending id, -1 behind them
+    // the probe table row: the chosen lists (any order: nothing depends on it), -1 behind them
     int32_t* out = a.probes + p * np;
     int base = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const bool in = live && want > 0 && (hi[j] || mem[j]);
+    for (int j = 0; j < KPL; ++j) {
+        const bool in = live && want > 0 && (((hi | mem) >> j) & 1u);
         const uint32_t gm = (uint32_t)(__ballot(in) >> sh) & 0xFFFFu;
-        if (in) out[base + __popc(gm & ((1u << sub) - 1u))] = sub * 8 + j;
+        if (in) out[base + __popc(gm & ((1u << sub) - 1u))] = id_of(j);
         base += __popc(gm);
     }
     if (live)
@@ -155,8 +163,11 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
     hipLaunchKernelGGL(tile_job_c16_kernel, dim3((unsigned)ceil_div(a.n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
                        a.n_tiles, tj);
     a.tile_job = tj;
-    FAL_REQUIRE(a.n_tiles * 2 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one coarse launch");
-    hipLaunchKernelGGL(coarse16_kernel, dim3((unsigned)(a.n_tiles * 2)), dim3(256), 0, ctx->stream, a);
+    FAL_REQUIRE(a.n_tiles * 4 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one coarse launch");
+    if (a.stride <= 128)
+        hipLaunchKernelGGL((coarse16_kernel<8, 16>), dim3((unsigned)(a.n_tiles * 2)), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((coarse16_kernel<32, 8>), dim3((unsigned)(a.n_tiles * 4)), dim3(128), 0, ctx->stream, a);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

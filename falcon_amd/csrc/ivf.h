@@ -29,9 +29,10 @@ struct fal_ivf {
     const void* Xpre = nullptr;      // optional float16 copy of X used ONLY as the prefilter of the fused flat scan
     void* Xl16 = nullptr;            // float16 rows in list order: prefilter of the IVF fine scan (ivf16.hip), owned
     int32_t* pos_of_row = nullptr;   // [n] sorted row -> list-order position (with Xl16), owned
-    uint16_t* ckeys = nullptr;       // [n, 128] approximate (row, centroid) similarities of the final k-means pass as 16-bit keys,
+    int ckeys_stride = 0;            // columns of ckeys: 128 x (groups of the bucket with the most lists)
+    uint16_t* ckeys = nullptr;       // [n, ckeys_stride] approximate (row, centroid) similarities of the final k-means pass as 16-bit keys,
                                      // by sorted row: the coarse quantiser reads them instead of scanning again; only when EVERY
-                                     // indexed bucket went through the float16 assignment (<= 128 lists), owned
+                                     // indexed bucket went through the float16 assignment (<= 512 lists), owned
     std::vector<int64_t> bucket_off; // host, n_buckets + 1
     std::vector<int32_t> n_list;     // host, per bucket
     std::vector<int64_t> list_base;  // host, global id of each bucket's list 0

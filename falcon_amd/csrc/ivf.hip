@@ -449,10 +449,14 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 }
                 // the final pass leaves its approximate similarities behind for the coarse quantiser (coarse16.hip)
                 static const bool no_ckeys = getenv("FALCON_NO_COARSE16") != nullptr;
-                if (it == kmeans_iters && !no_ckeys && djobs.empty() && ajobs.empty() && n_merge == 0)
-                    B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kAssignGroup, (void**)&ivf->ckeys));
+                if (it == kmeans_iters && !no_ckeys && djobs.empty() && ajobs.empty()) {
+                    int max_nl = 0;
+                    for (const BucketDev& b : bk) max_nl = std::max(max_nl, (int)b.n_list);
+                    ivf->ckeys_stride = kAssignGroup * (int)ceil_div(max_nl, kAssignGroup);
+                    B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * ivf->ckeys_stride, (void**)&ivf->ckeys));
+                }
                 B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, n_single, n_merge, n_group, n,
-                                      ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr));
+                                      ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr, ivf->ckeys_stride));
             }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,

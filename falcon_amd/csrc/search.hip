@@ -446,9 +446,10 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(n_slots + 2), st));
     // the final k-means pass left the (row, centroid) similarities behind as 16-bit keys: no second scan (coarse16.hip)
     static const bool no_c16 = getenv("FALCON_NO_COARSE16") != nullptr;
-    const bool from_keys = ivf->ckeys != nullptr && ivf->X != nullptr && !no_c16;
+    const bool from_keys = ivf->ckeys != nullptr && ivf->X != nullptr && !no_c16 && ivf->ckeys_stride <= 512;
     if (from_keys) {
-        Coarse16Args ca{ivf->ckeys, ivf->X, ivf->centroids, d, coarse_dev, (int)coarse.size(), ivf_tiles, nullptr, ivf->perm, np, probes};
+        Coarse16Args ca{ivf->ckeys, ivf->ckeys_stride, ivf->X, ivf->centroids, d, coarse_dev, (int)coarse.size(), ivf_tiles, nullptr,
+                        ivf->perm, np, probes};
         FAL_TRY(launch_coarse16(ctx, ca));
     }
     if (!from_keys) FAL_TRY(ivf_ensure_xl(ctx, ivf));

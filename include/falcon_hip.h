@@ -123,7 +123,7 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim,
                   const int64_t* bucket_off, int64_t n_buckets, const int32_t* n_list,
                   int kmeans_iters, fal_ivf** out);
 /* The same build with float16 copies [n, low_dim] of X (fal_vectorize FAL_DTYPE_F16 on the same peaks) as a PREFILTER of
- * the k-means / final assignment of buckets with <= 128 lists: the arg-max runs on the f16 matrix cores and only the
+ * the k-means / final assignment of buckets with <= 512 lists: the arg-max runs on the f16 matrix cores and only the
  * rows whose two best centroids are closer than the float16 error bound are re-evaluated exactly in float32 -- every
  * assignment, centroid and list is identical to fal_ivf_build's (low_dim in {64, 128, 256, 400}; X16 NULL = fal_ivf_build). */
 int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, int low_dim,

@@ -97,6 +97,23 @@ def test_ivf_prefilter_long_lists_take_the_second_pass_or_the_staged_scan(ctx):
     assert n_fb == 0
 
 
+def test_coarse_quantiser_from_the_build_keys_with_up_to_512_lists(ctx):
+    """buckets with 129..512 lists: the float16 assignment runs in groups of 128 centroids, the keys have up to 512 columns
+    and the quantiser reads 32 keys per lane -- the search equals the one through an exactly built index bit for bit"""
+    import torch
+    sizes = [21000, 3000, 11000]
+    nl = np.array([512, 64, 200], np.int32)
+    off, X, mz, rt = _buckets(sizes, 128, 67)
+    X[off[0]:off[0] + 21000:41] = X[off[0]]                   # identical k-means seeds -> identical centroids (ties)
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    plain = ctx.ivf_build(Xd, off, nl, kmeans_iters=3)
+    keyed = ctx.ivf_build(Xd, off, nl, kmeans_iters=3, Xkm=Xd.to(torch.float16).contiguous())
+    for n_probe in (32, 5):
+        s0, i0 = plain.search(n_probe, 64)
+        s1, i1 = keyed.search(n_probe, 64)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
 @pytest.mark.parametrize("d,n_probe", [(400, 16), (400, 3), (128, 8), (64, 1)])
 def test_coarse_quantiser_from_the_build_keys_gives_the_same_search(ctx, d, n_probe):
     """an index built with the float16 k-means prefilter keeps the final pass's (row, centroid) similarities as 16-bit keys and
