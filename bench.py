@@ -168,13 +168,13 @@ def main():
         base.update(kw)
         return AnnParams(**base)
 
-    def make_parts(n_total, first_block=0):
+    def make_parts(n_total, first_block=0, mz_lo=400.0, mz_hi=1200.0):
         """the dataset, split by precursor charge (falcon.py:151-160), resident in HBM -> [SpectrumDataset], host view"""
         if args.generator == "device":
-            data = synth.generate_device(n_total, dev, seed=42, first_block=first_block)
+            data = synth.generate_device(n_total, dev, seed=42, first_block=first_block, mz_lo=mz_lo, mz_hi=mz_hi)
             sel = lambda c: synth.select_charge_device(data, c)
         else:
-            data = synth.generate(n_total, seed=42, first_block=first_block)
+            data = synth.generate(n_total, seed=42, first_block=first_block, mz_lo=mz_lo, mz_hi=mz_hi)
             sel = lambda c: synth.select_charge(data, c)
         parts = []
         for charge in (2, 3):
@@ -365,7 +365,14 @@ def main():
             concurrent["on"] = False          # 10 M spectra: two concurrent partitions lose (2.4x slower; tools/concurrent_parts.py)
         big = make_parts(args.configs_spectra)
         for name, kw in (("f32", dict(low_dim=400, dtype="f32", scan="f32")),
-                         ("f16", dict(low_dim=800, dtype="f16", scan="f32"))):
+                         ("f16", dict(low_dim=800, dtype="f16", scan="f32")),
+                         # BASELINE configs[3]'s bucket regime on one GPU: the same number of spectra in a quarter of the precursor
+                         # range (buckets of 20-35 k rows: n_list 512) with that config's n_probe = 32
+                         ("f32-dense", dict(low_dim=400, dtype="f32", scan="f32", n_probe=32))):
+            if name == "f32-dense":
+                del big
+                torch.cuda.empty_cache()
+                big = make_parts(args.configs_spectra, mz_lo=400.0, mz_hi=600.0)
             pc = params(**kw)
             ra = (20.0, "ppm", None, 0.05, args.batch_size, pc)
             try:
@@ -377,11 +384,14 @@ def main():
             n_big = sum(len(x) for x in big)
             peak = PEAK_MFMA_F16_TFLOPS if name == "f16" else PEAK_MFMA_F32_TFLOPS
             extra.append({
-                "workload": f"{args.configs_spectra} synthetic spectra on 1 GPU (charges 2+3), low_dim={pc.low_dim} {name}, "
+                "workload": f"{args.configs_spectra} synthetic spectra on 1 GPU (charges 2+3"
+                            f"{', precursor m/z 400-600' if name == 'f32-dense' else ''}), low_dim={pc.low_dim} {name.split('-')[0]}, "
                             f"n_neighbors={pc.n_neighbors}, n_neighbors_ann={pc.n_neighbors_ann}, n_probe={pc.n_probe}, "
                             f"eps={pc.eps}, precursor_tol=20ppm, mz_interval={pc.mz_interval}",
-                "baseline_config": "configs[2] dataset on one GPU" if name == "f32" else "configs[4]",
-                "steps": 3, "ms_per_step": dtc / 3 * 1e3, "value": n_big * 3 / dtc, "unit": "spectra/s", "dtype": name,
+                "baseline_config": {"f32": "configs[2] dataset on one GPU", "f16": "configs[4]",
+                                    "f32-dense": "configs[3] regime (n_list 512, n_probe 32, n_neighbors_ann 128) at one GPU's size: "
+                                                 "precursors in 400-600 m/z"}[name],
+                "steps": 3, "ms_per_step": dtc / 3 * 1e3, "value": n_big * 3 / dtc, "unit": "spectra/s", "dtype": name.split("-")[0],
                 "stage_ms": sc["stage_ms"], "pairs_per_step": sc["pairs"],
                 "cosine_kernel": {"scan_ms": sc["scan_ms"], "scan_plus_topk_ms": sc["topk_ms"],
                                   "scan_tflops": sc["scan_tflops"], "scan_frac_of_mfma_peak": sc["scan_tflops"] / peak,
