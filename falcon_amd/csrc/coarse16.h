@@ -17,7 +17,10 @@ struct Coarse16Args {
     const int32_t* tile_job;     // (filled by launch_coarse16)
     const int32_t* perm;         // [n] list-order position -> sorted row
     int np;                      // probes per query
-    int32_t* probes;             // [n, np] by list-order position: the chosen bucket-local lists in ascending id, -1 behind them
+    int32_t* probes;             // [n, np] by list-order position: the chosen bucket-local lists, -1 behind them
+    int32_t* ovf_count;          // (launch_coarse16) queries with more members than the wave-level kernel holds
+    int32_t* ovf_list;
+    int ovf_cap;
 };
 
 int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a);

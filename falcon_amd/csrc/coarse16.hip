@@ -16,6 +16,7 @@
 // Reference: README.md:107-113 (n_probe lists per query); faiss IndexIVFFlat's quantizer->search is a dependency of the
 // reference, not in the snapshot.
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 #include "scan.h"
@@ -25,7 +26,9 @@
 namespace fal {
 
 // KPL keys per lane (8: buckets with <= 128 lists, 32: <= 512), 16 lanes per query, QPW queries per workgroup
-template <int KPL, int QPW>
+// (the workgroup-level form: every query keeps room for ALL its keys as members.  It serves the queries coarse16w_kernel
+// hands over -- more than 16 members: many equal similarities --, or everything with FALCON_COARSE16_WG.)
+template <int KPL, int QPW, bool LIST>
 __global__ __launch_bounds__(16 * QPW) void coarse16_kernel(Coarse16Args a) {
     constexpr int kMem = 16 * KPL;                         // members a query can hold (every key, in the worst case)
     constexpr int kThreads = 16 * QPW;
@@ -34,10 +37,13 @@ __global__ __launch_bounds__(16 * QPW) void coarse16_kernel(Coarse16Args a) {
     __shared__ int32_t q_cnt[QPW];
     __shared__ int64_t q_row[QPW], q_cbase[QPW];
     const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, sub = lane & 15, qw = tid >> 4;
-    const int64_t g = (int64_t)blockIdx.x * QPW + qw;                // tile-order slot of this 16-lane group's query
+    const int64_t n_items = LIST ? (int64_t)min(*a.ovf_count, a.ovf_cap) : 32 * a.n_tiles;
+  for (int64_t item0 = (int64_t)blockIdx.x * QPW; item0 < n_items; item0 += (int64_t)gridDim.x * QPW) {
+    const int64_t item = item0 + qw;
+    const int64_t g = LIST ? (item < n_items ? (int64_t)a.ovf_list[item] : (int64_t)-1) : item;   // tile-order slot of the group's query
     const int64_t t = g >> 5;
     const int ql = (int)(g & 31);
-    bool live = t < a.n_tiles;
+    bool live = g >= 0 && t < a.n_tiles;
     DenseJob job{};
     if (live) job = a.jobs[a.tile_job[t]];
     const int lt = (int)(t - job.tile0);
@@ -147,6 +153,154 @@ __global__ __launch_bounds__(16 * QPW) void coarse16_kernel(Coarse16Args a) {
     }
     if (live)
         for (int i = want + sub; i < np; i += 16) out[i] = -1;
+    __syncthreads();
+  }
+}
+
+// The production form: ONE WAVE serves 16 queries.  Four rounds of four queries do the threshold search and the
+// classification; the members of all ambiguous queries of the wave then share ONE round of exact chains (a chain is 400
+// dependent fmaf behind memory latency, ~30 us: with a chain round per 4 queries -- or per 16 queries but with three of four
+// waves of a workgroup waiting for it -- the kernel spent its time there), then the four rounds rank and emit.  A query with
+// more than 16 members (many equal similarities) is handed to the workgroup-level kernel.
+template <int KPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 6 : 3, 8))) void coarse16w_kernel(Coarse16Args a) {
+    constexpr int kCap = 16;
+    __shared__ float m_val[16][kCap];
+    __shared__ int32_t m_id[16][kCap];
+    __shared__ int32_t q_cnt[16];
+    __shared__ int64_t q_row[16], q_cbase[16];
+    const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
+    const int sh = 16 * grp;
+    const int np = a.np;
+    auto gcount = [&](bool pred) -> int { return __popc((uint32_t)(__ballot(pred) >> sh) & 0xFFFFu); };
+    auto id_of = [&](int x) -> int { return (16 * (x >> 3) + sub) * 8 + (x & 7); };
+    uint32_t hi[4], mem[4];
+    int need[4], nmem[4], want[4];
+    int64_t pq[4];
+    bool emit[4], amb[4];
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int qi = 4 * rd + grp;
+        const int64_t g = (int64_t)blockIdx.x * 16 + qi;             // tile-order slot of this 16-lane group's query
+        const int64_t t = g >> 5;
+        const int ql = (int)(g & 31);
+        bool live = t < a.n_tiles;
+        DenseJob job{};
+        if (live) job = a.jobs[a.tile_job[t]];
+        const int lt = (int)(t - job.tile0);
+        live = live && 32 * lt + ql < job.nq;
+        const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;
+        const int64_t row = live ? a.perm[p] : 0;
+        const int nl = live ? job.nc : 0;
+        uint32_t u[KPL];
+#pragma unroll
+        for (int q = 0; q < KPL / 8; ++q) {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (live && (16 * q + sub) * 8 < nl) raw = *reinterpret_cast<const uint4*>(a.ckeys + row * (int64_t)a.stride + (16 * q + sub) * 8);
+            const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[8 * q + j] = (id_of(8 * q + j) < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
+        }
+        const int wnt = min(np, nl);
+        uint32_t T = 0;
+        for (int bit = 16; bit >= 0; --bit) {
+            const uint32_t c = T | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) cnt += gcount(u[j] >= c);
+            if (cnt >= wnt && wnt > 0) T = c;
+        }
+        const float Tv = (float)(max(T, 1u) - 1u) * (1.f / 65535.f);
+        const float e = 1.3e-3f * Tv + 1.2e-5f;
+        const int delta = 2 * ((int)ceilf(e * 65535.f) + 1) + 2;
+        int n_hi = 0, n_mem = 0;
+        uint32_t h = 0, m = 0;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const int df = (int)u[j] - (int)T;
+            const bool h1 = u[j] != 0u && df > delta;
+            const bool m1 = u[j] != 0u && df <= delta && df >= -delta;
+            h |= h1 ? (1u << j) : 0u;
+            m |= m1 ? (1u << j) : 0u;
+            n_hi += gcount(h1);
+            n_mem += gcount(m1);
+        }
+        const int nd = wnt - n_hi;
+        bool ambiguous = wnt > 0 && n_mem > nd;
+        bool handed = false;
+        if (ambiguous && n_mem > kCap) {                             // too many members for the wave's lists
+            if (sub == 0) {
+                const int at = atomicAdd(a.ovf_count, 1);
+                if (at < a.ovf_cap) a.ovf_list[at] = (int32_t)g;
+            }
+            handed = true;
+            ambiguous = false;
+        }
+        if (sub == 0) {
+            q_cnt[qi] = ambiguous ? n_mem : 0;
+            q_row[qi] = row;
+            q_cbase[qi] = job.c_row0;
+        }
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const bool m1 = ((m >> j) & 1u) && ambiguous;
+            const uint32_t gm = (uint32_t)(__ballot(m1) >> sh) & 0xFFFFu;
+            if (m1) m_id[qi][base + __popc(gm & ((1u << sub) - 1u))] = id_of(j);
+            base += __popc(gm);
+        }
+        hi[rd] = h; mem[rd] = m; need[rd] = nd; nmem[rd] = n_mem; want[rd] = wnt; pq[rd] = p;
+        emit[rd] = live && wnt > 0 && !handed; amb[rd] = ambiguous;
+        if (live && !handed)
+            for (int i = wnt + sub; i < np; i += 16) a.probes[p * np + i] = -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    {
+        int off[17];
+        off[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) off[k + 1] = off[k] + q_cnt[k];
+        for (int i = lane; i < off[16]; i += 64) {
+            int k = 0;
+#pragma unroll
+            for (int kk = 1; kk < 16; ++kk) k = off[kk] <= i ? kk : k;
+            const int mm = i - off[k];
+            m_val[k][mm] = exact_dot(a.X + q_row[k] * a.d, a.C + (q_cbase[k] + m_id[k][mm]) * (int64_t)a.d, a.d);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int qi = 4 * rd + grp;
+        uint32_t m = mem[rd];
+        if (amb[rd]) {
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) {
+                if (!((m >> j) & 1u)) continue;
+                const int me = id_of(j);
+                float mine = 0.f;
+                for (int i = 0; i < nmem[rd]; ++i) mine = m_id[qi][i] == me ? m_val[qi][i] : mine;
+                int rank = 0;
+                for (int i = 0; i < nmem[rd]; ++i) {
+                    const float v = m_val[qi][i];
+                    const int id = m_id[qi][i];
+                    rank += (v > mine || (v == mine && id < me)) ? 1 : 0;
+                }
+                if (rank >= need[rd]) m &= ~(1u << j);
+            }
+        }
+        int32_t* out = a.probes + pq[rd] * np;
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            const bool in = emit[rd] && (((hi[rd] | m) >> j) & 1u);
+            const uint32_t gm = (uint32_t)(__ballot(in) >> sh) & 0xFFFFu;
+            if (in) out[base + __popc(gm & ((1u << sub) - 1u))] = id_of(j);
+            base += __popc(gm);
+        }
+    }
 }
 
 __global__ void tile_job_c16_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t n_tiles, int32_t* __restrict__ tile_job) {
@@ -158,16 +312,32 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
     if (a_in.n_tiles <= 0) return FAL_OK;
     Coarse16Args a = a_in;
     int32_t* tj = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)std::max<int64_t>(a.n_tiles, 1 << 16), (void**)&tj));
+    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(a.n_tiles, 1 << 16) + 32 * a.n_tiles + 64), (void**)&tj));
     StageScope ts(ctx, ST_COARSE);
     hipLaunchKernelGGL(tile_job_c16_kernel, dim3((unsigned)ceil_div(a.n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
                        a.n_tiles, tj);
     a.tile_job = tj;
     FAL_REQUIRE(a.n_tiles * 4 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one coarse launch");
-    if (a.stride <= 128)
-        hipLaunchKernelGGL((coarse16_kernel<8, 16>), dim3((unsigned)(a.n_tiles * 2)), dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((coarse16_kernel<32, 8>), dim3((unsigned)(a.n_tiles * 4)), dim3(128), 0, ctx->stream, a);
+    // the queries the wave-level kernel hands over (count in front), behind the tile table
+    a.ovf_count = tj + std::max<int64_t>(a.n_tiles, 1 << 16);
+    a.ovf_list = a.ovf_count + 16;
+    a.ovf_cap = (int)std::min<int64_t>(32 * a.n_tiles, INT32_MAX);
+    FAL_CHECK_HIP(hipMemsetAsync(a.ovf_count, 0, sizeof(int32_t), ctx->stream));
+    static const bool wg_form = getenv("FALCON_COARSE16_WG") != nullptr;      // (A/B runs: the workgroup-level kernel for everything)
+    const unsigned list_grid = (unsigned)std::min<int64_t>(a.n_tiles * 4, (int64_t)ctx->num_cus * 16);
+    if (a.stride <= 128) {
+        if (wg_form) hipLaunchKernelGGL((coarse16_kernel<8, 16, false>), dim3((unsigned)(a.n_tiles * 2)), dim3(256), 0, ctx->stream, a);
+        else {
+            hipLaunchKernelGGL((coarse16w_kernel<8>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL((coarse16_kernel<8, 16, true>), dim3(list_grid), dim3(256), 0, ctx->stream, a);
+        }
+    } else {
+        if (wg_form) hipLaunchKernelGGL((coarse16_kernel<32, 8, false>), dim3((unsigned)(a.n_tiles * 4)), dim3(128), 0, ctx->stream, a);
+        else {
+            hipLaunchKernelGGL((coarse16w_kernel<32>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL((coarse16_kernel<32, 8, true>), dim3(list_grid), dim3(128), 0, ctx->stream, a);
+        }
+    }
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }
