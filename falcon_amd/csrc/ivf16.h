@@ -38,6 +38,7 @@ struct Select16Args {
     float* gmem_v;               // members: approximate value ...
     uint32_t* gmem_id;           // ... and position in the query's key stream (resolve_kernel: -> row where needed)
     int64_t n_tiles;             // (filled by launch_select16)
+    int64_t max_keys;            // the most keys any query of the search has (picks the kernel form)
     int32_t* big_count;          // queries with more than 2,048 keys: second pass with 64 keys per lane
     int32_t* big_list;
     int big_cap;

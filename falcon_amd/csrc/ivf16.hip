@@ -312,7 +312,10 @@ __device__ __forceinline__ void select16_trivial(const Select16Args& a, int64_t 
 
 // BIG = false: one wave per query slot of the launch's tiles; queries with more keys than 32 per lane are appended to
 // a.big_list.  BIG = true: the listed queries, 64 keys per lane (more than 4,096 keys: exact fallback)
-template <bool BIG>
+// WIDE: the first pass also holds 40 keys per lane (a search whose queries have up to 2,560 keys: BASELINE configs[3]'s n_probe
+// = 32 over ~70-row lists -- most of them would otherwise take the second pass at one wave per SIMD); the narrow form keeps
+// the common n_probe = 16 case at its register count
+template <bool BIG, bool WIDE>
 __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_big = BIG ? min(*a.big_count, a.big_cap) : 0;
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
                 else if (nc <= 1024) select16_body<16>(a, row, nc, k, lane, out_row);
                 else if (nc <= 1536) select16_body<24>(a, row, nc, k, lane, out_row);
                 else if (nc <= 2048) select16_body<32>(a, row, nc, k, lane, out_row);
+                else if (WIDE && nc <= 2560) select16_body<40>(a, row, nc, k, lane, out_row);
                 else if (lane == 0) {
                     const int at = atomicAdd(a.big_count, 1);
                     if (at < a.big_cap) a.big_list[at] = (int32_t)slot;
@@ -419,8 +423,10 @@ int launch_select16(fal_ctx* ctx, const Select16Args& a_in, int64_t n_tiles) {
     hipLaunchKernelGGL(tile_job16_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
                        a.tile_begin, n_tiles, tj);
     a.tile_job = tj;
-    hipLaunchKernelGGL((select16_kernel<false>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL((select16_kernel<true>), dim3((unsigned)(ctx->num_cus * 4)), dim3(256), 0, ctx->stream, a);
+    if (a.max_keys > 2048) hipLaunchKernelGGL((select16_kernel<false, true>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((select16_kernel<false, false>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
+    if (a.max_keys > 2048)
+        hipLaunchKernelGGL((select16_kernel<true, false>), dim3((unsigned)(ctx->num_cus * 4)), dim3(256), 0, ctx->stream, a);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

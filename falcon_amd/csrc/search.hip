@@ -601,6 +601,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             sa.keys = keys; sa.keys_base = base; sa.k = k_ann; sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size();
             sa.tile_begin = t0; sa.q_sim_off = q_sim_off;
             sa.perm = ivf->perm; sa.thr = fa.thr; sa.gmem_v = fa.gmem_v; sa.gmem_id = fa.gmem_id;
+            sa.max_keys = max_total;
             FAL_TRY(launch_select16(ctx, sa, t1 - t0));
         }
         FAL_TRY(launch_fused_ivf_tail(ctx, fa, d, *std::max_element(xt32, xt32 + 8), max_cand));
