@@ -70,7 +70,7 @@ struct fal_ctx {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
         size_t used = 0;
     } timers[fal::kNumStages];
-    fal::Scratch scratch[28];
+    fal::Scratch scratch[32];
     int32_t* fb_host = nullptr;           // pinned: fallback-query count of the last fused scan
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 

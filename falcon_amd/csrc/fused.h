@@ -50,7 +50,8 @@ struct FusedArgs {
     int dbg;                     // FALCON_FUSED_DBG: experiment bits (results invalid when set)
     // IVF buckets (ivf16.hip): the candidates of a query are the rows of its probed lists; thr / gmem_* come from
     // select16_kernel instead of approx_kernel
-    int ivf;                     // 1: jobs32 are IVF buckets (c_row0 = global id of the bucket's list 0)
+    int ivf;                     // 1: jobs32 are IVF buckets (c_row0 = global id of the bucket's list 0); 2: the same, and the kept
+                                 // candidates + their exact similarities come from pairs16.hip instead of band_kernel
     const int32_t* assign;       // [n] bucket-local list of every sorted row
     const int32_t* pos_of_row;   // [n] sorted row -> list-order position
     const int32_t* probes;       // [n, n_probe] by list-order position (-1 = none)

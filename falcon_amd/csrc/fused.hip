@@ -577,11 +577,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (need_thr) t = a.thr[row];
         const int k0 = i0 & 0xFF, k1 = i1 & 0xFF;
         bool fb = ((i0 | i1) & 0x200) != 0;
-        const bool amb = ((i0 | i1) & 0x100) != 0;
+        bool amb = ((i0 | i1) & 0x100) != 0;
         int why = fb ? 2 : 0;                                // (reason counters of the fallback list: fb_count[1..3])
         if (need_thr) {
             if (!fb && (t.flags & 2)) why = 1;
             fb = fb || (t.flags & 2);
+        }
+        uint32_t ki_x = ki_l;
+        bool drop = false;
+        if (a.ivf == 2) {
+            // pairs16.hip handed over every window candidate whose KEY is not certainly below the k-th best, with its exact
+            // similarity: below L certainly not among the k best, inside [L, U] ambiguous
+            const int half0 = lane >= kKeepHalf, idx0 = lane - half0 * kKeepHalf;
+            const bool mine0 = lane < FAL_FUSED_KEEP && idx0 < (half0 ? k1 : k0) && !fb;
+            const float s = sortable_f32(ku_l);
+            const bool ok = mine0 && s >= t.L;
+            const bool amb_l = ok && s <= t.U;
+            drop = mine0 && !ok;
+            ki_x |= amb_l ? 0x80000000u : 0u;
+            const bool amb_x = __ballot(amb_l) != 0ull;
+            if (amb_x && !amb && !fb) {                      // (cannot happen: an exact value inside [L, U] has its key inside the
+                fb = true;                                   //  ambiguous range, which kept16_kernel flags)
+                why = 3;
+            }
+            amb = amb_x;
         }
         uint32_t uT = 0, iT = 0xFFFFFFFFu;                  // exact k-th key (only when an ambiguous candidate exists)
         if (!fb && amb) {
@@ -670,9 +689,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         bool keepit = false;
         uint32_t u = 0, id = 0;
         const int half = lane >= kKeepHalf, idx = lane - half * kKeepHalf;
-        if (lane < FAL_FUSED_KEEP && idx < (half ? k1 : k0)) {
+        if (lane < FAL_FUSED_KEEP && idx < (half ? k1 : k0) && !drop) {
             u = ku_l;
-            id = ki_l;
+            id = ki_x;
             keepit = true;
             if (id & 0x80000000u) {
                 id &= 0x7FFFFFFFu;
@@ -830,7 +849,7 @@ int launch_fused_ivf_tail(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_
     if (a.n_jobs32 <= 0 || list_tiles32 <= 0) return FAL_OK;
     FAL_REQUIRE(list_tiles32 * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     const int steps = d / 16;
-    {
+    if (a.ivf != 2) {
         StageScope ts(ctx, ST_SCAN);
         dim3 grid((unsigned)(list_tiles32 * 8)), block(64);
         const size_t lds = sizeof(uint32_t) * 32 * (size_t)a.mask_words;

@@ -279,7 +279,10 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
         n_mem = 0;
     }
     t.mc = min(n_mem, FAL_FUSED_MEM / 2) | (max(n_mem - FAL_FUSED_MEM / 2, 0) << 16);
-    if (lane == 0) a.thr[out_row] = t;
+    if (lane == 0) {
+        a.thr[out_row] = t;
+        if (a.gsel) a.gsel[out_row] = make_int2((int)T - delta, (int)T + delta);
+    }
     if (n_mem == 0) return;
     float* gv = a.gmem_v + out_row * FAL_FUSED_MEM;
     uint32_t* gi = a.gmem_id + out_row * FAL_FUSED_MEM;
@@ -307,6 +310,7 @@ __device__ __forceinline__ void select16_trivial(const Select16Args& a, int64_t 
         t0.bstar = 1 << 30;
         t0.flags = flags;
         a.thr[out_row] = t0;
+        if (a.gsel) a.gsel[out_row] = make_int2(INT32_MIN, INT32_MIN);      // every window candidate stays, none is ambiguous
     }
 }
 

@@ -582,6 +582,17 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         fa.ivf = 1; fa.assign = ivf->assign; fa.pos_of_row = ivf->pos_of_row; fa.probes = probes; fa.n_probe = np;
         fa.mask_words = (max_n_list + 31) / 32; fa.list_off = ivf->list_off; fa.perm = ivf->perm;
         FAL_TRY(fused_prepare(ctx, &fa, ivf->n));
+        // the exact part: only the (query, candidate) pairs that can matter (pairs16.hip) when the per-query list table fits LDS
+        // (buckets with <= 512 lists); else -- or with FALCON_IVF16_BAND -- the whole precursor window on the fp32 matrix cores
+        static const bool force_band = getenv("FALCON_IVF16_BAND") != nullptr;
+        const bool pairs = max_n_list <= 512 && !force_band;
+        int2 *gsel = nullptr, *win = nullptr;
+        if (pairs) {
+            fa.ivf = 2;
+            FAL_TRY(ctx->reserve(SLOT_WIN, 2 * sizeof(int2) * (size_t)ivf->n, (void**)&gsel));
+            win = gsel + ivf->n;
+            FAL_TRY(launch_windows16(ctx, coarse_dev, (int)coarse.size(), ivf_tiles, nf->pmz, nf->tol, nf->is_da, win));
+        }
         uint16_t* keys = nullptr;
         FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(uint16_t) * (need_fine + 2 * kSimsSlack), (void**)&keys));
         int64_t max_cand = 0;
@@ -602,8 +613,19 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             sa.tile_begin = t0; sa.q_sim_off = q_sim_off;
             sa.perm = ivf->perm; sa.thr = fa.thr; sa.gmem_v = fa.gmem_v; sa.gmem_id = fa.gmem_id;
             sa.max_keys = max_total;
+            sa.gsel = gsel;
             FAL_TRY(launch_select16(ctx, sa, t1 - t0));
+            if (pairs) {
+                Kept16Args ka{};
+                ka.keys = keys; ka.keys_base = base; ka.jobs = coarse_dev; ka.tile_begin = t0; ka.n_probe = np;
+                ka.tab_stride = max_n_list; ka.probes = probes; ka.list_off = ivf->list_off; ka.q_sim_off = q_sim_off;
+                ka.pos_of_row = ivf->pos_of_row; ka.assign = ivf->assign; ka.pmz = nf->pmz; ka.rt = nf->rt; ka.rt_tol = nf->rt_tol;
+                ka.tol_f = fa.tol_f; ka.rt_f = fa.rt_f; ka.is_da = nf->is_da; ka.gsel = gsel; ka.win = win;
+                ka.gkept_id = fa.gkept_id; ka.gkcnt = fa.gkcnt;
+                FAL_TRY(launch_kept16(ctx, ka, t1 - t0));
+            }
         }
+        if (pairs) FAL_TRY(launch_pairs16(ctx, fa, d, *std::max_element(xt32, xt32 + 8)));
         FAL_TRY(launch_fused_ivf_tail(ctx, fa, d, *std::max_element(xt32, xt32 + 8), max_cand));
         FAL_CHECK_HIP(hipStreamSynchronize(st));
         return FAL_OK;
