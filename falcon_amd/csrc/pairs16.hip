@@ -154,62 +154,23 @@ __global__ __launch_bounds__(512) void kept16_kernel(Kept16Args a) {
     }
 }
 
-// the k-ordered fmaf chain of simtile.h's exact_dot with WHOLE CACHE LINES per step: 8 consecutive float4 (128 bytes) of either
-// half of either row.  With exact_dot's 4 per step a lane came back to every line of its gathered row in the next step -- by then
-// the line had left the 32 kB L1 (eight waves x 64 rows x two halves in flight), so the L2 served every line twice and more
-__device__ __forceinline__ float exact_dot_lines(const float* __restrict__ a, const float* __restrict__ b, int d) {
-    const int dh4 = d >> 3;
-    const float4* a4 = reinterpret_cast<const float4*>(a);
-    const float4* b4 = reinterpret_cast<const float4*>(b);
-    float acc = 0.f;
-    constexpr int U = 8;
-    int j = 0;
-    for (; j + U <= dh4; j += U) {
-        float4 al[U], ah[U], bl[U], bh[U];
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            bl[t] = b4[j + t];
-            bh[t] = b4[dh4 + j + t];
-        }
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            al[t] = a4[j + t];
-            ah[t] = a4[dh4 + j + t];
-        }
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            acc = __builtin_fmaf(al[t].x, bl[t].x, acc);
-            acc = __builtin_fmaf(ah[t].x, bh[t].x, acc);
-            acc = __builtin_fmaf(al[t].y, bl[t].y, acc);
-            acc = __builtin_fmaf(ah[t].y, bh[t].y, acc);
-            acc = __builtin_fmaf(al[t].z, bl[t].z, acc);
-            acc = __builtin_fmaf(ah[t].z, bh[t].z, acc);
-            acc = __builtin_fmaf(al[t].w, bl[t].w, acc);
-            acc = __builtin_fmaf(ah[t].w, bh[t].w, acc);
-        }
-    }
-    for (; j < dh4; ++j) {
-        const float4 al = a4[j], ah = a4[dh4 + j], bl = b4[j], bh = b4[dh4 + j];
-        acc = __builtin_fmaf(al.x, bl.x, acc);
-        acc = __builtin_fmaf(ah.x, bh.x, acc);
-        acc = __builtin_fmaf(al.y, bl.y, acc);
-        acc = __builtin_fmaf(ah.y, bh.y, acc);
-        acc = __builtin_fmaf(al.z, bl.z, acc);
-        acc = __builtin_fmaf(ah.z, bh.z, acc);
-        acc = __builtin_fmaf(al.w, bl.w, acc);
-        acc = __builtin_fmaf(ah.w, bh.w, acc);
-    }
-    return acc;
-}
-
-// exact similarity of every kept pair: the pairs of a 32-query tile in consecutive lanes
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) void pairs16_kernel(FusedArgs a, int d) {
+// exact similarity of every kept pair: the pairs of a 32-query tile in consecutive lanes, one k-ordered fmaf chain per lane
+// (bit-identical to the matrix-core chain).  A lane's candidate row is a gathered row: with a row per lane a load instruction
+// touches 64 cache lines for 16 bytes each and the texture addresser, not the memory, sets the pace (94 us per chain measured).
+// So the candidates' bytes are fetched COALESCED -- an instruction covers 16 rows x 64 bytes: lane L fetches piece L & 3 of the
+// row of pair 16g + (L >> 2) -- and transposed through LDS (pair slots of 176 bytes: conflict-free b128 reads) into the lanes
+// that own the pairs.  The query rows are shared by neighbouring lanes (a wave's 64 pairs span a dozen queries): read directly.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void pairs16_kernel(FusedArgs a, int d) {
+    constexpr int kSlot = 176;                                   // bytes per pair: 64 (low half) + 16 + 64 (high half) + 32
+    constexpr int U = 4;                                         // 16-byte steps of either half per batch
     __shared__ int32_t off[33];
+    __shared__ __attribute__((aligned(16))) unsigned char tbuf[4][64 * kSlot];
     int ji, lt;
     if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
     const int nqw = min(32, job.nc - 32 * lt);
     const int64_t row_t = job.q_row0 + 32 * lt;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x < 64) {                                      // counts of the tile's queries, prefix sum by the first wave
         const int q = threadIdx.x;
         int c = 0;
@@ -228,14 +189,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) voi
     }
     __syncthreads();
     const int P = off[32];
-    for (int i = threadIdx.x; i < P; i += 256) {
+    const int dh4 = d >> 3;
+    const float4* X4 = reinterpret_cast<const float4*>(a.X);
+    unsigned char* tb = tbuf[w];
+    for (int i0 = 64 * w; i0 < P; i0 += 256) {                   // (wave-uniform: the lanes of a wave work together)
+        const int i = i0 + lane;
+        const bool live = i < P;
+        const int ic = min(i, P - 1);
         int q = 0;
 #pragma unroll
-        for (int s = 16; s >= 1; s >>= 1) q = (q + s < 32 && off[q + s] <= i) ? q + s : q;
-        const int j = i - off[q];
+        for (int s = 16; s >= 1; s >>= 1) q = (q + s < 32 && off[q + s] <= ic) ? q + s : q;
+        const int j = ic - off[q];
         const int64_t row = row_t + q;
         const uint32_t id = a.gkept_id[row * FAL_FUSED_KEEP + j];
-        a.gkept_u[row * FAL_FUSED_KEEP + j] = max(f32_sortable(exact_dot_lines(a.X + row * d, a.X + (int64_t)id * d, d)), 1u);
+        int64_t idT[4];                                          // candidate row of the pair this lane FETCHES for in instruction g
+#pragma unroll
+        for (int g = 0; g < 4; ++g) idT[g] = (int64_t)(uint32_t)__shfl((int)id, 16 * g + (lane >> 2), 64) * (2 * dh4);
+        const float4* qp = X4 + row * (2 * dh4);
+        float acc = 0.f;
+        for (int j0 = 0; j0 < dh4; j0 += U) {
+            const int pc = min(j0 + (lane & 3), dh4 - 1);
+            float4 sl[4], sh[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                sl[g] = X4[idT[g] + pc];
+                sh[g] = X4[idT[g] + dh4 + pc];
+            }
+            float4 ql[U], qh[U];
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                const int jj = min(j0 + t, dh4 - 1);
+                ql[t] = qp[jj];
+                qh[t] = qp[dh4 + jj];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned char* slot = tb + (16 * g + (lane >> 2)) * kSlot + (lane & 3) * 16;
+                *reinterpret_cast<float4*>(slot) = sl[g];
+                *reinterpret_cast<float4*>(slot + 80) = sh[g];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned char* mine = tb + lane * kSlot;
+#pragma unroll
+            for (int t = 0; t < U; ++t) {
+                if (j0 + t < dh4) {                              // (wave-uniform)
+                    const float4 cl = *reinterpret_cast<const float4*>(mine + t * 16);
+                    const float4 ch = *reinterpret_cast<const float4*>(mine + 80 + t * 16);
+                    acc = __builtin_fmaf(ql[t].x, cl.x, acc);
+                    acc = __builtin_fmaf(qh[t].x, ch.x, acc);
+                    acc = __builtin_fmaf(ql[t].y, cl.y, acc);
+                    acc = __builtin_fmaf(qh[t].y, ch.y, acc);
+                    acc = __builtin_fmaf(ql[t].z, cl.z, acc);
+                    acc = __builtin_fmaf(qh[t].z, ch.z, acc);
+                    acc = __builtin_fmaf(ql[t].w, cl.w, acc);
+                    acc = __builtin_fmaf(qh[t].w, ch.w, acc);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (live) a.gkept_u[row * FAL_FUSED_KEEP + j] = max(f32_sortable(acc), 1u);
     }
 }
 
