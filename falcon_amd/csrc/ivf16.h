@@ -49,30 +49,26 @@ struct Select16Args {
 struct Kept16Args {              // pairs16.hip
     const uint16_t* keys;
     int64_t keys_base;
-    const DenseJob* jobs;        // IVF tile table; tile t = sorted rows [q_row0 + 32 lt, ...) here
-    int64_t tile_begin;
+    const DenseJob* jobs;        // IVF tile table (tile order = list-order positions)
+    int64_t tile_begin, n_tiles;
     const int32_t* tile_job;     // (launch_kept16: the table launch_select16 built for the same tiles)
     int n_probe;
-    int tab_stride;              // >= the largest n_list (ints per query of the list table in LDS)
     const int32_t* probes;
     const int64_t* list_off;
     const int64_t* q_sim_off;
-    const int32_t* pos_of_row;
-    const int32_t* assign;
-    const float* pmz;
-    const float* rt;
-    double rt_tol;
+    const int32_t* perm;         // [n] list-order position -> sorted row
+    const float* pmz_l;          // [n] precursor m/z by list-order position (ascending inside a list)
+    const float* rt;             // [n] by sorted row, or nullptr
+    double tol, rt_tol;
     float tol_f, rt_f;
     int is_da;
-    const int2* gsel;
-    const int2* win;             // [n] by sorted row: precursor window [lo, hi) in sorted rows
+    const int2* gsel;            // [n] by sorted row (select16_kernel)
     uint32_t* gkept_id;          // [n, FAL_FUSED_KEEP] kept candidates (sorted rows), entries 0 .. count - 1
     int32_t* gkcnt;              // [n, 2] count (first 32 | the rest) | 0x100 ambiguous | 0x200 more than the hand-off holds
 };
 
 bool ivf16_supports(int d);
-int launch_windows16(fal_ctx* ctx, const DenseJob* jobs, int n_jobs, int64_t n_tiles, const float* pmz, double tol, int is_da,
-                     void* win);
+int launch_gather_pmz(fal_ctx* ctx, const float* pmz, const int32_t* perm, int64_t n, float* out);
 int launch_kept16(fal_ctx* ctx, const Kept16Args& a, int64_t n_tiles);        // right after launch_select16 on the same tiles
 int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32);
 int launch_gather16(fal_ctx* ctx, const void* X16, const int32_t* perm, int64_t n, int d, void* out, int32_t* pos_of_row);

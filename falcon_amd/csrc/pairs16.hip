@@ -3,12 +3,10 @@
 // band_kernel<., IVF> evaluates the whole precursor window of a 32-query tile on the fp32 matrix cores (240 rows at
 // BASELINE configs[2]'s bucket density, 870 at configs[3]'s) although a query keeps ~5 of them: the cost grows with the
 // window, the need does not.  Here:
-//   window16_kernel   the precursor window [lo, hi) of every query as a range of sorted rows (binary searches inside the bucket,
-//      slightly widened: the exact tolerance tests run on the candidates below);
-//   kept16_kernel   16 lanes per query walk the window.  A per-query table in LDS maps a list of the bucket to where its
-//      keys start in the query's key stream (or "not probed"): a window row that lies in a probed list has its key looked up --
-//      stream offset of the list + the row's position inside the list -- and stays if the key is not certainly below the k-th
-//      best (select16_kernel left that threshold) and the exact tolerance tests pass;
+//   kept16_kernel   16 lanes per query, one per probed list.  Inside a list the rows keep their precursor order, so the part of
+//      a probed list inside the query's precursor window is a contiguous range of list positions (two binary searches on the
+//      precursor m/z in list order) and its keys are contiguous in the query's key stream.  A row stays if its key is not
+//      certainly below the k-th best (select16_kernel left that threshold) and the exact tolerance tests pass;
 //   pairs16_kernel   the exact similarity of every kept pair by the k-ordered fmaf chain (bit-identical to the matrix-core
 //      chain), one pair per lane, the pairs of a 32-query tile compacted so that the lanes are full;
 //   resolve_kernel (fused.hip, ivf = 2)   thresholds on the exact values, the k-th key for ambiguous queries, sort, store.
@@ -27,122 +25,109 @@ namespace fal {
 
 constexpr int32_t kNotProbed = INT_MIN;
 
-__global__ void window16_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t n_tiles, const float* __restrict__ pmz,
-                                double tol, int is_da, int2* __restrict__ win) {
-    const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const int64_t t = g >> 5;
-    if (t >= n_tiles) return;
-    const DenseJob job = jobs[find_job(jobs, n_jobs, t)];
-    const int ql = 32 * (int)(t - job.tile0) + (int)(g & 31);
-    if (ql >= job.nq) return;
-    const int64_t b0 = job.q_row0, b1 = job.q_row0 + job.nq;    // the bucket's sorted rows
-    const int64_t row = b0 + ql;
-    const double q = (double)pmz[row];
-    double lob, hib;
-    if (is_da) {
-        lob = q - tol - 1e-3;
-        hib = q + tol + 1e-3;
-    } else {
-        const double tt = tol * 1e-6;
-        lob = q * (1.0 - 1.01 * tt - 2e-6);
-        hib = tt < 0.5 ? q * (1.0 + 1.01 * tt / (1.0 - tt) + 2e-6) : INFINITY;
-    }
-    int64_t lo = b0, hi = row;                                   // first row with pmz >= lob (rows are sorted by precursor m/z)
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((double)pmz[mid] < lob) lo = mid + 1; else hi = mid;
-    }
-    const int64_t wlo = lo;
-    lo = row;
-    hi = b1;                                                     // first row with pmz > hib
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((double)pmz[mid] <= hib) lo = mid + 1; else hi = mid;
-    }
-    win[row] = make_int2((int)wlo, (int)lo);
+// pmz_l[pos] = pmz[perm[pos]]: precursor m/z in list order (inside a list the rows keep their sorted order: ascending)
+__global__ void gather_pmz_kernel(const float* __restrict__ pmz, const int32_t* __restrict__ perm, int64_t n, float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = pmz[perm[i]];
 }
 
-// one workgroup = the 32 queries of a sorted-row tile, 16 lanes each
-__global__ __launch_bounds__(512) void kept16_kernel(Kept16Args a) {
-    extern __shared__ int32_t tab_all[];                         // [32][tab_stride]: list -> (key-stream offset - first position), or kNotProbed
-    const int tid = threadIdx.x, ql = tid >> 4, sub = tid & 15, lane = tid & 63, sh = 16 * (lane >> 4);
-    const int64_t t = a.tile_begin + blockIdx.x;
-    const DenseJob job = a.jobs[a.tile_job[blockIdx.x]];
+// 16 lanes per query, one lane per probed list (two rounds for 32 probes ...).  Inside a list the rows are sorted by
+// precursor m/z, so the part of the list inside the query's (slightly widened) precursor window is a contiguous range of list
+// positions -- two binary searches -- and its keys are contiguous in the query's key stream.  A row stays if its key is not
+// certainly below the k-th best (select16_kernel left that threshold) and the exact tolerance tests pass.
+__global__ __launch_bounds__(256) void kept16_kernel(Kept16Args a) {
+    const int tid = threadIdx.x, sub = tid & 15, lane = tid & 63, sh = 16 * (lane >> 4);
+    const int64_t g = (int64_t)blockIdx.x * 16 + (tid >> 4);     // tile-order slot (tile-order = list-order positions)
+    const int64_t t = a.tile_begin + (g >> 5);
+    const int ql = (int)(g & 31);
+    bool live = (g >> 5) < a.n_tiles;
+    DenseJob job{};
+    if (live) job = a.jobs[a.tile_job[g >> 5]];
     const int lt = (int)(t - job.tile0);
-    const int nl = job.nc, np = a.n_probe;
-    const int64_t row0 = job.q_row0, lbase = job.c_row0;
-    const bool live = 32 * lt + ql < job.nq;
-    const int64_t row = row0 + min(32 * lt + ql, job.nq - 1);
-    const int64_t p = a.pos_of_row[row];                         // list-order position of the query
-    int32_t* tq = tab_all + ql * a.tab_stride;
-    for (int i = sub; i < nl; i += 16) tq[i] = kNotProbed;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    {
-        const int32_t* pr = a.probes + p * np;
-        int run = 0;
-        for (int j0 = 0; j0 < np; j0 += 16) {                    // stream offset of every probed list: prefix sum inside the lane group
-            const int j = j0 + sub;
-            const int32_t l = j < np ? pr[j] : -1;
-            int64_t b = 0, e = 0;
-            if (l >= 0) {
-                b = a.list_off[lbase + l];
-                e = a.list_off[lbase + l + 1];
-            }
-            const int len = (int)(e - b);
-            int incl = len;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const int o = __shfl_up(incl, off, 16);
-                if (sub >= off) incl += o;
-            }
-            if (l >= 0) tq[l] = (int32_t)((int64_t)(run + incl - len) - b);
-            run += __shfl(incl, 15, 16);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    const int64_t lp = p - row0;                                 // the query's tile-order slot: its keys start at q_sim_off[slot]
-    const uint16_t* krow = a.keys + (a.q_sim_off[32 * (job.tile0 + (lp >> 5)) + (lp & 31)] - a.keys_base);
-    const int2 sel = a.gsel[row];
-    const int2 wn = a.win[row];
-    const float qmz = a.pmz[row];
+    live = live && 32 * lt + ql < job.nq;
+    const int np = a.n_probe;
+    const int64_t lbase = job.c_row0;
+    const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;      // the query's list-order position
+    const int64_t row = live ? a.perm[p] : 0;                    // ... and sorted row
+    const uint16_t* krow = a.keys + (a.q_sim_off[live ? 32 * t + ql : 32 * a.tile_begin] - a.keys_base);
+    const int2 sel = live ? a.gsel[row] : make_int2(INT32_MAX, INT32_MIN);
+    const float qmz = a.pmz_l[p];
     const bool use_rt = a.rt != nullptr && a.rt_tol >= 0.0;
     const float qrt = use_rt ? a.rt[row] : 0.f;
     const float tol_f = a.tol_f, rt_f = a.rt_f;
-    uint32_t* gk = a.gkept_id + row * FAL_FUSED_KEEP;
-    int kc = 0;
-    bool amb = false;
-    constexpr int U = 2;                                         // window rows per lane and step: their loads are in flight together
-    for (int64_t c0 = live ? wn.x : 0; c0 < (live ? wn.y : 0); c0 += 16 * U) {
-        int ls[U], ps[U];
-        float mz[U], rt[U];
-        bool inw[U];
-#pragma unroll
-        for (int x = 0; x < U; ++x) {
-            const int64_t c = c0 + 16 * x + sub;
-            inw[x] = c < wn.y;
-            const int64_t cc = inw[x] ? c : row;
-            ls[x] = a.assign[cc];
-            ps[x] = a.pos_of_row[cc];
-            mz[x] = a.pmz[cc];
-            rt[x] = use_rt ? a.rt[cc] : 0.f;
+    float lob, hib;                                               // conservative float32 bounds of the window (exact tests below)
+    {
+        const double q = (double)qmz;
+        double lo, hi;
+        if (a.is_da) {
+            lo = q - a.tol - 1e-3;
+            hi = q + a.tol + 1e-3;
+        } else {
+            const double tt = a.tol * 1e-6;
+            lo = q * (1.0 - 1.01 * tt - 2e-6);
+            hi = tt < 0.5 ? q * (1.0 + 1.01 * tt / (1.0 - tt) + 2e-6) : INFINITY;
         }
+        lob = (float)lo;
+        lob = (double)lob > lo ? __uint_as_float(__float_as_uint(lob) - 1u) : lob;       // round down (positive values)
+        hib = (float)hi;
+        hib = (double)hib < hi ? __uint_as_float(__float_as_uint(hib) + 1u) : hib;       // round up
+    }
+    uint32_t* gk = a.gkept_id + row * FAL_FUSED_KEEP;
+    const int32_t* pr = a.probes + p * np;
+    int kc = 0, run = 0;
+    bool amb = false;
+    for (int j0 = 0; j0 < np; j0 += 16) {
+        const int j = j0 + sub;
+        const int32_t l = (live && j < np) ? pr[j] : -1;
+        int64_t b = 0, e = 0;
+        if (l >= 0) {
+            b = a.list_off[lbase + l];
+            e = a.list_off[lbase + l + 1];
+        }
+        const int len = (int)(e - b);
+        int incl = len;
 #pragma unroll
-        for (int x = 0; x < U; ++x) {
-            const int64_t c = c0 + 16 * x + sub;
-            const int32_t off1 = inw[x] ? tq[ls[x]] : kNotProbed;
-            const bool member = off1 != kNotProbed && c != row;
-            const int u = member ? (int)krow[(int64_t)off1 + ps[x]] + 1 : 0;
-            const float diff = qmz - mz[x];                      // mass_diff(query, neighbour): the arithmetic of filter_kernel
-            const float xx = a.is_da ? diff : diff / mz[x];
-            bool ok = member && u >= sel.x && fabsf(xx) <= tol_f;
-            if (use_rt) ok = ok && fabsf(qrt - rt[x]) <= rt_f;
+        for (int off = 1; off < 16; off <<= 1) {
+            const int o = __shfl_up(incl, off, 16);
+            if (sub >= off) incl += o;
+        }
+        const int seg = run + incl - len;                        // where this list's keys start in the query's stream
+        run += __shfl(incl, 15, 16);
+        // first position with pmz >= lob / first with pmz > hib
+        int64_t lo = b, hi = e;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.pmz_l[mid] < lob) lo = mid + 1; else hi = mid;
+        }
+        const int64_t wa = lo;
+        hi = e;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.pmz_l[mid] <= hib) lo = mid + 1; else hi = mid;
+        }
+        const int64_t wb = lo;
+        // walk the range; the lanes of the group append their survivors together (ballot ranks)
+        for (int64_t c = wa;; ++c) {
+            const bool in = c < wb;
+            if (((uint32_t)(__ballot(in) >> sh) & 0xFFFFu) == 0u) break;
+            bool ok = in && c != p;
+            int u = 0;
+            if (ok) {
+                u = (int)krow[seg + (c - b)] + 1;
+                const float nmz = a.pmz_l[c];
+                const float diff = qmz - nmz;                    // mass_diff(query, neighbour): the arithmetic of filter_kernel
+                const float xx = a.is_da ? diff : diff / nmz;
+                ok = u >= sel.x && fabsf(xx) <= tol_f;
+            }
+            uint32_t id = 0;
+            if (ok) {
+                id = (uint32_t)a.perm[c];
+                if (use_rt) ok = fabsf(qrt - a.rt[id]) <= rt_f;
+            }
             amb = amb || (ok && u <= sel.y);
             const uint32_t gm = (uint32_t)(__ballot(ok) >> sh) & 0xFFFFu;
             if (ok) {
                 const int at = kc + __popc(gm & ((1u << sub) - 1u));
-                if (at < FAL_FUSED_KEEP) gk[at] = (uint32_t)c;
+                if (at < FAL_FUSED_KEEP) gk[at] = id;
             }
             kc += __popc(gm);
         }
@@ -253,12 +238,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
-int launch_windows16(fal_ctx* ctx, const DenseJob* jobs, int n_jobs, int64_t n_tiles, const float* pmz, double tol, int is_da,
-                     void* win) {
-    if (n_tiles <= 0) return FAL_OK;
+int launch_gather_pmz(fal_ctx* ctx, const float* pmz, const int32_t* perm, int64_t n, float* out) {
+    if (n <= 0) return FAL_OK;
     StageScope ts(ctx, ST_COARSE);
-    hipLaunchKernelGGL(window16_kernel, dim3((unsigned)ceil_div(n_tiles * 32, 256)), dim3(256), 0, ctx->stream, jobs, n_jobs, n_tiles,
-                       pmz, tol, is_da, reinterpret_cast<int2*>(win));
+    hipLaunchKernelGGL(gather_pmz_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16)), dim3(256), 0,
+                       ctx->stream, pmz, perm, n, out);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }
@@ -269,10 +253,9 @@ int launch_kept16(fal_ctx* ctx, const Kept16Args& a_in, int64_t n_tiles) {
     int32_t* tj = nullptr;           // (the tile -> job table launch_select16 left in the slot for the same tiles)
     FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * 16, (void**)&tj));
     a.tile_job = tj;
-    const size_t lds = sizeof(int32_t) * 32 * (size_t)a.tab_stride;
-    FAL_CHECK_HIP(hipFuncSetAttribute((const void*)kept16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    a.n_tiles = n_tiles;
     StageScope ts(ctx, ST_SELECT);
-    hipLaunchKernelGGL(kept16_kernel, dim3((unsigned)n_tiles), dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL(kept16_kernel, dim3((unsigned)(n_tiles * 2)), dim3(256), 0, ctx->stream, a);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

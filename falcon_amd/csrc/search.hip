@@ -582,16 +582,17 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         fa.ivf = 1; fa.assign = ivf->assign; fa.pos_of_row = ivf->pos_of_row; fa.probes = probes; fa.n_probe = np;
         fa.mask_words = (max_n_list + 31) / 32; fa.list_off = ivf->list_off; fa.perm = ivf->perm;
         FAL_TRY(fused_prepare(ctx, &fa, ivf->n));
-        // the exact part: only the (query, candidate) pairs that can matter (pairs16.hip) when the per-query list table fits LDS
-        // (buckets with <= 512 lists); else -- or with FALCON_IVF16_BAND -- the whole precursor window on the fp32 matrix cores
+        // the exact part: only the (query, candidate) pairs that can matter (pairs16.hip); with FALCON_IVF16_BAND the whole
+        // precursor window on the fp32 matrix cores (band_kernel: A/B runs)
         static const bool force_band = getenv("FALCON_IVF16_BAND") != nullptr;
-        const bool pairs = max_n_list <= 512 && !force_band;
-        int2 *gsel = nullptr, *win = nullptr;
+        const bool pairs = !force_band;
+        int2* gsel = nullptr;
+        float* pmz_l = nullptr;
         if (pairs) {
             fa.ivf = 2;
-            FAL_TRY(ctx->reserve(SLOT_WIN, 2 * sizeof(int2) * (size_t)ivf->n, (void**)&gsel));
-            win = gsel + ivf->n;
-            FAL_TRY(launch_windows16(ctx, coarse_dev, (int)coarse.size(), ivf_tiles, nf->pmz, nf->tol, nf->is_da, win));
+            FAL_TRY(ctx->reserve(SLOT_WIN, (sizeof(int2) + sizeof(float)) * (size_t)ivf->n, (void**)&gsel));
+            pmz_l = reinterpret_cast<float*>(gsel + ivf->n);
+            FAL_TRY(launch_gather_pmz(ctx, nf->pmz, ivf->perm, ivf->n, pmz_l));
         }
         uint16_t* keys = nullptr;
         FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(uint16_t) * (need_fine + 2 * kSimsSlack), (void**)&keys));
@@ -618,10 +619,9 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             if (pairs) {
                 Kept16Args ka{};
                 ka.keys = keys; ka.keys_base = base; ka.jobs = coarse_dev; ka.tile_begin = t0; ka.n_probe = np;
-                ka.tab_stride = max_n_list; ka.probes = probes; ka.list_off = ivf->list_off; ka.q_sim_off = q_sim_off;
-                ka.pos_of_row = ivf->pos_of_row; ka.assign = ivf->assign; ka.pmz = nf->pmz; ka.rt = nf->rt; ka.rt_tol = nf->rt_tol;
-                ka.tol_f = fa.tol_f; ka.rt_f = fa.rt_f; ka.is_da = nf->is_da; ka.gsel = gsel; ka.win = win;
-                ka.gkept_id = fa.gkept_id; ka.gkcnt = fa.gkcnt;
+                ka.probes = probes; ka.list_off = ivf->list_off; ka.q_sim_off = q_sim_off; ka.perm = ivf->perm; ka.pmz_l = pmz_l;
+                ka.rt = nf->rt; ka.tol = nf->tol; ka.rt_tol = nf->rt_tol; ka.tol_f = fa.tol_f; ka.rt_f = fa.rt_f; ka.is_da = nf->is_da;
+                ka.gsel = gsel; ka.gkept_id = fa.gkept_id; ka.gkcnt = fa.gkcnt;
                 FAL_TRY(launch_kept16(ctx, ka, t1 - t0));
             }
         }
