@@ -136,11 +136,16 @@ class ClusterPipeline:
         rank, world = shard
         splits = np.asarray(st["splits"], np.int64)
         owner = fdist.shard_units(fdist.bucket_costs(np.diff(splits), st["n_list"], p.n_probe), world)
-        pos, sub_splits, mine = fdist.shard_rows(splits, owner, rank)
-        pos_d = c.to_dev(pos, torch.int64)
-        order_sub = st["order"][pos_d] if len(pos) else st["order"][:0]
-        return dict(order=order_sub, mzs=st["mzs"][pos_d] if len(pos) else st["mzs"][:0],
-                    rts=None if st["rts"] is None else st["rts"][pos_d], splits=sub_splits,
+        first, sizes, sub_splits, mine = fdist.shard_buckets(splits, owner, rank)
+        n_sub = int(sub_splits[-1])
+        if n_sub:
+            # sorted positions of the subset's rows, expanded on the device from the per-bucket (first, size) pairs
+            shift = c.to_dev(np.stack([first - sub_splits[:-1], sizes]), torch.int64)
+            pos_d = torch.repeat_interleave(shift[0], shift[1], output_size=n_sub) + torch.arange(n_sub, device=c.tdev)
+        order_sub = st["order"][pos_d] if n_sub else st["order"][:0]
+        rts = st["rts"]
+        return dict(order=order_sub, mzs=st["mzs"][pos_d] if n_sub else st["mzs"][:0],
+                    rts=None if rts is None else (rts[pos_d] if n_sub else rts[:0]), splits=sub_splits,
                     n_list=np.asarray(st["n_list"])[mine], rows=order_sub, n_total=int(st["order"].numel()),
                     buckets=mine)
 

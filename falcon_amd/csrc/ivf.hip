@@ -12,6 +12,7 @@
 #include "scan.h"
 #include "ivf.h"
 #include "ivf16.h"
+#include "util.h"
 
 namespace fal {
 
@@ -147,6 +148,160 @@ __global__ __launch_bounds__(64) void list_walk_kernel(const float* __restrict__
         const int e = 64 * p + lane;
         if (p < passes && e < d / 4)
             o[e] = make_float4(acc[p].x * inv, acc[p].y * inv, acc[p].z * inv, acc[p].w * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k-means update from the SPARSE form of the rows.  A vectorised spectrum has at most as many non-zero components as peaks
+// (~50 of 400), and adding a zero never changes a float32 sum (the accumulators start at +0.0), so summing a list's members
+// over their non-zero components only -- in the same row order -- gives the same centroid bit for bit while reading 384 B per
+// member instead of 4 d.  The members of a list come from a stable sort of the rows by list (row order inside a list).
+// ------------------------------------------------------------------------------------------
+constexpr int kSparseW = 64;                 // entries per row (one per lane)
+constexpr uint16_t kColPad = 0xFFFF;         // unused entry
+constexpr uint16_t kColDense = 0xFFFE;       // in entry 0: the row has more than kSparseW non-zeros, read the dense row
+
+// rows of the IVF buckets -> (column, value) entries; blocks of 256 rows, seg_off = first block of every bucket
+__global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restrict__ X, int d, const BucketDev* __restrict__ bk,
+                                                            const int64_t* __restrict__ seg_off, int nb,
+                                                            uint16_t* __restrict__ cols, float* __restrict__ vals) {
+    __shared__ uint16_t sc[4][kSparseW];
+    __shared__ float sv[4][kSparseW];
+    int lo = 0, hi = nb - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_off[mid] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const BucketDev b = bk[lo];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r_first = (int)(blockIdx.x - seg_off[lo]) * 256;
+    const int r_end = min(b.n, r_first + 256);
+    for (int rl = r_first + w; rl < r_end; rl += 4) {
+        const int64_t r = b.row0 + rl;
+        sc[w][lane] = kColPad;
+        sv[w][lane] = 0.f;
+        const float4* row = reinterpret_cast<const float4*>(X + r * d);
+        int base = 0;
+        for (int e0 = 0; e0 < d / 4; e0 += 64) {
+            const int e = e0 + lane;
+            const float4 x = e < d / 4 ? row[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+            const int c = (int)(x.x != 0.f) + (int)(x.y != 0.f) + (int)(x.z != 0.f) + (int)(x.w != 0.f);
+            int pre = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(pre, off, 64);
+                if (lane >= off) pre += y;
+            }
+            const int tot = __shfl(pre, 63, 64);
+            if (base + tot <= kSparseW) {
+                int pos = base + pre - c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (xs[j] != 0.f) {
+                        sc[w][pos] = (uint16_t)(4 * e + j);
+                        sv[w][pos] = xs[j];
+                        ++pos;
+                    }
+            }
+            base += tot;
+        }
+        if (base > kSparseW && lane == 0) sc[w][0] = kColDense;
+        cols[r * kSparseW + lane] = sc[w][lane];
+        vals[r * kSparseW + lane] = sv[w][lane];
+    }
+}
+
+// global list of every sorted row (bucket by binary search on the bucket table) = the key of the stable sort by list
+__global__ void list_key_kernel(const int32_t* __restrict__ assign, const int64_t* __restrict__ bucket_off,
+                                const int64_t* __restrict__ list_base, int n_buckets, int64_t n, uint32_t* __restrict__ keys) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_buckets - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (bucket_off[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        keys[i] = (uint32_t)(list_base[lo] + assign[i]);
+    }
+}
+
+// list_off[L] = first position of list L in the sorted keys (lower bound), list_off[total] = n
+__global__ void list_bounds_kernel(const uint32_t* __restrict__ keys_sorted, int64_t n, int64_t total, int64_t* __restrict__ list_off) {
+    for (int64_t L = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; L <= total; L += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)keys_sorted[mid] < L) lo = mid + 1; else hi = mid;
+        }
+        list_off[L] = lo;
+    }
+}
+
+// update: one wave per (bucket, list); the members (sorted rows, in row order) are added one after the other into the wave's
+// LDS accumulators, eight members' entries in flight.  Normalisation as in list_walk_kernel.  Empty lists keep their centroid.
+__global__ __launch_bounds__(64) void centroid_update_kernel(const uint16_t* __restrict__ cols, const float* __restrict__ vals,
+                                                             const float* __restrict__ X, int d,
+                                                             const int32_t* __restrict__ rows_sorted,
+                                                             const int64_t* __restrict__ list_off,
+                                                             const BucketDev* __restrict__ bk, int nb, float* __restrict__ C) {
+    __shared__ float acc[FAL_MAX_LOW_DIM];
+    const BucketDev b = bk[find_bucket(bk, nb, blockIdx.x)];
+    const int li = (int)(blockIdx.x - b.wave0);
+    const int lane = threadIdx.x;
+    const int64_t o0 = list_off[b.list0 + li];
+    const int cnt = (int)(list_off[b.list0 + li + 1] - o0);
+    if (cnt == 0) return;   // keep the previous centroid
+    for (int c = lane; c < d; c += 64) acc[c] = 0.f;
+    constexpr int G = 8;
+    for (int base = 0; base < cnt; base += 64) {
+        const int m_in = min(64, cnt - base);
+        const int my = lane < m_in ? rows_sorted[o0 + base + lane] : 0;
+        for (int g = 0; g < m_in; g += G) {
+            int c[G];
+            float v[G];
+            int64_t m[G];
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                const bool ok = g + t < m_in;
+                m[t] = __shfl(my, ok ? g + t : 0, 64);
+                c[t] = ok ? (int)cols[m[t] * kSparseW + lane] : (int)kColPad;
+                v[t] = ok ? vals[m[t] * kSparseW + lane] : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < G; ++t) {
+                if (g + t >= m_in) break;
+                if (__shfl(c[t], 0, 64) == (int)kColDense) {
+                    const float* row = X + m[t] * d;
+                    for (int e = lane; e < d; e += 64) acc[e] += row[e];
+                } else if (c[t] != (int)kColPad) {
+                    acc[c[t]] += v[t];      // LDS operations of a wave execute in order: member after member
+                }
+            }
+        }
+    }
+    constexpr int P = FAL_MAX_LOW_DIM / 256;
+    const int passes = (d + 255) / 256;
+    float4 r[P];
+    double part = 0.0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int e = 64 * p + lane;
+        r[p] = (p < passes && e < d / 4) ? make_float4(acc[4 * e], acc[4 * e + 1], acc[4 * e + 2], acc[4 * e + 3])
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < passes) {
+            part += (double)r[p].x * (double)r[p].x;
+            part += (double)r[p].y * (double)r[p].y;
+            part += (double)r[p].z * (double)r[p].z;
+            part += (double)r[p].w * (double)r[p].w;
+        }
+    }
+    const double nr = wave_xor_sum_d(part);
+    const float inv = nr > 0.0 ? (float)__ddiv_rn(1.0, __dsqrt_rn(nr)) : 0.f;
+    float4* o = reinterpret_cast<float4*>(C + (b.list0 + li) * d);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int e = 64 * p + lane;
+        if (p < passes && e < d / 4) o[e] = make_float4(r[p].x * inv, r[p].y * inv, r[p].z * inv, r[p].w * inv);
     }
 }
 
@@ -441,6 +596,57 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             B_TRY(ctx->upload(hjobs_dev, hjobs.data(), sizeof(AssignJob) * hjobs.size()));
             B_TRY(ctx->reserve(SLOT_INVCNT, sizeof(uint16_t) * (size_t)total * low_dim + 64, &C16));
         }
+        // centroid update: members of every list from a stable sort of the rows by list, sums over the rows' sparse form
+        // (centroid_update_kernel).  FALCON_KMEANS_DENSE_UPDATE keeps the dense walk over the assignment array (A/B runs).
+        static const bool dense_update = getenv("FALCON_KMEANS_DENSE_UPDATE") != nullptr;
+        uint16_t* sp_cols = nullptr;
+        float* sp_vals = nullptr;
+        uint32_t *key_in = nullptr, *key_out = nullptr;
+        int32_t* iota = nullptr;
+        int64_t *boff_dev = nullptr, *lbase_dev = nullptr;
+        int end_bit = 1;
+        while (end_bit < 32 && (1ll << end_bit) < total) ++end_bit;
+        if (!dense_update) {
+            std::vector<int64_t> seg_off(bk.size() + 1, 0), tab(2 * (size_t)(n_buckets + 1));
+            for (size_t i = 0; i < bk.size(); ++i) seg_off[i + 1] = seg_off[i] + ceil_div(bk[i].n, 256);
+            for (int64_t b = 0; b <= n_buckets; ++b) {
+                tab[b] = bucket_off[b];
+                tab[n_buckets + 1 + b] = ivf->list_base[b];
+            }
+            int64_t* seg_dev = nullptr;
+            void* sortbuf = nullptr;
+            B_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * seg_off.size(), (void**)&seg_dev));
+            B_TRY(ctx->upload(seg_dev, seg_off.data(), sizeof(int64_t) * seg_off.size()));
+            B_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * tab.size(), (void**)&boff_dev));
+            B_TRY(ctx->upload(boff_dev, tab.data(), sizeof(int64_t) * tab.size()));
+            lbase_dev = boff_dev + n_buckets + 1;
+            if (kmeans_iters > 0) {
+                B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, (void**)&sp_cols));
+                B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&sp_vals));
+            }
+            B_TRY(ctx->reserve(SLOT_SORT2, 3 * sizeof(uint32_t) * (size_t)n, &sortbuf));
+            key_in = (uint32_t*)sortbuf;
+            key_out = key_in + n;
+            iota = (int32_t*)(key_out + n);
+            StageScope ts(ctx, ST_BUILD);
+            if (kmeans_iters > 0)
+                hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
+                                   nbk, sp_cols, sp_vals);
+            B_HIP(hipGetLastError());
+            hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, st, iota, n);
+            B_HIP(hipGetLastError());
+        }
+        // stable sort of the rows by (global) list: perm = rows in list order, list_off = the lists' boundaries
+        auto sort_by_list = [&]() -> int {
+            hipLaunchKernelGGL(list_key_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 8192)), dim3(256), 0, st, ivf->assign,
+                               boff_dev, lbase_dev, (int)n_buckets, n, key_in);
+            FAL_CHECK_HIP(hipGetLastError());
+            FAL_TRY(sort_pairs_u32_i32(ctx, key_in, key_out, iota, ivf->perm, n, end_bit, SLOT_SORT));
+            hipLaunchKernelGGL(list_bounds_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total + 1, 256), 4096)), dim3(256), 0, st,
+                               key_out, n, total, ivf->list_off);
+            FAL_CHECK_HIP(hipGetLastError());
+            return FAL_OK;
+        };
         for (int it = 0; it <= kmeans_iters; ++it) {
             if (!hjobs.empty()) {
                 {
@@ -465,19 +671,31 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, n_wide, n_wave, n, keys, ivf->assign));
             if (it == kmeans_iters) break;   // final assignment against the final centroids
             StageScope ts(ctx, ST_BUILD);
-            hipLaunchKernelGGL(list_walk_kernel<0>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign,
-                               bkd, nbk, ivf->centroids, nullptr, nullptr, nullptr);
-        B_HIP(hipGetLastError());
+            if (dense_update) {
+                hipLaunchKernelGGL(list_walk_kernel<0>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign,
+                                   bkd, nbk, ivf->centroids, nullptr, nullptr, nullptr);
+            } else {
+                B_TRY(sort_by_list());
+                hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)waves), dim3(64), 0, st, sp_cols, sp_vals, X, low_dim,
+                                   ivf->perm, ivf->list_off, bkd, nbk, ivf->centroids);
+            }
+            B_HIP(hipGetLastError());
         }
         StageScope ts(ctx, ST_BUILD);
-        hipLaunchKernelGGL(list_walk_kernel<1>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
-                           nbk, nullptr, ivf->counts, nullptr, nullptr);
-        B_HIP(hipGetLastError());
-        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, ivf->counts, total, ivf->list_off);
-        B_HIP(hipGetLastError());
-        hipLaunchKernelGGL(list_walk_kernel<2>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
-                           nbk, nullptr, nullptr, ivf->list_off, ivf->perm);
-        B_HIP(hipGetLastError());
+        if (dense_update) {
+            hipLaunchKernelGGL(list_walk_kernel<1>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
+                               nbk, nullptr, ivf->counts, nullptr, nullptr);
+            B_HIP(hipGetLastError());
+            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, ivf->counts, total, ivf->list_off);
+            B_HIP(hipGetLastError());
+            hipLaunchKernelGGL(list_walk_kernel<2>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
+                               nbk, nullptr, nullptr, ivf->list_off, ivf->perm);
+            B_HIP(hipGetLastError());
+        } else {
+            B_TRY(sort_by_list());
+            if (sp_cols) ctx->pool_free(sp_cols);      // (recycled in stream order)
+            if (sp_vals) ctx->pool_free(sp_vals);
+        }
         // the float32 rows in list order are made on demand (fal_ivf_ensure_xl: the staged fine scan and the staged coarse scan read
         // them; the default path -- coarse quantiser from the build's keys, float16 prefilter -- does not: 16 GB at 10 M spectra)
         ivf->Xl = nullptr;

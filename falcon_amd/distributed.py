@@ -207,15 +207,22 @@ def bucket_costs(sizes: np.ndarray, n_list: np.ndarray, n_probe: int) -> np.ndar
     return sizes * cand
 
 
+def shard_buckets(splits: np.ndarray, owner: np.ndarray, rank: int):
+    """this rank's buckets (whole and in order): -> (first sorted position of each, sizes, the bucket boundaries of the
+    subset, bucket ids).  Per-bucket arrays only: the per-row expansion is `shard_rows` (host) or two device ops."""
+    mine = np.flatnonzero(owner == rank)
+    sizes = (splits[1:] - splits[:-1])[mine].astype(np.int64)
+    sub_splits = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    return np.asarray(splits[:-1], np.int64)[mine], sizes, sub_splits, mine
+
+
 def shard_rows(splits: np.ndarray, owner: np.ndarray, rank: int):
     """sorted positions of the rows of this rank's buckets (buckets stay whole and in order), the
     bucket boundaries of that subset, and the bucket ids."""
-    mine = np.flatnonzero(owner == rank)
-    sizes = (splits[1:] - splits[:-1])[mine]
-    sub_splits = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    first, sizes, sub_splits, mine = shard_buckets(splits, owner, rank)
     if len(mine) == 0:
         return np.zeros(0, np.int64), sub_splits, mine
-    rows = np.repeat(splits[:-1][mine] - sub_splits[:-1], sizes) + np.arange(sub_splits[-1])
+    rows = np.repeat(first - sub_splits[:-1], sizes) + np.arange(sub_splits[-1])
     return rows.astype(np.int64), sub_splits, mine
 
 

@@ -87,6 +87,52 @@ def test_ivf_build_matches_oracle(ctx, sizes, nlists, d):
             assert np.array_equal(cent[lb[b]:lb[b + 1]], C)
 
 
+def sparse_unit_vectors(n, d, seed, nnz_lo=20, nnz_hi=50):
+    """rows shaped like vectorised spectra: a few dozen non-zero components, near-duplicates in groups; plus rows with exactly
+    64 and with more than 64 non-zeros (the k-means update reads those dense), a negative component, and all-zero rows"""
+    rng = np.random.default_rng(seed)
+    n_groups = max(1, n // 12)
+    proto = np.zeros((n_groups, d), np.float32)
+    for g in range(n_groups):
+        c = rng.choice(d, rng.integers(nnz_lo, nnz_hi + 1), replace=False)
+        proto[g, c] = rng.random(len(c)).astype(np.float32) + 0.05
+    X = proto[rng.integers(0, n_groups, n)].copy()
+    X *= (1.0 + 0.3 * rng.standard_normal(X.shape).astype(np.float32)) * (X != 0)
+    for r in rng.choice(n, max(4, n // 50), replace=False):        # wide rows
+        k = 64 if (r % 3 == 0 or d <= 65) else int(rng.integers(65, min(d, 160) + 1))
+        X[r] = 0
+        X[r, rng.choice(d, k, replace=False)] = rng.random(k).astype(np.float32) + 0.01
+    nrm = np.sqrt((X.astype(np.float64) ** 2).sum(1))
+    X = (X / np.maximum(nrm, 1e-30)[:, None]).astype(np.float32)
+    X[rng.choice(n, 5, replace=False)] = 0
+    return X
+
+
+@pytest.mark.parametrize("sizes,nlists,d,half", [
+    ([3000, 500, 2200], [64, 1, 32], 400, False), ([5000, 2100], [200, 33], 400, True), ([1500], [16], 64, False),
+    ([2600, 40], [48, 1], 128, True),
+])
+def test_ivf_build_on_sparse_rows_matches_oracle(ctx, sizes, nlists, d, half):
+    """k-means on rows with few non-zero components: the centroid update sums the members' non-zero entries only (rows sorted
+    by list, centroid_update_kernel) -- centroids, assignments and lists still equal the oracle's dense sums bit for bit"""
+    import torch
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    X = sparse_unit_vectors(off[-1], d, 17, nnz_hi=min(50, d // 2))
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    idxr = ctx.ivf_build(Xd, off, np.array(nlists, np.int32), kmeans_iters=5,
+                         Xkm=Xd.to(torch.float16).contiguous() if half else None)
+    cent, asg, perm, loff = [t.cpu().numpy() for t in idxr.export()]
+    lb = np.concatenate([[0], np.cumsum(nlists)])
+    assert loff[0] == 0 and loff[-1] == off[-1]
+    for b, (a, e) in enumerate(zip(off[:-1], off[1:])):
+        C, ra, rperm, roff = fo.ivf_build(X[a:e], nlists[b], 5)
+        assert np.array_equal(asg[a:e], ra), (b, (asg[a:e] != ra).sum())
+        assert np.array_equal(loff[lb[b]:lb[b + 1] + 1] - a, roff)
+        assert np.array_equal(perm[a:e] - a, rperm)
+        if nlists[b] > 1:
+            assert np.array_equal(cent[lb[b]:lb[b + 1]].view(np.uint32), C.view(np.uint32))
+
+
 @pytest.mark.parametrize("n_probe,k", [(4, 32), (16, 128), (64, 64)])
 def test_ivf_search_matches_oracle_on_same_index(ctx, n_probe, k):
     import torch
