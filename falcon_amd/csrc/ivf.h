@@ -42,6 +42,7 @@ struct fal_ivf {
     float* centroids = nullptr;      // [total_lists, d]
     int32_t* assign = nullptr;       // [n] bucket-local list of each sorted row
     int32_t* perm = nullptr;         // [n] list-order position -> sorted row
+    void* build_tmp[2] = {nullptr, nullptr};   // the rows' sparse form during the build (released at its end)
     int64_t* list_off = nullptr;     // [total_lists + 1] list-order positions
     int64_t* counts = nullptr;       // [total_lists + 1]
     void* bk_dev = nullptr;          // BucketDev[n_ivf_buckets]

@@ -382,7 +382,7 @@ extern "C" {
 int fal_ivf_destroy(fal_ivf* ivf) {
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
-                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys};
+                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys, ivf->build_tmp[0], ivf->build_tmp[1]};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -621,8 +621,10 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             B_TRY(ctx->upload(boff_dev, tab.data(), sizeof(int64_t) * tab.size()));
             lbase_dev = boff_dev + n_buckets + 1;
             if (kmeans_iters > 0) {
-                B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, (void**)&sp_cols));
-                B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&sp_vals));
+                B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, &ivf->build_tmp[0]));
+                B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, &ivf->build_tmp[1]));
+                sp_cols = (uint16_t*)ivf->build_tmp[0];
+                sp_vals = (float*)ivf->build_tmp[1];
             }
             B_TRY(ctx->reserve(SLOT_SORT2, 3 * sizeof(uint32_t) * (size_t)n, &sortbuf));
             key_in = (uint32_t*)sortbuf;
@@ -693,8 +695,10 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             B_HIP(hipGetLastError());
         } else {
             B_TRY(sort_by_list());
-            if (sp_cols) ctx->pool_free(sp_cols);      // (recycled in stream order)
-            if (sp_vals) ctx->pool_free(sp_vals);
+            for (void*& t : ivf->build_tmp) {          // (recycled in stream order)
+                if (t) ctx->pool_free(t);
+                t = nullptr;
+            }
         }
         // the float32 rows in list order are made on demand (fal_ivf_ensure_xl: the staged fine scan and the staged coarse scan read
         // them; the default path -- coarse quantiser from the build's keys, float16 prefilter -- does not: 16 GB at 10 M spectra)

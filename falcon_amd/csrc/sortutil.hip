@@ -100,11 +100,13 @@ __global__ void gather_f32_kernel(const float* __restrict__ src, const int64_t* 
 
 int sort_pairs_u32_i32(fal_ctx* ctx, const uint32_t* kin, uint32_t* kout, const int32_t* vin, int32_t* vout,
                        int64_t n, int end_bit, int scratch_slot) {
+    // Onesweep radix passes from 128 k keys on (rocprim's default merge sort below 1 M keys takes ~20 launches)
+    using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 131072>;
     size_t bytes = 0;
-    FAL_CHECK_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, ctx->stream));
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, ctx->stream));
     void* tmp = nullptr;
     FAL_TRY(ctx->reserve(scratch_slot, bytes, &tmp));
-    FAL_CHECK_HIP(rocprim::radix_sort_pairs(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, ctx->stream));
+    FAL_CHECK_HIP(rocprim::radix_sort_pairs<SortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, 0, end_bit, ctx->stream));
     return FAL_OK;
 }
 
