@@ -59,6 +59,8 @@ struct FusedArgs {
     int mask_words;              // 32-bit words of one query's probe mask (>= max n_list / 32)
     const int64_t* list_off;     // [total_lists + 1]
     const int32_t* perm;         // [n] list-order position -> sorted row
+    const uint16_t* sp_cols;     // [n, 64] the rows' sparse form (ivf.h), or nullptr: pairs16 then reads the dense rows
+    const float* sp_vals;
 };
 
 bool fused_supports(int d);

@@ -4,6 +4,11 @@
 #include "common.h"
 
 namespace fal {
+// the sparse form of a row (fal_ivf::sp_cols / sp_vals)
+constexpr int kSparseW = 64;                 // entries per row (one per lane)
+constexpr uint16_t kColPad = 0xFFFF;         // unused entry
+constexpr uint16_t kColDense = 0xFFFE;       // in entry 0: the row has more than kSparseW non-zeros, read the dense row
+
 // context scratch slots
 enum { SLOT_JOBS = 0, SLOT_SIMS = 1, SLOT_PROBES = 2, SLOT_PROBE_SIM = 3, SLOT_QOFF = 4, SLOT_JOBS2 = 5,
        SLOT_MISC = 6, SLOT_MISC2 = 7, SLOT_SORT = 8, SLOT_SORT2 = 9, SLOT_TAIL = 10, SLOT_TAIL2 = 11,
@@ -42,7 +47,10 @@ struct fal_ivf {
     float* centroids = nullptr;      // [total_lists, d]
     int32_t* assign = nullptr;       // [n] bucket-local list of each sorted row
     int32_t* perm = nullptr;         // [n] list-order position -> sorted row
-    void* build_tmp[2] = {nullptr, nullptr};   // the rows' sparse form during the build (released at its end)
+    // the rows of the IVF buckets in sparse form, [n, 64] each (entry = column, value; in the order of the exact similarity chains;
+    // column 0xFFFF = unused entry, 0xFFFE in entry 0 = more than 64 non-zeros, use the dense row); owned, null with the dense update
+    uint16_t* sp_cols = nullptr;
+    float* sp_vals = nullptr;
     int64_t* list_off = nullptr;     // [total_lists + 1] list-order positions
     int64_t* counts = nullptr;       // [total_lists + 1]
     void* bk_dev = nullptr;          // BucketDev[n_ivf_buckets]

@@ -157,9 +157,6 @@ __global__ __launch_bounds__(64) void list_walk_kernel(const float* __restrict__
 // over their non-zero components only -- in the same row order -- gives the same centroid bit for bit while reading 384 B per
 // member instead of 4 d.  The members of a list come from a stable sort of the rows by list (row order inside a list).
 // ------------------------------------------------------------------------------------------
-constexpr int kSparseW = 64;                 // entries per row (one per lane)
-constexpr uint16_t kColPad = 0xFFFF;         // unused entry
-constexpr uint16_t kColDense = 0xFFFE;       // in entry 0: the row has more than kSparseW non-zeros, read the dense row
 
 // rows of the IVF buckets -> (column, value) entries; blocks of 256 rows, seg_off = first block of every bucket
 __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restrict__ X, int d, const BucketDev* __restrict__ bk,
@@ -180,13 +177,19 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
         const int64_t r = b.row0 + rl;
         sc[w][lane] = kColPad;
         sv[w][lane] = 0.f;
+        // entries in the order of the exact similarity chains (column 0, d/2, 1, d/2 + 1, ...: dense.hip / pairs16.hip), so that
+        // a chain over a row's entries visits its non-zero terms in the order the dense chain does
         const float4* row = reinterpret_cast<const float4*>(X + r * d);
+        const int dh4 = d >> 3;
         int base = 0;
-        for (int e0 = 0; e0 < d / 4; e0 += 64) {
+        for (int e0 = 0; e0 < dh4; e0 += 64) {
             const int e = e0 + lane;
-            const float4 x = e < d / 4 ? row[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float xs[4] = {x.x, x.y, x.z, x.w};
-            const int c = (int)(x.x != 0.f) + (int)(x.y != 0.f) + (int)(x.z != 0.f) + (int)(x.w != 0.f);
+            const float4 lo = e < dh4 ? row[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 hi = e < dh4 ? row[dh4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xs[8] = {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lo.w, hi.w};
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c += (int)(xs[j] != 0.f);
             int pre = c;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -197,9 +200,9 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
             if (base + tot <= kSparseW) {
                 int pos = base + pre - c;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 8; ++j)
                     if (xs[j] != 0.f) {
-                        sc[w][pos] = (uint16_t)(4 * e + j);
+                        sc[w][pos] = (uint16_t)((j & 1) * (d >> 1) + 4 * e + (j >> 1));
                         sv[w][pos] = xs[j];
                         ++pos;
                     }
@@ -382,7 +385,7 @@ extern "C" {
 int fal_ivf_destroy(fal_ivf* ivf) {
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
-                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys, ivf->build_tmp[0], ivf->build_tmp[1]};
+                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -620,20 +623,17 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             B_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * tab.size(), (void**)&boff_dev));
             B_TRY(ctx->upload(boff_dev, tab.data(), sizeof(int64_t) * tab.size()));
             lbase_dev = boff_dev + n_buckets + 1;
-            if (kmeans_iters > 0) {
-                B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, &ivf->build_tmp[0]));
-                B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, &ivf->build_tmp[1]));
-                sp_cols = (uint16_t*)ivf->build_tmp[0];
-                sp_vals = (float*)ivf->build_tmp[1];
-            }
+            B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, (void**)&ivf->sp_cols));
+            B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&ivf->sp_vals));
+            sp_cols = ivf->sp_cols;
+            sp_vals = ivf->sp_vals;
             B_TRY(ctx->reserve(SLOT_SORT2, 3 * sizeof(uint32_t) * (size_t)n, &sortbuf));
             key_in = (uint32_t*)sortbuf;
             key_out = key_in + n;
             iota = (int32_t*)(key_out + n);
             StageScope ts(ctx, ST_BUILD);
-            if (kmeans_iters > 0)
-                hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
-                                   nbk, sp_cols, sp_vals);
+            hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
+                               nbk, sp_cols, sp_vals);
             B_HIP(hipGetLastError());
             hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, st, iota, n);
             B_HIP(hipGetLastError());
@@ -694,11 +694,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                                nbk, nullptr, nullptr, ivf->list_off, ivf->perm);
             B_HIP(hipGetLastError());
         } else {
-            B_TRY(sort_by_list());
-            for (void*& t : ivf->build_tmp) {          // (recycled in stream order)
-                if (t) ctx->pool_free(t);
-                t = nullptr;
-            }
+            B_TRY(sort_by_list());       // (the sparse rows stay with the index: pairs16.hip evaluates its exact chains over them)
         }
         // the float32 rows in list order are made on demand (fal_ivf_ensure_xl: the staged fine scan and the staged coarse scan read
         // them; the default path -- coarse quantiser from the build's keys, float16 prefilter -- does not: 16 GB at 10 M spectra)

@@ -238,6 +238,139 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 }
 
+// The same chains over the rows' SPARSE form (ivf.h: <= 64 (column, value) entries per row, in chain order).  A term whose
+// candidate component is zero leaves the accumulator as it is (q * 0 = +-0, and the accumulator, starting at +0.0, is never -0.0
+// unless every earlier product underflowed below 2^-150), so the chain over the candidate's entries alone gives the same bits
+// while a pair costs 384 bytes and <= 64 fmaf instead of 4 d bytes and d fmaf.  The tile's 32 query rows are expanded into LDS
+// once (from their own sparse form); a lane reads the query component of an entry from there.  The candidates' entries are
+// fetched coalesced, 16 entries of 64 pairs at a time (an instruction covers 16 pairs x 64 bytes of values / 32 pairs x 32 bytes
+// of columns), and transposed through LDS into the lanes that own the pairs.  Rows with more than 64 non-zeros (entry 0 =
+// kColDense) take the dense chain.
+__global__ __launch_bounds__(256) void pairs16s_kernel(FusedArgs a, int d) {
+    constexpr int kSlot = 112;                                   // bytes per pair and step: 16 columns + 16 values + 16
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* qs = reinterpret_cast<float*>(smem);                  // [32][d]
+    unsigned char* tbuf = smem + (size_t)32 * d * 4;             // [4][64 * kSlot]
+    int32_t* off = reinterpret_cast<int32_t*>(tbuf + 4 * 64 * kSlot);   // [33]
+    int ji, lt;
+    if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
+    const DenseJob job = a.jobs32[ji];
+    const int nqw = min(32, job.nc - 32 * lt);
+    const int64_t row_t = job.q_row0 + 32 * lt;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {
+        const int q = threadIdx.x;
+        int c = 0;
+        if (q < nqw) {
+            const int i0 = a.gkcnt[(row_t + q) * 2], i1 = a.gkcnt[(row_t + q) * 2 + 1];
+            if (((i0 | i1) & 0x200) == 0) c = (i0 & 0xFF) + (i1 & 0xFF);
+        }
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (q >= o) incl += v;
+        }
+        if (q < 32) off[q + 1] = incl;
+        if (q == 0) off[0] = 0;
+    }
+    {
+        float4* z = reinterpret_cast<float4*>(qs);
+        for (int i = threadIdx.x; i < 8 * d; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int P = off[32];
+    if (P == 0) return;
+    for (int q = w; q < nqw; q += 4) {                           // the queries with pairs, expanded
+        if (off[q + 1] == off[q]) continue;
+        const int64_t row = row_t + q;
+        const int c = a.sp_cols[row * kSparseW + lane];
+        const float v = a.sp_vals[row * kSparseW + lane];
+        if (__shfl(c, 0, 64) == (int)kColDense) {
+            for (int e = lane; e < d; e += 64) qs[q * d + e] = a.X[row * d + e];
+        } else if (c != (int)kColPad) {
+            qs[q * d + c] = v;
+        }
+    }
+    __syncthreads();
+    const int dh4 = d >> 3;
+    unsigned char* tb = tbuf + w * 64 * kSlot;
+    for (int i0 = 64 * w; i0 < P; i0 += 256) {                   // (wave-uniform: the lanes of a wave work together)
+        const int i = i0 + lane;
+        const bool live = i < P;
+        const int ic = min(i, P - 1);
+        int q = 0;
+#pragma unroll
+        for (int s = 16; s >= 1; s >>= 1) q = (q + s < 32 && off[q + s] <= ic) ? q + s : q;
+        const int j = ic - off[q];
+        const int64_t row = row_t + q;
+        const uint32_t id = a.gkept_id[row * FAL_FUSED_KEEP + j];
+        int64_t idV[4], idC[2];                                  // rows this lane FETCHES for: values (16 B of 64), columns (16 B of 32)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) idV[g] = (int64_t)(uint32_t)__shfl((int)id, 16 * g + (lane >> 2), 64) * kSparseW + 4 * (lane & 3);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) idC[g] = (int64_t)(uint32_t)__shfl((int)id, 32 * g + (lane >> 1), 64) * kSparseW + 8 * (lane & 1);
+        const float* qrow = qs + q * d;
+        float acc = 0.f;
+        bool dense = false;
+        for (int ch = 0; ch < kSparseW / 16; ++ch) {
+            float4 sv[4];
+            uint4 sc[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const float4*>(a.sp_vals + idV[g] + 16 * ch);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) sc[g] = *reinterpret_cast<const uint4*>(a.sp_cols + idC[g] + 16 * ch);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(tb + (16 * g + (lane >> 2)) * kSlot + 32 + (lane & 3) * 16) = sv[g];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) *reinterpret_cast<uint4*>(tb + (32 * g + (lane >> 1)) * kSlot + (lane & 1) * 16) = sc[g];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned char* mine = tb + lane * kSlot;
+            const uint4 c0 = *reinterpret_cast<const uint4*>(mine), c1 = *reinterpret_cast<const uint4*>(mine + 16);
+            const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            if (ch == 0 && (cw[0] & 0xFFFFu) == (uint32_t)kColDense) dense = true;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(mine + 32 + 16 * t);
+                const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t col = (cw[2 * t + (u >> 1)] >> (16 * (u & 1))) & 0xFFFFu;
+                    const bool on = col < (uint32_t)kColDense;
+                    const float qv = qrow[on ? col : 0u];
+                    const float nx = __builtin_fmaf(qv, vs[u], acc);
+                    acc = on ? nx : acc;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // entries are packed: a row whose last entry of this step is unused has none in the next
+            if (__ballot((cw[7] >> 16) < (uint32_t)kColDense) == 0ull) break;
+        }
+        if (__ballot(dense) != 0ull) {                           // (rare) rows kept dense: the dense chain
+            if (dense) {
+                const float4* cp = reinterpret_cast<const float4*>(a.X) + (int64_t)id * (2 * dh4);
+                const float4* qp = reinterpret_cast<const float4*>(qrow);
+                acc = 0.f;
+                for (int jj = 0; jj < dh4; ++jj) {
+                    const float4 cl = cp[jj], chh = cp[dh4 + jj], ql = qp[jj], qh = qp[dh4 + jj];
+                    acc = __builtin_fmaf(ql.x, cl.x, acc);
+                    acc = __builtin_fmaf(qh.x, chh.x, acc);
+                    acc = __builtin_fmaf(ql.y, cl.y, acc);
+                    acc = __builtin_fmaf(qh.y, chh.y, acc);
+                    acc = __builtin_fmaf(ql.z, cl.z, acc);
+                    acc = __builtin_fmaf(qh.z, chh.z, acc);
+                    acc = __builtin_fmaf(ql.w, cl.w, acc);
+                    acc = __builtin_fmaf(qh.w, chh.w, acc);
+                }
+            }
+        }
+        if (live) a.gkept_u[row * FAL_FUSED_KEEP + j] = max(f32_sortable(acc), 1u);
+    }
+}
+
 int launch_gather_pmz(fal_ctx* ctx, const float* pmz, const int32_t* perm, int64_t n, float* out) {
     if (n <= 0) return FAL_OK;
     StageScope ts(ctx, ST_COARSE);
@@ -263,7 +396,17 @@ int launch_kept16(fal_ctx* ctx, const Kept16Args& a_in, int64_t n_tiles) {
 int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32) {
     if (list_tiles32 <= 0) return FAL_OK;
     StageScope ts(ctx, ST_SCAN);
-    hipLaunchKernelGGL(pairs16_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
+    if (a.sp_cols != nullptr && a.sp_vals != nullptr && d <= 512) {
+        const size_t lds = (size_t)32 * d * 4 + 4 * 64 * 112 + 34 * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            FAL_CHECK_HIP(hipFuncSetAttribute((const void*)pairs16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(pairs16s_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), lds, ctx->stream, a, d);
+    } else {
+        hipLaunchKernelGGL(pairs16_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
+    }
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

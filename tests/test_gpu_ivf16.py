@@ -5,7 +5,7 @@ test_gpu_regimes.py pin to the oracle."""
 import numpy as np
 import pytest
 
-from tests.test_gpu_search import unit_vectors
+from tests.test_gpu_search import sparse_unit_vectors, unit_vectors
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,24 @@ def test_ivf_prefilter_neighbours_bit_identical_to_the_staged_path(ctx, d, n_pro
                                           tol, mode, rt_tol)
     assert (e_idx >= 0).sum() > off[-1] // 8
     assert n_fb < 0.05 * off[-1], n_fb                        # the prefiltered path did the work, not the fallback
+
+
+@pytest.mark.parametrize("d,n_probe,k_ann,keep,tol,mode,rt_tol", [
+    (400, 16, 128, 64, 20.0, "ppm", None), (400, 8, 32, 8, 0.05, "Da", 30.0), (128, 16, 64, 16, 20.0, "ppm", None),
+    (64, 4, 32, 16, 60.0, "ppm", None),
+])
+def test_ivf_prefilter_on_sparse_rows_bit_identical_to_the_staged_path(ctx, d, n_probe, k_ann, keep, tol, mode, rt_tol):
+    """rows shaped like vectorised spectra (a few dozen non-zero components): the exact chains of the kept pairs run over the
+    rows' sparse form (pairs16s_kernel) -- plus rows with exactly 64 / more than 64 non-zeros (dense chain), negative components
+    and all-zero rows; the staged path computes every similarity densely on the fp32 matrix cores"""
+    sizes = [6000, 300, 2500, 9000, 40, 1300]
+    nl = np.array([64, 1, 32, 128, 1, 16], np.int32)
+    off, _, mz, rt = _buckets(sizes, d, 33)
+    X = sparse_unit_vectors(int(off[-1]), d, 35, nnz_hi=min(50, d // 2))
+    X[off[3] + 10:off[3] + 16] = X[off[3] + 10]
+    e_idx, n_fb = _staged_and_prefiltered(ctx, X, off, nl, mz, rt if rt_tol is not None else None, n_probe, k_ann, keep,
+                                          tol, mode, rt_tol)
+    assert (e_idx >= 0).sum() > off[-1] // 8
 
 
 def test_ivf_prefilter_handles_ties_zero_rows_and_few_candidates(ctx):
