@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // fetched coalesced, 16 entries of 64 pairs at a time (an instruction covers 16 pairs x 64 bytes of values / 32 pairs x 32 bytes
 // of columns), and transposed through LDS into the lanes that own the pairs.  Rows with more than 64 non-zeros (entry 0 =
 // kColDense) take the dense chain.
-__global__ __launch_bounds__(256) void pairs16s_kernel(FusedArgs a, int d) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pairs16s_kernel(FusedArgs a, int d) {
     constexpr int kSlot = 112;                                   // bytes per pair and step: 16 columns + 16 values + 16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* qs = reinterpret_cast<float*>(smem);                  // [32][d]
@@ -274,6 +274,15 @@ __global__ __launch_bounds__(256) void pairs16s_kernel(FusedArgs a, int d) {
         if (q < 32) off[q + 1] = incl;
         if (q == 0) off[0] = 0;
     }
+    // the sparse rows of this wave's queries: all loads in flight before the accumulator rows are cleared
+    int qc[8];
+    float qv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int64_t row = row_t + min(w + 4 * t, nqw - 1);
+        qc[t] = a.sp_cols[row * kSparseW + lane];
+        qv[t] = a.sp_vals[row * kSparseW + lane];
+    }
     {
         float4* z = reinterpret_cast<float4*>(qs);
         for (int i = threadIdx.x; i < 8 * d; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -281,15 +290,16 @@ __global__ __launch_bounds__(256) void pairs16s_kernel(FusedArgs a, int d) {
     __syncthreads();
     const int P = off[32];
     if (P == 0) return;
-    for (int q = w; q < nqw; q += 4) {                           // the queries with pairs, expanded
-        if (off[q + 1] == off[q]) continue;
-        const int64_t row = row_t + q;
-        const int c = a.sp_cols[row * kSparseW + lane];
-        const float v = a.sp_vals[row * kSparseW + lane];
-        if (__shfl(c, 0, 64) == (int)kColDense) {
-            for (int e = lane; e < d; e += 64) qs[q * d + e] = a.X[row * d + e];
-        } else if (c != (int)kColPad) {
-            qs[q * d + c] = v;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = w + 4 * t;
+        if (q < nqw) {
+            if (__shfl(qc[t], 0, 64) == (int)kColDense) {
+                const int64_t row = row_t + q;
+                for (int e = lane; e < d; e += 64) qs[q * d + e] = a.X[row * d + e];
+            } else if (qc[t] != (int)kColPad) {
+                qs[q * d + qc[t]] = qv[t];
+            }
         }
     }
     __syncthreads();
@@ -313,42 +323,56 @@ __global__ __launch_bounds__(256) void pairs16s_kernel(FusedArgs a, int d) {
         const float* qrow = qs + q * d;
         float acc = 0.f;
         bool dense = false;
-        for (int ch = 0; ch < kSparseW / 16; ++ch) {
-            float4 sv[4];
-            uint4 sc[2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) sv[g] = *reinterpret_cast<const float4*>(a.sp_vals + idV[g] + 16 * ch);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) sc[g] = *reinterpret_cast<const uint4*>(a.sp_cols + idC[g] + 16 * ch);
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(tb + (16 * g + (lane >> 2)) * kSlot + 32 + (lane & 3) * 16) = sv[g];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) *reinterpret_cast<uint4*>(tb + (32 * g + (lane >> 1)) * kSlot + (lane & 1) * 16) = sc[g];
+        // every entry of the 64 candidates in flight at once (four steps of 16 entries)
+#define FAL_LD_V(g, c) (*reinterpret_cast<const float4*>(a.sp_vals + idV[g] + 16 * (c)))
+#define FAL_LD_C(g, c) (*reinterpret_cast<const uint4*>(a.sp_cols + idC[g] + 16 * (c)))
+        const float4 a00 = FAL_LD_V(0, 0), a01 = FAL_LD_V(1, 0), a02 = FAL_LD_V(2, 0), a03 = FAL_LD_V(3, 0);
+        const uint4 b00 = FAL_LD_C(0, 0), b01 = FAL_LD_C(1, 0);
+        const float4 a10 = FAL_LD_V(0, 1), a11 = FAL_LD_V(1, 1), a12 = FAL_LD_V(2, 1), a13 = FAL_LD_V(3, 1);
+        const uint4 b10 = FAL_LD_C(0, 1), b11 = FAL_LD_C(1, 1);
+        const float4 a20 = FAL_LD_V(0, 2), a21 = FAL_LD_V(1, 2), a22 = FAL_LD_V(2, 2), a23 = FAL_LD_V(3, 2);
+        const uint4 b20 = FAL_LD_C(0, 2), b21 = FAL_LD_C(1, 2);
+        const float4 a30 = FAL_LD_V(0, 3), a31 = FAL_LD_V(1, 3), a32 = FAL_LD_V(2, 3), a33 = FAL_LD_V(3, 3);
+        const uint4 b30 = FAL_LD_C(0, 3), b31 = FAL_LD_C(1, 3);
+#undef FAL_LD_V
+#undef FAL_LD_C
+        bool more = true;                                        // (wave-uniform) some row has entries in this step
+        unsigned char* wv = tb + (lane >> 2) * kSlot + 32 + (lane & 3) * 16;      // this lane's piece of pair (lane >> 2) + 16 g
+        unsigned char* wc = tb + (lane >> 1) * kSlot + (lane & 1) * 16;           // ... of pair (lane >> 1) + 32 g
+        auto step = [&](float4 s0, float4 s1, float4 s2, float4 s3, uint4 t0, uint4 t1, bool first) {
+            if (!more) return;
+            *reinterpret_cast<float4*>(wv) = s0;
+            *reinterpret_cast<float4*>(wv + 16 * kSlot) = s1;
+            *reinterpret_cast<float4*>(wv + 32 * kSlot) = s2;
+            *reinterpret_cast<float4*>(wv + 48 * kSlot) = s3;
+            *reinterpret_cast<uint4*>(wc) = t0;
+            *reinterpret_cast<uint4*>(wc + 32 * kSlot) = t1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const unsigned char* mine = tb + lane * kSlot;
             const uint4 c0 = *reinterpret_cast<const uint4*>(mine), c1 = *reinterpret_cast<const uint4*>(mine + 16);
-            const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            if (ch == 0 && (cw[0] & 0xFFFFu) == (uint32_t)kColDense) dense = true;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(mine + 32 + 16 * t);
-                const float vs[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t col = (cw[2 * t + (u >> 1)] >> (16 * (u & 1))) & 0xFFFFu;
-                    const bool on = col < (uint32_t)kColDense;
-                    const float qv = qrow[on ? col : 0u];
-                    const float nx = __builtin_fmaf(qv, vs[u], acc);
-                    acc = on ? nx : acc;
-                }
-            }
+            const float4 v0 = *reinterpret_cast<const float4*>(mine + 32), v1 = *reinterpret_cast<const float4*>(mine + 48);
+            const float4 v2 = *reinterpret_cast<const float4*>(mine + 64), v3 = *reinterpret_cast<const float4*>(mine + 80);
+            if (first && (c0.x & 0xFFFFu) == (uint32_t)kColDense) dense = true;
+            auto term = [&](uint32_t col, float val) {
+                const bool on = col < (uint32_t)kColDense;
+                const float qv = qrow[on ? col : 0u];
+                const float nx = __builtin_fmaf(qv, val, acc);
+                acc = on ? nx : acc;
+            };
+            term(c0.x & 0xFFFFu, v0.x); term(c0.x >> 16, v0.y); term(c0.y & 0xFFFFu, v0.z); term(c0.y >> 16, v0.w);
+            term(c0.z & 0xFFFFu, v1.x); term(c0.z >> 16, v1.y); term(c0.w & 0xFFFFu, v1.z); term(c0.w >> 16, v1.w);
+            term(c1.x & 0xFFFFu, v2.x); term(c1.x >> 16, v2.y); term(c1.y & 0xFFFFu, v2.z); term(c1.y >> 16, v2.w);
+            term(c1.z & 0xFFFFu, v3.x); term(c1.z >> 16, v3.y); term(c1.w & 0xFFFFu, v3.z); term(c1.w >> 16, v3.w);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             // entries are packed: a row whose last entry of this step is unused has none in the next
-            if (__ballot((cw[7] >> 16) < (uint32_t)kColDense) == 0ull) break;
-        }
+            more = __ballot((c1.w >> 16) < (uint32_t)kColDense) != 0ull;
+        };
+        step(a00, a01, a02, a03, b00, b01, true);
+        step(a10, a11, a12, a13, b10, b11, false);
+        step(a20, a21, a22, a23, b20, b21, false);
+        step(a30, a31, a32, a33, b30, b31, false);
         if (__ballot(dense) != 0ull) {                           // (rare) rows kept dense: the dense chain
             if (dense) {
                 const float4* cp = reinterpret_cast<const float4*>(a.X) + (int64_t)id * (2 * dh4);
