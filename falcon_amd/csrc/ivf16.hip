@@ -222,38 +222,73 @@ __device__ __forceinline__ int wcount(bool p) { return __popcll(__ballot(p)); }
 //     kernel is bound by the latency of its dependent loads)
 template <int R>
 __device__ __forceinline__ void select16_body(const Select16Args& a, const uint16_t* __restrict__ row, int nc, int k, int lane,
-                                              int64_t out_row) {
+                                              int64_t out_row, uint32_t* hist) {
+    // Keys in 16-byte pieces (8 per load instruction and lane; a 2-byte load per key made the kernel wait for its R load
+    // instructions): the stream is read from the 16-byte boundary in front of it, `lead` keys early; key t of piece (j, lane) is
+    // stream position 8 (64 j + lane) + t - lead.
     uint32_t u[R];
+    const int lead = (int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1);
+    auto pos_of = [&](int i) -> int { return 8 * (64 * (i >> 3) + lane) + (i & 7) - lead; };
     {
-        const uint16_t* rl = row + lane;
-        uint16_t raw[R];
+        const uint4* base = reinterpret_cast<const uint4*>(reinterpret_cast<uintptr_t>(row) & ~(uintptr_t)15);
+        uint4 raw[R / 8];
 #pragma unroll
-        for (int i = 0; i < R; ++i) raw[i] = rl[i * 64];           // unclamped: the buffer has kSimsSlack floats of slack
+        for (int j = 0; j < R / 8; ++j) raw[j] = base[64 * j + lane];       // unclamped: the buffer has kSimsSlack floats of slack
 #pragma unroll
-        for (int i = 0; i < R; ++i) u[i] = (i * 64 + lane < nc) ? (uint32_t)raw[i] + 1u : 0u;
-    }
-    // largest T with count(u >= T) >= k; on an early exit (a threshold that splits off exactly k keys) the k-th largest
-    // key itself is the smallest key >= T
-    uint32_t T = 0;
-    bool early = false;
-    for (int bit = 16; bit >= 0; --bit) {
-        const uint32_t c = T | (1u << bit);
-        int cnt = 0;
+        for (int j = 0; j < R / 8; ++j) {
+            const uint32_t wv[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
 #pragma unroll
-        for (int i = 0; i < R; ++i) cnt += wcount(u[i] >= c);
-        if (cnt >= k) T = c;
-        if (cnt == k) {
-            early = true;
-            break;
+            for (int t = 0; t < 8; ++t) {
+                const int pos = pos_of(8 * j + t);
+                u[8 * j + t] = (pos >= 0 && pos < nc) ? ((wv[t >> 1] >> (16 * (t & 1))) & 0xFFFFu) + 1u : 0u;
+            }
         }
     }
-    if (early) {
-        uint32_t m = 0xFFFFFFFFu;
+    // T = the k-th largest key (nc > k, so T >= 1).  Two histogram levels in LDS -- 256 bins of the key's high byte, then the
+    // low byte inside the bin that holds the k-th key -- instead of a bitwise search with R ballot counts per bit (17 x R
+    // compare + count + add against 2 x R LDS atomics and two suffix sums over the lanes).
+    uint32_t T;
+    {
+        auto level = [&](auto bin_of_key, int kk, int* above) -> int {        // -> bin of the kk-th largest, *above = keys in higher bins
+            hist[lane] = 0u; hist[lane + 64] = 0u; hist[lane + 128] = 0u; hist[lane + 192] = 0u; hist[lane + 256] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < R; ++i) m = min(m, u[i] >= T ? u[i] : 0xFFFFFFFFu);
+            for (int i = 0; i < R; ++i) {
+                const int b = bin_of_key(u[i]);
+                if (b >= 0) __hip_atomic_fetch_add(&hist[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t c[5];                                                    // bins 5 lane .. 5 lane + 4
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, 64));
-        T = m;
+            for (int j = 0; j < 5; ++j) c[j] = hist[5 * lane + j];
+            const int own = (int)(c[0] + c[1] + c[2] + c[3] + c[4]);
+            int suf = own;                                                    // keys in this lane's bins and all higher ones
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(suf, off, 64);
+                if (lane + off < 64) suf += o;
+            }
+            const unsigned long long reach = __ballot(suf >= kk);             // (a prefix of the lanes: suf falls with the lane)
+            const int L = 63 - __clzll(reach);
+            int acc = suf - own, bin = 5 * lane;
+#pragma unroll
+            for (int j = 4; j >= 0; --j) {
+                if (acc + (int)c[j] >= kk) { bin = 5 * lane + j; break; }
+                acc += (int)c[j];
+            }
+            *above = __shfl(acc, L, 64);
+            const int res = __shfl(bin, L, 64);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            return res;
+        };
+        int above1 = 0, above2 = 0;
+        const int b1 = level([&](uint32_t key) -> int { return key ? (int)min(key >> 8, 255u) : -1; }, k, &above1);
+        const int b2 = level([&](uint32_t key) -> int { return (key && (int)min(key >> 8, 255u) == b1) ? (int)key - (b1 << 8) : -1; },
+                             k - above1, &above2);
+        T = (uint32_t)((b1 << 8) + b2);
     }
     const float Tv = (float)(T - 1u) * (1.f / 65535.f);
     const float e = 1.3e-3f * Tv + 1.2e-5f;
@@ -296,7 +331,7 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
             if (in) {
                 const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
                 gv[slot] = (float)(u[i] - 1u) * (1.f / 65535.f);
-                gi[slot] = (uint32_t)(i * 64 + lane);            // stream position (resolve_kernel: -> row)
+                gi[slot] = (uint32_t)pos_of(i);                  // stream position (resolve_kernel: -> row)
             }
             base += __popcll(mask);
         }
@@ -321,7 +356,9 @@ __device__ __forceinline__ void select16_trivial(const Select16Args& a, int64_t 
 // the common n_probe = 16 case at its register count
 template <bool BIG, bool WIDE>
 __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
+    __shared__ uint32_t hist_all[4][320];                        // a wave's key histogram (select16_body)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* hist = hist_all[w];
     const int n_big = BIG ? min(*a.big_count, a.big_cap) : 0;
     for (int64_t item = (int64_t)blockIdx.x * 4 + w;; item += (int64_t)gridDim.x * 4) {
         int64_t slot;
@@ -341,19 +378,20 @@ __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
             const int64_t out_row = a.perm[p];
             const uint16_t* row = a.keys + (o0 - a.keys_base);
             const int k = a.k;
+            const int span = nc + (int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1);      // keys from the 16-byte boundary in front
             if (nc <= k) select16_trivial(a, out_row, 0, lane);  // every candidate is among the k best
             else if (!BIG) {
-                if (nc <= 512) select16_body<8>(a, row, nc, k, lane, out_row);
-                else if (nc <= 1024) select16_body<16>(a, row, nc, k, lane, out_row);
-                else if (nc <= 1536) select16_body<24>(a, row, nc, k, lane, out_row);
-                else if (nc <= 2048) select16_body<32>(a, row, nc, k, lane, out_row);
-                else if (WIDE && nc <= 2560) select16_body<40>(a, row, nc, k, lane, out_row);
+                if (span <= 512) select16_body<8>(a, row, nc, k, lane, out_row, hist);
+                else if (span <= 1024) select16_body<16>(a, row, nc, k, lane, out_row, hist);
+                else if (span <= 1536) select16_body<24>(a, row, nc, k, lane, out_row, hist);
+                else if (span <= 2048) select16_body<32>(a, row, nc, k, lane, out_row, hist);
+                else if (WIDE && span <= 2560) select16_body<40>(a, row, nc, k, lane, out_row, hist);
                 else if (lane == 0) {
                     const int at = atomicAdd(a.big_count, 1);
                     if (at < a.big_cap) a.big_list[at] = (int32_t)slot;
                 }
             } else {
-                if (nc <= 4096) select16_body<64>(a, row, nc, k, lane, out_row);
+                if (span <= 4096) select16_body<64>(a, row, nc, k, lane, out_row, hist);
                 else select16_trivial(a, out_row, 2, lane);      // more keys than the registers hold: exact fallback
             }
         }
