@@ -63,28 +63,71 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
 
     uint32_t T = 1, I = 0xFFFFFFFFu;
     if (m > k) {
-        // largest T with count(key >= T) >= k
-        T = 0;
-        bool exact = false;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t c = T | (1u << bit);
-            int cnt = 0;
+        // T = the k-th largest key, by radix levels over LDS histograms (sel_u is free until the compaction below): the
+        // bits all keys share are skipped, then 8 bits per level -- R LDS atomics and one suffix sum over the lanes per
+        // level instead of R ballot counts per BIT.  A level whose bin holds exactly the keys still wanted ends the
+        // search: T = the prefix so far is then a threshold with exactly k keys at or above it.
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
-            for (int i = 0; i < R; ++i) cnt += wave_count(u[i] >= c);
-            if (cnt >= k) T = c;
-            if (cnt == k) {
-                exact = true;
-                break;
-            }
+        for (int i = 0; i < R; ++i) {
+            mn = min(mn, u[i] ? u[i] : 0xFFFFFFFFu);
+            mx = max(mx, u[i]);
         }
-        if (!exact) {
-            int gt = 0, eq = 0;
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                gt += wave_count(u[i] > T);
-                eq += wave_count(u[i] == T);
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        }
+        int shift = 32 - __clz((int)(mn ^ mx));                 // low bits in which the keys differ (0: all keys equal)
+        if (mn == mx) shift = 0;
+        uint32_t prefix = shift >= 32 ? 0u : (mx >> shift) << shift;
+        int kk = k, eq = m;                                     // keys still wanted at or below the prefix; keys equal to T
+        bool exact = false;
+        uint32_t* hist = sel_u;
+        while (shift > 0 && !exact) {
+            const int wbits = min(8, shift);
+            const int hi = shift;                               // bits [hi, 32) are fixed by the prefix
+            shift -= wbits;
+            const uint32_t dmask = (1u << wbits) - 1u;
+            const uint32_t himask = hi >= 32 ? 0u : ~0u << hi;
+            *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                if (u[i] != 0u && (u[i] & himask) == prefix)
+                    __hip_atomic_fetch_add(&hist[(u[i] >> shift) & dmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const uint4 cv = *reinterpret_cast<const uint4*>(hist + 4 * lane);      // bins 4 lane .. 4 lane + 3
+            const int c[4] = {(int)cv.x, (int)cv.y, (int)cv.z, (int)cv.w};
+            const int own = c[0] + c[1] + c[2] + c[3];
+            int suf = own;                                      // keys in this lane's bins and in all higher ones
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(suf, off, 64);
+                if (lane + off < 64) suf += o;
             }
-            const int need = k - gt;
+            const int L = 63 - __clzll((unsigned long long)__ballot(suf >= kk));    // the lane whose bins hold the kk-th largest
+            int acc = suf - own, bin = 4 * lane, cj = c[0];
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                if (acc + c[j] >= kk) { bin = 4 * lane + j; cj = c[j]; break; }
+                acc += c[j];
+            }
+            acc = __shfl(acc, L, 64);
+            bin = __shfl(bin, L, 64);
+            cj = __shfl(cj, L, 64);
+            kk -= acc;
+            prefix |= (uint32_t)bin << shift;
+            exact = cj == kk;
+            eq = cj;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        T = prefix;
+        if (!exact) {
+            const int need = kk;                                // keys equal to T that are still wanted (ties: lowest ids)
             if (eq > need) {
                 uint32_t lo = 0;      // largest value with count(key == T && id < lo) < need
                 for (int bit = 31; bit >= 0; --bit) {
