@@ -279,15 +279,26 @@ __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) T = min(T, (uint32_t)__shfl_xor((int)T, off, 64));
             int cnt = carry;
+            static_assert(RS == 4, "the 16-byte chunk load holds four keys per lane");
+            const bool wide = ((reinterpret_cast<uintptr_t>(qy.row) + 4 * (uintptr_t)fresh) & 15) == 0;      // (wave-uniform)
             for (int64_t pos = fresh; pos < qy.nc; pos += 64 * RS) {
                 const int nf = (int)min<int64_t>(qy.nc - pos, 64 * RS);
-                const float* rl = qy.row + pos + lane;
+                // a 16-byte load per lane where the row allows it (one load instruction per chunk instead of four: the long rows
+                // of the exhaustive float16 configuration spend their time here); key i of a lane is then chunk position
+                // 4 lane + i instead of 64 i + lane
                 float fv[RS];
+                if (wide) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(qy.row + pos + 4 * lane);
+                    fv[0] = v4.x; fv[1] = v4.y; fv[2] = v4.z; fv[3] = v4.w;
+                } else {
+                    const float* rl = qy.row + pos + lane;
 #pragma unroll
-                for (int i = 0; i < RS; ++i) fv[i] = rl[i * 64];
+                    for (int i = 0; i < RS; ++i) fv[i] = rl[i * 64];
+                }
 #pragma unroll
                 for (int i = 0; i < RS; ++i) {
-                    const uint32_t u = (i * 64 + lane < nf) ? max(f32_sortable(fv[i]), 1u) : 0u;
+                    const int cp = wide ? 4 * lane + i : i * 64 + lane;      // position inside the chunk
+                    const uint32_t u = (cp < nf) ? max(f32_sortable(fv[i]), 1u) : 0u;
                     // MODE_DENSE: ids grow with the position, an equal key further on loses the tie.  MODE_IVF: ids are
                     // arbitrary, equal keys stay in the race until ids are resolved.
                     const bool in = MODE == MODE_DENSE ? u > T : u >= T;
@@ -296,8 +307,8 @@ __device__ __forceinline__ int select_rounds(const SelectArgs& a, const SelQuery
                         if (in) {
                             const int wpos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
                             sel_u[wpos] = u;
-                            sel_id[wpos] = MODE == MODE_DENSE ? (uint32_t)(qy.id0 + pos + i * 64 + lane)
-                                                              : (0x80000000u | (uint32_t)(pos + i * 64 + lane));
+                            sel_id[wpos] = MODE == MODE_DENSE ? (uint32_t)(qy.id0 + pos + cp)
+                                                              : (0x80000000u | (uint32_t)(pos + cp));
                         }
                         cnt += __popcll(mask);
                     }
