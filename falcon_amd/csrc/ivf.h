@@ -52,6 +52,6 @@ struct fal_ivf {
     uint16_t* sp_cols = nullptr;
     float* sp_vals = nullptr;
     int64_t* list_off = nullptr;     // [total_lists + 1] list-order positions
-    int64_t* counts = nullptr;       // [total_lists + 1]
+    int64_t* counts = nullptr;       // [total_lists + 1] list sizes (flat buckets; IVF lists only with the dense k-means update)
     void* bk_dev = nullptr;          // BucketDev[n_ivf_buckets]
 };

@@ -54,7 +54,8 @@ __device__ __forceinline__ double wave_xor_sum_d(double v) {
     return v;
 }
 
-// update: one wave per (bucket, list).  The wave walks the bucket's assignment array in row
+// The DENSE form of the k-means update (FALCON_KMEANS_DENSE_UPDATE; the default is centroid_update_kernel below, over the rows'
+// sparse form): one wave per (bucket, list).  The wave walks the bucket's assignment array in row
 // order, 64 rows per step; members are found with a ballot and added one by one IN ROW ORDER
 // (float32), so the sum does not depend on scheduling.  Then spherical normalisation with the
 // same fixed-order float64 tree as the vectorise kernel.  Empty lists keep their centroid.
