@@ -55,6 +55,45 @@ __global__ __launch_bounds__(kScanBlock) void scan_apply_kernel(const T* __restr
     if (i < n) out[i] = pre + x - v;
 }
 
+// the same with the scan of the block sums folded in: a block adds up the sums of the blocks in front of it itself (a few
+// thousand L2-resident values), the last block writes the total -- two launches per scan instead of three and a copy
+template <class T>
+__global__ __launch_bounds__(kScanBlock) void scan_apply_fused_kernel(const T* __restrict__ in, int64_t n,
+                                                                      const int64_t* __restrict__ block_sums,
+                                                                      int64_t* __restrict__ out) {
+    __shared__ int64_t ws[kScanBlock / 64];
+    __shared__ int64_t front_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t part = 0;
+    for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += kScanBlock) part += block_sums[j];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (lane == 0) ws[w] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t f = 0;
+        for (int j = 0; j < kScanBlock / 64; ++j) f += ws[j];
+        front_s = f;
+    }
+    __syncthreads();
+    const int64_t front = front_s;
+    __syncthreads();
+    const int64_t i = blockIdx.x * (int64_t)kScanBlock + threadIdx.x;
+    const int64_t v = i < n ? in[i] : 0;
+    int64_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) ws[w] = x;
+    __syncthreads();
+    int64_t pre = front;
+    for (int j = 0; j < w; ++j) pre += ws[j];
+    if (i < n) out[i] = pre + x - v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanBlock - 1) out[n] = pre + x;      // the total
+}
+
 // out[0..n) exclusive prefix of in[0..n) ; out[n] = total.  tmp: ceil(n/1024)+1 int64 (x2).
 template <class T>
 static int device_scan_t(fal_ctx* ctx, const T* in, int64_t n, int64_t* out, int scratch_slot) {
@@ -68,6 +107,11 @@ static int device_scan_t(fal_ctx* ctx, const T* in, int64_t n, int64_t* out, int
     int64_t* sums = tmp;
     int64_t* offs = tmp + nb + 1;
     hipLaunchKernelGGL(scan_block_sums_kernel<T>, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, sums);
+    if (nb <= 4096) {
+        hipLaunchKernelGGL(scan_apply_fused_kernel<T>, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, sums, out);
+        FAL_CHECK_HIP(hipGetLastError());
+        return FAL_OK;
+    }
     FAL_TRY(launch_exclusive_scan(ctx, sums, nb, offs));
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3((unsigned)nb), dim3(kScanBlock), 0, ctx->stream, in, n, offs, out);
     // total
