@@ -92,28 +92,30 @@ __global__ __launch_bounds__(256) void kept16_kernel(Kept16Args a) {
         }
         const int seg = run + incl - len;                        // where this list's keys start in the query's stream
         run += __shfl(incl, 15, 16);
-        // first position with pmz >= lob / first with pmz > hib
+        // first position with pmz >= lob
         int64_t lo = b, hi = e;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
             if (a.pmz_l[mid] < lob) lo = mid + 1; else hi = mid;
         }
         const int64_t wa = lo;
-        hi = e;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (a.pmz_l[mid] <= hib) lo = mid + 1; else hi = mid;
-        }
-        const int64_t wb = lo;
-        // walk the range; the lanes of the group append their survivors together (ballot ranks)
+        // walk the window from there; it ends at the first row above hib (the rows of a list are in precursor order, and the
+        // walk reads their precursor anyway: no second search).  The lanes of the group append their survivors together
+        // (ballot ranks)
+        bool past = false;
         for (int64_t c = wa;; ++c) {
-            const bool in = c < wb;
+            bool in = !past && c < e;
+            float nmz = 0.f;
+            if (in) {
+                nmz = a.pmz_l[c];
+                in = nmz <= hib;
+                past = !in;
+            }
             if (((uint32_t)(__ballot(in) >> sh) & 0xFFFFu) == 0u) break;
             bool ok = in && c != p;
             int u = 0;
             if (ok) {
                 u = (int)krow[seg + (c - b)] + 1;
-                const float nmz = a.pmz_l[c];
                 const float diff = qmz - nmz;                    // mass_diff(query, neighbour): the arithmetic of filter_kernel
                 const float xx = a.is_da ? diff : diff / nmz;
                 ok = u >= sel.x && fabsf(xx) <= tol_f;
