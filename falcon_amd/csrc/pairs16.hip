@@ -99,32 +99,50 @@ __global__ __launch_bounds__(256) void kept16_kernel(Kept16Args a) {
             if (a.pmz_l[mid] < lob) lo = mid + 1; else hi = mid;
         }
         const int64_t wa = lo;
-        // walk the window from there; it ends at the first row above hib (the rows of a list are in precursor order, and the
-        // walk reads their precursor anyway: no second search).  The lanes of the group append their survivors together
-        // (ballot ranks)
-        bool past = false;
-        for (int64_t c = wa;; ++c) {
-            bool in = !past && c < e;
-            float nmz = 0.f;
-            if (in) {
-                nmz = a.pmz_l[c];
-                in = nmz <= hib;
-                past = !in;
+        hi = e;
+        while (lo < hi) {                                        // first position above the window
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.pmz_l[mid] <= hib) lo = mid + 1; else hi = mid;
+        }
+        // The window rows of the group's 16 lists, FLATTENED over its lanes: a lane per row, 16 rows per step (a lane per LIST
+        // walked max-window-length steps with a third of the lanes busy -- the walk was two thirds of this kernel).  Row t of
+        // the group belongs to the list whose exclusive prefix of window lengths is the last one <= t.
+        const int wlen = (int)(lo - wa);
+        int wincl = wlen;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int o = __shfl_up(wincl, off, 16);
+            if (sub >= off) wincl += o;
+        }
+        const int wtotal = __shfl(wincl, 15, 16);
+        const int wexcl = wincl - wlen;
+        const int wa_lo = (int)(uint32_t)wa, wa_hi = (int)(wa >> 32);
+        const int rel = (int)(wa - b) + seg;                     // key-stream position of the window's first row
+        for (int t0 = 0; t0 < wtotal; t0 += 16) {                // (uniform inside the group; groups of a wave may differ)
+            const int t = t0 + sub;
+            int L = 0;
+#pragma unroll
+            for (int s = 8; s >= 1; s >>= 1) {
+                const int cand = L + s;
+                const int ex = __shfl(wexcl, min(cand, 15), 16);
+                L = (cand < 16 && ex <= t) ? cand : L;
             }
-            if (((uint32_t)(__ballot(in) >> sh) & 0xFFFFu) == 0u) break;
+            const int o = t - __shfl(wexcl, L, 16);             // offset inside list L's window
+            const int64_t c = (((int64_t)__shfl(wa_hi, L, 16) << 32) | (uint32_t)__shfl(wa_lo, L, 16)) + o;
+            const int kpos = __shfl(rel, L, 16) + o;
+            const bool in = t < wtotal;
             bool ok = in && c != p;
             int u = 0;
-            if (ok) {
-                u = (int)krow[seg + (c - b)] + 1;
+            uint32_t id = 0;
+            if (ok) {                                            // precursor, key and row: three loads in flight
+                const float nmz = a.pmz_l[c];
+                u = (int)krow[kpos] + 1;
+                id = (uint32_t)a.perm[c];
                 const float diff = qmz - nmz;                    // mass_diff(query, neighbour): the arithmetic of filter_kernel
                 const float xx = a.is_da ? diff : diff / nmz;
                 ok = u >= sel.x && fabsf(xx) <= tol_f;
             }
-            uint32_t id = 0;
-            if (ok) {
-                id = (uint32_t)a.perm[c];
-                if (use_rt) ok = fabsf(qrt - a.rt[id]) <= rt_f;
-            }
+            if (ok && use_rt) ok = fabsf(qrt - a.rt[id]) <= rt_f;
             amb = amb || (ok && u <= sel.y);
             const uint32_t gm = (uint32_t)(__ballot(ok) >> sh) & 0xFFFFu;
             if (ok) {
