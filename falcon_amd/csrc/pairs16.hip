@@ -4,7 +4,7 @@
 // BASELINE configs[2]'s bucket density, 870 at configs[3]'s) although a query keeps ~5 of them: the cost grows with the
 // window, the need does not.  Here:
 //   kept16_kernel   16 lanes per query, one per probed list.  Inside a list the rows keep their precursor order, so the part of
-//      a probed list inside the query's precursor window is a contiguous range of list positions (a binary search on the
+//      a probed list inside the query's precursor window is a contiguous range of list positions (two binary searches on the
 //      precursor m/z in list order) and its keys are contiguous in the query's key stream.  A row stays if its key is not
 //      certainly below the k-th best (select16_kernel left that threshold) and the exact tolerance tests pass;
 //   pairs16_kernel   the exact similarity of every kept pair by the k-ordered fmaf chain (bit-identical to the matrix-core
@@ -32,7 +32,7 @@ __global__ void gather_pmz_kernel(const float* __restrict__ pmz, const int32_t* 
 
 // 16 lanes per query, one lane per probed list (two rounds for 32 probes ...).  Inside a list the rows are sorted by
 // precursor m/z, so the part of the list inside the query's (slightly widened) precursor window is a contiguous range of list
-// positions -- a binary search for its start, the walk stops at the first row above it -- and its keys are contiguous in the query's key stream.  A row stays if its key is not
+// positions -- two binary searches -- and its keys are contiguous in the query's key stream.  A row stays if its key is not
 // certainly below the k-th best (select16_kernel left that threshold) and the exact tolerance tests pass.
 __global__ __launch_bounds__(256) void kept16_kernel(Kept16Args a) {
     const int tid = threadIdx.x, sub = tid & 15, lane = tid & 63, sh = 16 * (lane >> 4);
