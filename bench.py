@@ -231,41 +231,16 @@ def main():
                     lasts.append(dict(pipe.last))
                 if collect is not None:
                     collect.append(collect_stages(int(outs[-1][0].numel())))
-        labels_all, current = [], 0
-        for labels, medoids in outs:
-            labels_all.append(labels + current)                  # falcon.py:189-193
-            current += int(medoids.numel())
-        labels = torch.cat(labels_all)
         if not exchanging or collect is not None:
-            return labels.cpu()
+            labels_all, current = [], 0
+            for labels, medoids in outs:
+                labels_all.append(labels + current)                  # falcon.py:189-193
+                current += int(medoids.numel())
+            return torch.cat(labels_all).cpu()
         # ---- the one exchange step: all-gatherv of the sparse neighbour lists (CSR, ids -> dataset
         # rows of the job) + labels + dataset rows; asynchronous: it travels while the next step computes
-        rows_local = sum(int(o[0].numel()) for o in outs)
-        if shard is not None:
-            rows_g = torch.cat([last["rows"].to(torch.int32) + int(part_off[j]) for j, last in enumerate(lasts)])
-        else:
-            rows_g = None
-        if args.exchange == "neighbors":
-            if csr_buf.get("rows", -1) < rows_local:
-                cap = max(rows_local, 1) * args.n_neighbors
-                csr_buf["buf"] = (torch.empty(rows_local + 1, dtype=torch.int64, device=dev),
-                                  torch.empty(cap, dtype=torch.int32, device=dev),
-                                  torch.empty(cap, dtype=torch.float32, device=dev))
-                csr_buf["rows"] = rows_local
-            row0 = 0
-            csr = (csr_buf["buf"][0][:rows_local + 1], csr_buf["buf"][1], csr_buf["buf"][2])
-            if rows_local == 0:
-                csr[0].zero_()
-            for j, last in enumerate(lasts):                     # charge partitions chain into one CSR on the device
-                if not last or last["nb_idx"].shape[0] == 0:
-                    continue
-                ctx.neighbors_to_csr(last["nb_idx"], last["nb_dist"], int(part_off[j]), out=csr_buf["buf"], row0=row0,
-                                     nb_count=last.get("nb_count"), id_map=last.get("rows"))
-                row0 += last["nb_idx"].shape[0]
-        else:                                                    # labels only: an empty graph
-            csr = (torch.zeros(labels.numel() + 1, dtype=torch.int64, device=dev),
-                   torch.empty(1, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.float32, device=dev))
-        handle = exchange.start(csr[0], csr[1], csr[2], labels, current, rows=rows_g)
+        handle, _, _ = fdist.start_graph_exchange(ctx, exchange, outs, lasts, part_off, args.n_neighbors, shard is not None,
+                                                  with_neighbors=args.exchange == "neighbors", csr_buf=csr_buf)
         done = finish_pending()
         pending.append(handle)
         return done

@@ -293,6 +293,38 @@ class ClusterPipeline:
         return outs
 
 
+    def run_chunked(self, datasets, precursor_tol_mass: float, precursor_tol_mode: str, rt_tol: Optional[float],
+                    fragment_tol: float, batch_size: int, p: AnnParams, n_chunks: int, on_chunk=None):
+        """Datasets whose working set exceeds one pass (BASELINE configs[3]: 50 M spectra need ~260 GB of vectors, index,
+        keys and hand-off buffers at once): the precursor buckets are dealt into `n_chunks` shares exactly as they are
+        dealt to GPUs (`_restrict`: LPT on `distributed.bucket_costs`; no neighbour pair crosses a bucket, reference
+        cluster.py:107-141) and the shares run one after the other on this GPU, each through `run_many(shard=(c,
+        n_chunks))`.  Same partition as one pass; cluster ids are share-major (the reference offsets the labels of its
+        blocks the same way, cluster.py:144-155).  `on_chunk(c, outs, lasts)` sees every share's raw results.
+        -> [(labels i32[N_j] by dataset row, medoids i32[n_labels_j] dataset rows)] per dataset."""
+        import torch
+        c = self.ctx
+        if n_chunks <= 1:
+            return self.run_many(datasets, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, batch_size, p)
+        labels = [torch.full((len(ds),), -1, dtype=torch.int32, device=c.tdev) for ds in datasets]
+        medoids = [[] for _ in datasets]
+        off = [0] * len(datasets)
+        for ch in range(n_chunks):
+            outs = self.run_many(datasets, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, batch_size, p,
+                                 shard=(ch, n_chunks))
+            for j, ((lab, med), last) in enumerate(zip(outs, self.lasts)):
+                rows = last["rows"]
+                if rows.numel() == 0:
+                    continue
+                labels[j][rows] = lab + off[j]
+                medoids[j].append(rows[med.long()].to(torch.int32))
+                off[j] += int(med.numel())
+            if on_chunk is not None:
+                on_chunk(ch, outs, self.lasts)
+            del outs
+        return [(labels[j], torch.cat(medoids[j]) if medoids[j] else c.empty((0,), torch.int32)) for j in range(len(datasets))]
+
+
 class PartitionRunner:
     """Runs independent partitions (precursor charges, falcon.py:151-160) concurrently: one host
     thread + one HIP stream + one `fal_ctx` per partition slot, the way the reference clusters its

@@ -41,9 +41,10 @@ class Config:
         p.add_argument("--rt_tol", type=float, default=None, help="Retention time tolerance (default: none).")
         p.add_argument("--fragment_tol", type=float, default=0.05, help="Fragment mass tolerance in m/z.")
         p.add_argument("--linkage", type=str, default="complete", choices=["complete", "single", "average"],
-                       help="Linkage of the hierarchical clustering (--clustering hierarchical; default: complete). "
-                            "Any other value is an error with the default DBSCAN clustering, which has no linkage.")
-        p.add_argument("--clustering", type=str, default="dbscan", choices=["dbscan", "hierarchical"],
+                       help="Linkage of the hierarchical clustering (default: complete). single / average select "
+                            "--clustering hierarchical when --clustering is not given (the reference honours them, "
+                            "config.py:97-103); together with an explicit --clustering dbscan they are an error.")
+        p.add_argument("--clustering", type=str, default=None, choices=["dbscan", "hierarchical"],
                        help="dbscan (README: density clustering of the neighbour graph, default) or hierarchical "
                             "(the snapshot's linkage + cut at the distance threshold, on the re-scored neighbour graph; "
                             "implies --rescore).")
@@ -133,6 +134,12 @@ class Config:
             ns["eps"] = ns["distance_threshold"]
         else:
             ns["distance_threshold"] = ns["eps"]
+        # the reference's --linkage values keep their meaning: a non-default linkage selects the hierarchical clustering;
+        # with an explicit --clustering dbscan (which has no linkage) the command line fails here, not per charge later
+        if ns["clustering"] is None:
+            ns["clustering"] = "hierarchical" if ns["linkage"] != "complete" else "dbscan"
+        elif ns["clustering"] == "dbscan" and ns["linkage"] != "complete":
+            self._parser.error(f"--linkage {ns['linkage']} needs --clustering hierarchical (DBSCAN has no linkage)")
         if ns["clustering"] == "hierarchical":
             ns["rescore"] = True
         if ns["n_neighbors_ann"] < ns["n_neighbors"]:

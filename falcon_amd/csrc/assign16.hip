@@ -397,8 +397,9 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
                     uint16_t* ckeys, int ckeys_stride) {
     if (n_single + n_merge <= 0) return FAL_OK;
+    // work lists of the exact kernels: a row enters at most one of them once per pass, so n_rows entries never overflow
     int32_t* amb = nullptr;
-    const int amb_cap = 1 << 24;
+    const int amb_cap = (int)std::max<int64_t>(n_rows, 1);
     FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(6 * (size_t)amb_cap + 16), (void**)&amb));
     FAL_CHECK_HIP(hipMemsetAsync(amb, 0, sizeof(int32_t) * 16, ctx->stream));
     Assign16Args a{};
@@ -441,7 +442,6 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     hipLaunchKernelGGL(assign_exact_pairs_kernel, dim3((unsigned)(ctx->num_cus * 8)), dim3(256), 0, ctx->stream, a, X, Cn, d);
     hipLaunchKernelGGL(assign_exact_rows_kernel, dim3((unsigned)(ctx->num_cus * 16)), dim3(64), 0, ctx->stream, a, X, Cn, d);
     FAL_CHECK_HIP(hipGetLastError());
-    if (!ctx->fb_host) FAL_CHECK_HIP(hipHostMalloc((void**)&ctx->fb_host, 64, hipHostMallocDefault));
     FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 1, amb, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));   // counter(6'): last pass
     return FAL_OK;
 }

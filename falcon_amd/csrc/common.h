@@ -71,7 +71,9 @@ struct fal_ctx {
         size_t used = 0;
     } timers[fal::kNumStages];
     fal::Scratch scratch[32];
-    int32_t* fb_host = nullptr;           // pinned: fallback-query count of the last fused scan
+    int32_t* fb_host = nullptr;           // pinned, 16 words, zeroed at creation: [0] / [2] fallback queries of the last prefiltered
+                                          // search (flat / IVF buckets), [1] ambiguous rows of the last k-means pass
+    int32_t* zero_dev = nullptr;          // 16 zero words on the device (stream-ordered resets of fb_host)
     int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // caching device allocator for per-call objects (index arrays): blocks are recycled, never

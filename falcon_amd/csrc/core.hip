@@ -167,6 +167,13 @@ int fal_ctx_create(int device, void* stream, int own_stream, fal_ctx** out) {
         }
         c->own_stream = true;
     }
+    if (hipHostMalloc((void**)&c->fb_host, 64, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&c->zero_dev, 64) != hipSuccess || hipMemset(c->zero_dev, 0, 64) != hipSuccess) {
+        fal::set_error("fal_ctx_create: cannot allocate the context's counters");
+        fal_ctx_destroy(c);
+        return FAL_ENOMEM;
+    }
+    memset(c->fb_host, 0, 64);
     *out = c;
     return FAL_OK;
 }
@@ -180,6 +187,7 @@ int fal_ctx_destroy(fal_ctx* c) {
     for (auto& b : c->pool) (void)hipFree(b.ptr);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->fb_host) (void)hipHostFree(c->fb_host);
+    if (c->zero_dev) (void)hipFree(c->zero_dev);
     if (c->arena) (void)hipHostFree(c->arena);
     for (auto& t : c->timers)
         for (auto& p : t.ev) {

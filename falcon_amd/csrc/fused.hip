@@ -828,20 +828,14 @@ int fused_prepare(fal_ctx* ctx, FusedArgs* ap, int64_t n_rows) {
     a.gkept_u = a.gmem_id + n_rows * FAL_FUSED_MEM;
     a.gkept_id = a.gkept_u + n_rows * FAL_FUSED_KEEP;
     a.gkcnt = reinterpret_cast<int32_t*>(a.gkept_id + n_rows * FAL_FUSED_KEEP);
-    ctx->counters[6] = (int64_t)(uintptr_t)hand;            // (debug tools read the hand-off buffers)
-    // fallback list
+    // fallback list: resolve_kernel pushes a query at most once, so n_rows entries can never overflow
     int32_t* fb = nullptr;
-    const int fb_cap = 1 << 22;
+    const int fb_cap = (int)std::max<int64_t>(n_rows, 1);
     FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(2 * fb_cap + 16), (void**)&fb));
     a.fb_count = fb;
-    ctx->counters[7] = (int64_t)(uintptr_t)fb;              // (debug tools: fallback count + reason counters)
     a.fb_list = fb + 16;
     a.fb_cap = fb_cap;
     FAL_CHECK_HIP(hipMemsetAsync(fb, 0, sizeof(int32_t) * 16, ctx->stream));
-    if (!ctx->fb_host) {
-        FAL_CHECK_HIP(hipHostMalloc((void**)&ctx->fb_host, 64, hipHostMallocDefault));
-        memset(ctx->fb_host, 0, 64);
-    }
     return FAL_OK;
 }
 

@@ -32,6 +32,11 @@ struct fal_ivf {
     const void* X16 = nullptr;       // optional f16 rows (sorted order) for the flat scan: [n, planes, d]
     int x16_planes = 0;
     const void* Xpre = nullptr;      // optional float16 copy of X used ONLY as the prefilter of the fused flat scan
+    // The float16 prefilters are exact only for rows without negative (or non-finite) components (their error bound is relative
+    // to the similarity).  1 = some row of an IVF bucket has one (found by the build's pass over the rows): the build and the
+    // searches use the exact kernels; 0 = none; -1 = not read back yet (neg_dev holds the flag on the device)
+    int rows_signed = 0;
+    int32_t* neg_dev = nullptr;
     void* Xl16 = nullptr;            // float16 rows in list order: prefilter of the IVF fine scan (ivf16.hip), owned
     int32_t* pos_of_row = nullptr;   // [n] sorted row -> list-order position (with Xl16), owned
     int ckeys_stride = 0;            // columns of ckeys: 128 x (groups of the bucket with the most lists)
@@ -48,10 +53,10 @@ struct fal_ivf {
     int32_t* assign = nullptr;       // [n] bucket-local list of each sorted row
     int32_t* perm = nullptr;         // [n] list-order position -> sorted row
     // the rows of the IVF buckets in sparse form, [n, 64] each (entry = column, value; in the order of the exact similarity chains;
-    // column 0xFFFF = unused entry, 0xFFFE in entry 0 = more than 64 non-zeros, use the dense row); owned, null with the dense update
+    // column 0xFFFF = unused entry, 0xFFFE in entry 0 = more than 64 non-zeros, use the dense row); owned
     uint16_t* sp_cols = nullptr;
     float* sp_vals = nullptr;
     int64_t* list_off = nullptr;     // [total_lists + 1] list-order positions
-    int64_t* counts = nullptr;       // [total_lists + 1] list sizes (flat buckets; IVF lists only with the dense k-means update)
+    int64_t* counts = nullptr;       // [total_lists + 1] list sizes (flat buckets)
     void* bk_dev = nullptr;          // BucketDev[n_ivf_buckets]
 };

@@ -54,104 +54,6 @@ __device__ __forceinline__ double wave_xor_sum_d(double v) {
     return v;
 }
 
-// The DENSE form of the k-means update (FALCON_KMEANS_DENSE_UPDATE; the default is centroid_update_kernel below, over the rows'
-// sparse form): one wave per (bucket, list).  The wave walks the bucket's assignment array in row
-// order, 64 rows per step; members are found with a ballot and added one by one IN ROW ORDER
-// (float32), so the sum does not depend on scheduling.  Then spherical normalisation with the
-// same fixed-order float64 tree as the vectorise kernel.  Empty lists keep their centroid.
-// WRITE_PERM: instead of updating, record the members (stable) at perm[list_off[L] ...].
-template <int MODE>   // 0 = update centroid, 1 = count members, 2 = write perm
-__global__ __launch_bounds__(64) void list_walk_kernel(const float* __restrict__ X, int d,
-                                                       const int32_t* __restrict__ assign,
-                                                       const BucketDev* __restrict__ bk, int nb,
-                                                       float* __restrict__ C, int64_t* __restrict__ counts,
-                                                       const int64_t* __restrict__ list_off,
-                                                       int32_t* __restrict__ perm) {
-    const BucketDev b = bk[find_bucket(bk, nb, blockIdx.x)];
-    const int li = (int)(blockIdx.x - b.wave0);
-    const int lane = threadIdx.x;
-    constexpr int P = FAL_MAX_LOW_DIM / 256;
-    const int passes = (d + 255) / 256;
-    float4 acc[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t cnt = 0;
-    int64_t wbase = (MODE == 2) ? list_off[b.list0 + li] : 0;
-    for (int r0 = 0; r0 < b.n; r0 += 64) {
-        const int r = r0 + lane;
-        const bool mine = r < b.n && assign[b.row0 + r] == li;
-        uint64_t mask = __ballot(mine);
-        if (MODE == 2) {
-            if (mine) perm[wbase + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(b.row0 + r);
-            wbase += __popcll(mask);
-        } else if (MODE == 1) {
-            cnt += __popcll(mask);
-        } else {
-            cnt += __popcll(mask);
-            // members are added IN ROW ORDER (the sum must not depend on scheduling), but their rows are fetched four at
-            // a time: one member per memory round trip made this kernel half of the k-means time
-            while (mask) {
-                constexpr int G = 4;
-                int js[G];
-#pragma unroll
-                for (int t = 0; t < G; ++t) {
-                    js[t] = mask ? __ffsll((unsigned long long)mask) - 1 : -1;       // (mask is wave-uniform)
-                    if (mask) mask &= mask - 1;
-                }
-                float4 v[G][P];
-#pragma unroll
-                for (int t = 0; t < G; ++t) {
-                    const float4* row = reinterpret_cast<const float4*>(X + (b.row0 + r0 + max(js[t], 0)) * d);
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const int e = 64 * p + lane;    // float4 index
-                        v[t][p] = (js[t] >= 0 && p < passes && e < d / 4) ? row[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < G; ++t) {
-                    if (js[t] < 0) continue;            // (-0.0 + 0.0 would flip a sign bit: skip, do not add zeros)
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const int e = 64 * p + lane;
-                        if (p < passes && e < d / 4) {
-                            acc[p].x += v[t][p].x;
-                            acc[p].y += v[t][p].y;
-                            acc[p].z += v[t][p].z;
-                            acc[p].w += v[t][p].w;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (MODE == 1) {
-        if (lane == 0) counts[b.list0 + li] = cnt;
-        return;
-    }
-    if (MODE == 2) return;
-    if (cnt == 0) return;   // keep the previous centroid
-    double part = 0.0;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (p < passes) {
-            part += (double)acc[p].x * (double)acc[p].x;
-            part += (double)acc[p].y * (double)acc[p].y;
-            part += (double)acc[p].z * (double)acc[p].z;
-            part += (double)acc[p].w * (double)acc[p].w;
-        }
-    }
-    const double nr = wave_xor_sum_d(part);
-    const float inv = nr > 0.0 ? (float)__ddiv_rn(1.0, __dsqrt_rn(nr)) : 0.f;
-    float4* o = reinterpret_cast<float4*>(C + (b.list0 + li) * d);
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const int e = 64 * p + lane;
-        if (p < passes && e < d / 4)
-            o[e] = make_float4(acc[p].x * inv, acc[p].y * inv, acc[p].z * inv, acc[p].w * inv);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // k-means update from the SPARSE form of the rows.  A vectorised spectrum has at most as many non-zero components as peaks
 // (~50 of 400), and adding a zero never changes a float32 sum (the accumulators start at +0.0), so summing a list's members
@@ -162,7 +64,8 @@ __global__ __launch_bounds__(64) void list_walk_kernel(const float* __restrict__
 // rows of the IVF buckets -> (column, value) entries; blocks of 256 rows, seg_off = first block of every bucket
 __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restrict__ X, int d, const BucketDev* __restrict__ bk,
                                                             const int64_t* __restrict__ seg_off, int nb,
-                                                            uint16_t* __restrict__ cols, float* __restrict__ vals) {
+                                                            uint16_t* __restrict__ cols, float* __restrict__ vals,
+                                                            int32_t* __restrict__ neg_flag) {
     __shared__ uint16_t sc[4][kSparseW];
     __shared__ float sv[4][kSparseW];
     int lo = 0, hi = nb - 1;
@@ -174,6 +77,7 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r_first = (int)(blockIdx.x - seg_off[lo]) * 256;
     const int r_end = min(b.n, r_first + 256);
+    bool neg = false;            // a component that is negative or not finite: the float16 prefilters' error bound needs rows >= 0
     for (int rl = r_first + w; rl < r_end; rl += 4) {
         const int64_t r = b.row0 + rl;
         sc[w][lane] = kColPad;
@@ -190,7 +94,10 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
             const float xs[8] = {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lo.w, hi.w};
             int c = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c += (int)(xs[j] != 0.f);
+            for (int j = 0; j < 8; ++j) {
+                c += (int)(xs[j] != 0.f);
+                neg |= !(xs[j] >= 0.f) || xs[j] > 65504.f;
+            }
             int pre = c;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -214,6 +121,7 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
         cols[r * kSparseW + lane] = sc[w][lane];
         vals[r * kSparseW + lane] = sv[w][lane];
     }
+    if (__ballot(neg) != 0ull && lane == 0) atomicOr(neg_flag, 1);
 }
 
 // global list of every sorted row (bucket by binary search on the bucket table) = the key of the stable sort by list
@@ -242,7 +150,7 @@ __global__ void list_bounds_kernel(const uint32_t* __restrict__ keys_sorted, int
 }
 
 // update: one wave per (bucket, list); the members (sorted rows, in row order) are added one after the other into the wave's
-// LDS accumulators, eight members' entries in flight.  Normalisation as in list_walk_kernel.  Empty lists keep their centroid.
+// LDS accumulators, eight members' entries in flight.  Normalisation: the fixed-order float64 tree of the vectorise kernel.  Empty lists keep their centroid.
 __global__ __launch_bounds__(64) void centroid_update_kernel(const uint16_t* __restrict__ cols, const float* __restrict__ vals,
                                                              const float* __restrict__ X, int d,
                                                              const int32_t* __restrict__ rows_sorted,
@@ -381,12 +289,29 @@ using namespace fal;
 // build
 // ------------------------------------------------------------------------------------------
 
+namespace fal {
+// any float16 component that is negative (not -0), infinite or NaN -> *flag = 1   (8 halves per lane and step)
+__global__ void rows_sign16_kernel(const uint4* __restrict__ x, int64_t n8, int32_t* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 v = x[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = w[j] & 0xFFFFu, hi = w[j] >> 16;
+            bad |= lo > 0x8000u || (lo & 0x7FFFu) >= 0x7C00u || hi > 0x8000u || (hi & 0x7FFFu) >= 0x7C00u;
+        }
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace fal
+
 extern "C" {
 
 int fal_ivf_destroy(fal_ivf* ivf) {
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
-                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals};
+                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals, ivf->neg_dev};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -413,11 +338,31 @@ int fal_ivf_attach_prefilter_ex(fal_ivf* ivf, const void* X16, int which) {
     FAL_REQUIRE(ivf && X16, FAL_EINVAL, "fal_ivf_attach_prefilter: NULL argument");
     FAL_REQUIRE(ivf->X, FAL_EINVAL, "fal_ivf_attach_prefilter: the index has no float32 rows to refine with");
     FAL_REQUIRE(which >= 1 && which <= 3, FAL_EINVAL, "fal_ivf_attach_prefilter_ex: which must be 1 (flat buckets), 2 (IVF buckets) or 3");
-    if (which & 1) ivf->Xpre = X16;
-    if ((which & 2) && ivf->n_ivf_buckets > 0 && !ivf->Xl16) {
+    fal_ctx* ctx = ivf->ctx;
+    if ((which & 1) && ivf->n > 0) {
+        // the precondition of the prefilter (header): no negative / non-finite component.  One pass over the float16 rows
+        // (2 d bytes per row) and one synchronisation; rows that fail it leave the flat buckets to the exact staged scan.
+        int32_t* flag = nullptr;
+        FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t), (void**)&flag));
+        FAL_CHECK_HIP(hipMemsetAsync(flag, 0, sizeof(int64_t), ctx->stream));
+        const int64_t n8 = ivf->n * (int64_t)ivf->d / 8;
+        hipLaunchKernelGGL(rows_sign16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n8, 256), (int64_t)ctx->num_cus * 32)), dim3(256),
+                           0, ctx->stream, reinterpret_cast<const uint4*>(X16), n8, flag);
+        FAL_CHECK_HIP(hipGetLastError());
+        FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 5, flag, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ivf->Xpre = ctx->fb_host[5] == 0 ? X16 : nullptr;
+        if (!ivf->Xpre) ctx->counters[6] |= 2;
+    }
+    if ((which & 2) && ivf->n_ivf_buckets > 0 && ivf->rows_signed < 0) {
+        FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 4, ivf->neg_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        ivf->rows_signed = ctx->fb_host[4] != 0 ? 1 : 0;
+        ctx->counters[6] |= ivf->rows_signed;
+    }
+    if ((which & 2) && ivf->n_ivf_buckets > 0 && !ivf->Xl16 && ivf->rows_signed == 0) {
         FAL_REQUIRE(ivf16_supports(ivf->d), FAL_EUNSUPPORTED,
                     "fal_ivf_attach_prefilter_ex: the IVF prefilter is instantiated for low_dim 64, 128, 256, 400 (got %d)", ivf->d);
-        fal_ctx* ctx = ivf->ctx;
         FAL_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)ivf->n * ivf->d, &ivf->Xl16));
         FAL_TRY(ctx->pool_alloc(sizeof(int32_t) * (size_t)ivf->n, (void**)&ivf->pos_of_row));
         FAL_TRY(launch_gather16(ctx, X16, ivf->perm, ivf->n, ivf->d, ivf->Xl16, ivf->pos_of_row));
@@ -456,6 +401,8 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
     } else {
         FAL_REQUIRE(n == 0, FAL_EINVAL, "fal_ivf_build: no buckets but n > 0");
     }
+    ctx->counters[6] = 0;      // bit 0: rows of an indexed bucket, bit 1: rows handed to the flat prefilter have negative / non-finite
+                               // components -> this index runs without float16 prefilters (fal_ctx_counter 6)
     fal_ivf* ivf = new fal_ivf();
     ivf->ctx = ctx;
     ivf->n = n;
@@ -526,6 +473,62 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                                ivf->centroids);
         B_HIP(hipGetLastError());
         }
+        // The rows' sparse form (k-means update: centroid_update_kernel; exact chains of the kept pairs: pairs16.hip), made before
+        // anything else because the same pass over the float32 rows tells whether any component is negative (or not finite):
+        // the float16 prefilters' error bound |f16-MFMA - exact| <= 1.3e-3 v + 2e-6 holds for NON-NEGATIVE rows only, so with
+        // such rows the build and the searches of this index use the exact float32 kernels (same results, slower).
+        uint16_t* sp_cols = nullptr;
+        float* sp_vals = nullptr;
+        uint32_t *key_in = nullptr, *key_out = nullptr;
+        int32_t* iota = nullptr;
+        int64_t *boff_dev = nullptr, *lbase_dev = nullptr;
+        int end_bit = 1;
+        while (end_bit < 32 && (1ll << end_bit) < total) ++end_bit;
+        {
+            std::vector<int64_t> seg_off(bk.size() + 1, 0), tab(2 * (size_t)(n_buckets + 1));
+            for (size_t i = 0; i < bk.size(); ++i) seg_off[i + 1] = seg_off[i] + ceil_div(bk[i].n, 256);
+            for (int64_t b = 0; b <= n_buckets; ++b) {
+                tab[b] = bucket_off[b];
+                tab[n_buckets + 1 + b] = ivf->list_base[b];
+            }
+            int64_t* seg_dev = nullptr;
+            void* sortbuf = nullptr;
+            B_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (seg_off.size() + 1), (void**)&seg_dev));
+            B_TRY(ctx->upload(seg_dev, seg_off.data(), sizeof(int64_t) * seg_off.size()));
+            int32_t* neg_dev = reinterpret_cast<int32_t*>(seg_dev + seg_off.size());
+            B_HIP(hipMemsetAsync(neg_dev, 0, sizeof(int64_t), st));
+            B_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * tab.size(), (void**)&boff_dev));
+            B_TRY(ctx->upload(boff_dev, tab.data(), sizeof(int64_t) * tab.size()));
+            lbase_dev = boff_dev + n_buckets + 1;
+            B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, (void**)&ivf->sp_cols));
+            B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&ivf->sp_vals));
+            sp_cols = ivf->sp_cols;
+            sp_vals = ivf->sp_vals;
+            B_TRY(ctx->reserve(SLOT_SORT2, 3 * sizeof(uint32_t) * (size_t)n, &sortbuf));
+            key_in = (uint32_t*)sortbuf;
+            key_out = key_in + n;
+            iota = (int32_t*)(key_out + n);
+            {
+                StageScope ts(ctx, ST_BUILD);
+                hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
+                                   nbk, sp_cols, sp_vals, neg_dev);
+                B_HIP(hipGetLastError());
+                hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, st, iota, n);
+                B_HIP(hipGetLastError());
+            }
+            // the one synchronisation of the build (only when float16 rows were handed in: ~20 us of an empty queue against the
+            // tens of ms of the k-means passes that follow)
+            if (X16 != nullptr) {
+                B_HIP(hipMemcpyAsync(ctx->fb_host + 4, neg_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                B_HIP(hipStreamSynchronize(st));
+                ivf->rows_signed = ctx->fb_host[4] != 0 ? 1 : 0;
+                ctx->counters[6] |= ivf->rows_signed;
+            } else {
+                ivf->rows_signed = -1;        // not known on the host yet: fal_ivf_attach_prefilter_ex reads it if it needs it
+                B_TRY(ctx->pool_alloc(sizeof(int32_t) * 2, (void**)&ivf->neg_dev));
+                B_HIP(hipMemcpyAsync(ivf->neg_dev, neg_dev, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            }
+        }
         // Buckets with few lists (<= kAssignMaxLists) are assigned by the shared-stream kernel (assign.hip): jobs =
         // (row segment) x (group of <= 128 centroids).  Buckets with many lists keep the row-resident kernel, whose
         // 32-row tile is amortised over their many centroid chunks.
@@ -548,7 +551,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         const int64_t wseg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(wave_rows, (int64_t)ctx->num_cus * 16 * 32) * 32));
         // buckets with <= 128 lists and float16 rows at hand: the prefiltered assignment (assign16.hip; identical results)
         static const bool no_a16 = getenv("FALCON_NO_ASSIGN16") != nullptr;
-        const bool use16 = X16 != nullptr && assign16_supports(low_dim) && !no_a16 && !row_major;
+        const bool use16 = X16 != nullptr && assign16_supports(low_dim) && !no_a16 && !row_major && ivf->rows_signed == 0;
         std::vector<AssignJob> hjobs, mjobs, gjobs;    // single-group jobs; merge jobs and their group jobs (129..512 lists)
         for (const BucketDev& b : bk) {
             if (use16 && b.n_list <= kAssignGroup) {
@@ -600,45 +603,6 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             B_TRY(ctx->upload(hjobs_dev, hjobs.data(), sizeof(AssignJob) * hjobs.size()));
             B_TRY(ctx->reserve(SLOT_INVCNT, sizeof(uint16_t) * (size_t)total * low_dim + 64, &C16));
         }
-        // centroid update: members of every list from a stable sort of the rows by list, sums over the rows' sparse form
-        // (centroid_update_kernel).  FALCON_KMEANS_DENSE_UPDATE keeps the dense walk over the assignment array (A/B runs).
-        static const bool dense_update = getenv("FALCON_KMEANS_DENSE_UPDATE") != nullptr;
-        uint16_t* sp_cols = nullptr;
-        float* sp_vals = nullptr;
-        uint32_t *key_in = nullptr, *key_out = nullptr;
-        int32_t* iota = nullptr;
-        int64_t *boff_dev = nullptr, *lbase_dev = nullptr;
-        int end_bit = 1;
-        while (end_bit < 32 && (1ll << end_bit) < total) ++end_bit;
-        if (!dense_update) {
-            std::vector<int64_t> seg_off(bk.size() + 1, 0), tab(2 * (size_t)(n_buckets + 1));
-            for (size_t i = 0; i < bk.size(); ++i) seg_off[i + 1] = seg_off[i] + ceil_div(bk[i].n, 256);
-            for (int64_t b = 0; b <= n_buckets; ++b) {
-                tab[b] = bucket_off[b];
-                tab[n_buckets + 1 + b] = ivf->list_base[b];
-            }
-            int64_t* seg_dev = nullptr;
-            void* sortbuf = nullptr;
-            B_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * seg_off.size(), (void**)&seg_dev));
-            B_TRY(ctx->upload(seg_dev, seg_off.data(), sizeof(int64_t) * seg_off.size()));
-            B_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * tab.size(), (void**)&boff_dev));
-            B_TRY(ctx->upload(boff_dev, tab.data(), sizeof(int64_t) * tab.size()));
-            lbase_dev = boff_dev + n_buckets + 1;
-            B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, (void**)&ivf->sp_cols));
-            B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&ivf->sp_vals));
-            sp_cols = ivf->sp_cols;
-            sp_vals = ivf->sp_vals;
-            B_TRY(ctx->reserve(SLOT_SORT2, 3 * sizeof(uint32_t) * (size_t)n, &sortbuf));
-            key_in = (uint32_t*)sortbuf;
-            key_out = key_in + n;
-            iota = (int32_t*)(key_out + n);
-            StageScope ts(ctx, ST_BUILD);
-            hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
-                               nbk, sp_cols, sp_vals);
-            B_HIP(hipGetLastError());
-            hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, st, iota, n);
-            B_HIP(hipGetLastError());
-        }
         // stable sort of the rows by (global) list: perm = rows in list order, list_off = the lists' boundaries
         auto sort_by_list = [&]() -> int {
             hipLaunchKernelGGL(list_key_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 8192)), dim3(256), 0, st, ivf->assign,
@@ -674,29 +638,13 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, n_wide, n_wave, n, keys, ivf->assign));
             if (it == kmeans_iters) break;   // final assignment against the final centroids
             StageScope ts(ctx, ST_BUILD);
-            if (dense_update) {
-                hipLaunchKernelGGL(list_walk_kernel<0>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign,
-                                   bkd, nbk, ivf->centroids, nullptr, nullptr, nullptr);
-            } else {
-                B_TRY(sort_by_list());
-                hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)waves), dim3(64), 0, st, sp_cols, sp_vals, X, low_dim,
-                                   ivf->perm, ivf->list_off, bkd, nbk, ivf->centroids);
-            }
+            B_TRY(sort_by_list());
+            hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)waves), dim3(64), 0, st, sp_cols, sp_vals, X, low_dim,
+                               ivf->perm, ivf->list_off, bkd, nbk, ivf->centroids);
             B_HIP(hipGetLastError());
         }
         StageScope ts(ctx, ST_BUILD);
-        if (dense_update) {
-            hipLaunchKernelGGL(list_walk_kernel<1>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
-                               nbk, nullptr, ivf->counts, nullptr, nullptr);
-            B_HIP(hipGetLastError());
-            hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, ivf->counts, total, ivf->list_off);
-            B_HIP(hipGetLastError());
-            hipLaunchKernelGGL(list_walk_kernel<2>, dim3((unsigned)waves), dim3(64), 0, st, X, low_dim, ivf->assign, bkd,
-                               nbk, nullptr, nullptr, ivf->list_off, ivf->perm);
-            B_HIP(hipGetLastError());
-        } else {
-            B_TRY(sort_by_list());       // (the sparse rows stay with the index: pairs16.hip evaluates its exact chains over them)
-        }
+        B_TRY(sort_by_list());       // (the sparse rows stay with the index: pairs16.hip evaluates its exact chains over them)
         // the float32 rows in list order are made on demand (fal_ivf_ensure_xl: the staged fine scan and the staged coarse scan read
         // them; the default path -- coarse quantiser from the build's keys, float16 prefilter -- does not: 16 GB at 10 M spectra)
         ivf->Xl = nullptr;

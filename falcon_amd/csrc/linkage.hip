@@ -23,6 +23,10 @@
 
 namespace fal {
 
+// Largest connected group the complete / average forms accept: the agglomeration is one wave per group and O(m^3 / 64)
+// over an m x m float64 matrix (m = 2,048: a few seconds; 5,000 would run for minutes and look like a hang).
+constexpr int kLinkageMaxComponent = 2048;
+
 __device__ __forceinline__ int32_t lk_find(int32_t* parent, int32_t x) {
     int32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != x) {
@@ -71,13 +75,16 @@ __global__ void lk_roots_kernel(int32_t* __restrict__ parent, int32_t* __restric
 }
 
 // per row: 1 where the row is the root of a component of >= 2 rows; sizes / squared sizes for the member and matrix offsets
+// (+ the largest component, for the size guard of the one-wave agglomeration)
 __global__ void lk_comp_kernel(const int32_t* __restrict__ parent, const int32_t* __restrict__ count, int64_t n,
-                               int32_t* __restrict__ is_comp, int64_t* __restrict__ msz, int64_t* __restrict__ msq) {
+                               int32_t* __restrict__ is_comp, int64_t* __restrict__ msz, int64_t* __restrict__ msq,
+                               int32_t* __restrict__ max_comp) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const bool c = parent[i] == (int32_t)i && count[i] >= 2;
         is_comp[i] = c;
         msz[i] = c ? count[i] : 0;
         msq[i] = c ? (int64_t)count[i] * count[i] : 0;
+        if (c && count[i] > kLinkageMaxComponent) atomicMax(max_comp, count[i]);
     }
 }
 
@@ -238,17 +245,24 @@ int linkage_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64
         int64_t* msq = msz + (n + 1);
         moff = msq + (n + 1);
         qoff = moff + (n + 1);
-        FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(n + 1), (void**)&crank));
-        hipLaunchKernelGGL(lk_comp_kernel, dim3(grid), dim3(256), 0, st, parent, count, n, flag, msz, msq);
+        FAL_TRY(ctx->reserve(SLOT_TAIL2, sizeof(int64_t) * (size_t)(n + 2), (void**)&crank));
+        int32_t* max_comp = reinterpret_cast<int32_t*>(crank + n + 1);      // (behind the n + 1 words of the scan)
+        FAL_CHECK_HIP(hipMemsetAsync(max_comp, 0, sizeof(int64_t), st));
+        hipLaunchKernelGGL(lk_comp_kernel, dim3(grid), dim3(256), 0, st, parent, count, n, flag, msz, msq, max_comp);
         FAL_TRY(device_scan_i32(ctx, flag, n, crank, SLOT_DB3));
         FAL_TRY(device_scan_i64(ctx, msz, n, moff, SLOT_DB3));
         FAL_TRY(device_scan_i64(ctx, msq, n, qoff, SLOT_DB3));
-        int64_t tot[3] = {0, 0, 0};
+        int64_t tot[4] = {0, 0, 0, 0};
+        FAL_CHECK_HIP(hipMemcpyAsync(&tot[3], max_comp, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         FAL_CHECK_HIP(hipMemcpyAsync(&tot[0], crank + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         FAL_CHECK_HIP(hipMemcpyAsync(&tot[1], moff + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         FAL_CHECK_HIP(hipMemcpyAsync(&tot[2], qoff + n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
         FAL_CHECK_HIP(hipStreamSynchronize(st));
         const int64_t n_comp = tot[0], n_mem = tot[1], n_sq = tot[2];
+        FAL_REQUIRE((int32_t)tot[3] <= kLinkageMaxComponent, FAL_EUNSUPPORTED,
+                    "hierarchical clustering (complete / average): a connected group of %d spectra within the distance threshold "
+                    "exceeds the supported %d (the agglomeration is cubic in the group size); use single linkage or DBSCAN, or a "
+                    "smaller threshold", (int32_t)tot[3], kLinkageMaxComponent);
         FAL_REQUIRE(n_sq < ((int64_t)1 << 32), FAL_EUNSUPPORTED,
                     "hierarchical clustering: the connected groups need %lld matrix entries (a group of tens of thousands of "
                     "spectra within the distance threshold); use single linkage or DBSCAN", (long long)n_sq);

@@ -442,11 +442,8 @@ int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32
     StageScope ts(ctx, ST_SCAN);
     if (a.sp_cols != nullptr && a.sp_vals != nullptr && d <= 512) {
         const size_t lds = (size_t)32 * d * 4 + 4 * 64 * 112 + 34 * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            FAL_CHECK_HIP(hipFuncSetAttribute((const void*)pairs16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
-        }
+        // (per launch: the attribute is per device, and two partition threads may launch at once)
+        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)pairs16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         hipLaunchKernelGGL(pairs16s_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), lds, ctx->stream, a, d);
     } else {
         hipLaunchKernelGGL(pairs16_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);

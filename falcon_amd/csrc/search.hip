@@ -195,7 +195,10 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     ctx->stage_reset(ST_COARSE);
     ctx->stage_reset(ST_SCAN);
     ctx->stage_reset(ST_SELECT);
-    if (ctx->fb_host) ctx->fb_host[0] = ctx->fb_host[2] = 0;      // fallback queries of this call (fal_ctx_counter 5)
+    // fallback queries of this call (fal_ctx_counter 5): reset in stream order -- a previous call's asynchronous copy into
+    // the same pinned words may still be in flight
+    FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host, ctx->zero_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 2, ctx->zero_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     const size_t cap = sims_capacity_floats();
 
     // ---- job tables ------------------------------------------------------------------------

@@ -193,6 +193,50 @@ class SparseGraphExchange:
         return out
 
 
+def start_graph_exchange(ctx, exchange: "SparseGraphExchange", outs, lasts, part_off, n_neighbors: int, sharded: bool,
+                         with_neighbors: bool = True, csr_buf: Optional[dict] = None):
+    """The one exchange step of a pass over a job of several partitions (precursor charges, falcon.py:151-193), as
+    `bench.py --gpus N` and the world-size-2 HIP test run it: this rank's neighbour lists of every partition chain into
+    ONE CSR on the device (`fal_neighbors_to_csr_mapped`: ids -> dataset rows of the job, partition j's rows start at
+    part_off[j]), the labels get the per-partition offsets, and `exchange.start` ships [counts | labels | rows | idx |
+    dist].  `outs` / `lasts`: what `ClusterPipeline.run_many(..., shard=...)` returned / left in `.lasts`.
+    -> (handle for `exchange.finish`, local labels i32, number of local labels).  `csr_buf`: a dict the caller keeps so
+    that the CSR buffers are allocated once."""
+    import torch
+    dev = ctx.tdev
+    labels_all, current = [], 0
+    for labels, medoids in outs:
+        labels_all.append(labels + current)                  # falcon.py:189-193
+        current += int(medoids.numel())
+    labels = torch.cat(labels_all) if labels_all else torch.empty(0, dtype=torch.int32, device=dev)
+    rows_local = sum(int(o[0].numel()) for o in outs)
+    rows_g = None
+    if sharded:
+        rows_g = torch.cat([last["rows"].to(torch.int32) + int(part_off[j]) for j, last in enumerate(lasts)])
+    if with_neighbors:
+        csr_buf = csr_buf if csr_buf is not None else {}
+        if csr_buf.get("rows", -1) < rows_local:
+            cap = max(rows_local, 1) * n_neighbors
+            csr_buf["buf"] = (torch.empty(rows_local + 1, dtype=torch.int64, device=dev),
+                              torch.empty(cap, dtype=torch.int32, device=dev),
+                              torch.empty(cap, dtype=torch.float32, device=dev))
+            csr_buf["rows"] = rows_local
+        row0 = 0
+        csr = (csr_buf["buf"][0][:rows_local + 1], csr_buf["buf"][1], csr_buf["buf"][2])
+        if rows_local == 0:
+            csr[0].zero_()
+        for j, last in enumerate(lasts):                     # charge partitions chain into one CSR on the device
+            if not last or "nb_idx" not in last or last["nb_idx"].shape[0] == 0:
+                continue
+            ctx.neighbors_to_csr(last["nb_idx"], last["nb_dist"], int(part_off[j]), out=csr_buf["buf"], row0=row0,
+                                 nb_count=last.get("nb_count"), id_map=last.get("rows"))
+            row0 += last["nb_idx"].shape[0]
+    else:                                                    # labels only: an empty graph
+        csr = (torch.zeros(labels.numel() + 1, dtype=torch.int64, device=dev),
+               torch.empty(1, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.float32, device=dev))
+    return exchange.start(csr[0], csr[1], csr[2], labels, current, rows=rows_g), labels, current
+
+
 # ---------------------------------------------------------------------------------------------
 # One dataset, N GPUs: buckets -> ranks by cost (LPT), every rank runs the path on its buckets,
 # one all-gatherv of (dataset rows, labels, medoids).  SURVEY 8e; reference analogue: blocks are

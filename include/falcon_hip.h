@@ -70,7 +70,11 @@ int fal_ctx_enable_timing(fal_ctx* ctx, int on);
  * which = 1: (query, centroid) inner products of the coarse quantiser;
  * which = 2: number of scan kernel launches (batches);  3: bytes of the sims scratch buffer;
  * which = 4: inner products the matrix cores actually computed for the flat buckets (tile padding
- *            included; the fp32 kernel computes only the blocks on/above each bucket's diagonal). */
+ *            included; the fp32 kernel computes only the blocks on/above each bucket's diagonal);
+ * which = 5: queries of the last prefiltered search that took the exact fallback (after a sync);
+ * which = 6: precondition check of the float16 prefilters for the LAST index built on this context: bit 0 = rows of
+ *            an indexed bucket, bit 1 = rows handed to the flat prefilter hold negative / non-finite components, so
+ *            that index is built / searched with the exact kernels (see fal_ivf_build_x16). */
 int fal_ctx_counter(fal_ctx* ctx, int which, int64_t* value);
 
 /* ---- a1  bin geometry: reference spectrum.py:172-199 `get_dim` (float32) --- [host] */
@@ -125,7 +129,13 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim,
 /* The same build with float16 copies [n, low_dim] of X (fal_vectorize FAL_DTYPE_F16 on the same peaks) as a PREFILTER of
  * the k-means / final assignment of buckets with <= 512 lists: the arg-max runs on the f16 matrix cores and only the
  * rows whose two best centroids are closer than the float16 error bound are re-evaluated exactly in float32 -- every
- * assignment, centroid and list is identical to fal_ivf_build's (low_dim in {64, 128, 256, 400}; X16 NULL = fal_ivf_build). */
+ * assignment, centroid and list is identical to fal_ivf_build's (low_dim in {64, 128, 256, 400}; X16 NULL = fal_ivf_build).
+ * PRECONDITION of every float16 prefilter of this library (here and fal_ivf_attach_prefilter[_ex]): X16 is the float16
+ * rounding of X, and no component of X is negative, infinite or NaN -- the error bound that makes the prefiltered results
+ * exact, |f16-MFMA(x.y) - fp32 chain(x.y)| <= 1.3e-3 (x.y) + 2e-6, is relative to the similarity and holds for
+ * non-negative rows only (hashed spectra are: intensities >= 0).  The precondition is CHECKED, not assumed: the build's
+ * pass over the rows of the indexed buckets looks at every component (one stream synchronisation when X16 is given), and
+ * an index whose rows fail it is built and searched with the exact float32 kernels -- same results, no error. */
 int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, int low_dim,
                       const int64_t* bucket_off, int64_t n_buckets, const int32_t* n_list,
                       int kmeans_iters, fal_ivf** out);
@@ -141,14 +151,18 @@ int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes);
  * precursor window are then evaluated exactly in float32 and the bracket is resolved exactly where it
  * matters -- the neighbour lists are BIT-IDENTICAL to the ones computed without the prefilter, the
  * [n, candidates] similarity matrix never exists in HBM.  low_dim in {64, 128, 256, 400}; other sizes
- * ignore the prefilter.  fal_ivf_search_topk never uses it.  The buffer is borrowed. ------------ [dev] */
+ * ignore the prefilter.  fal_ivf_search_topk never uses it.  The buffer is borrowed.  Precondition as stated at
+ * fal_ivf_build_x16 (non-negative finite components); the call checks it with one pass over X16 and one stream
+ * synchronisation, and rows that fail it make the searches ignore the prefilter (exact staged scan). ---- [dev] */
 int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16);
 /* The same with a choice of where the prefilter is used: which & 1 = flat buckets (as above), which & 2 = buckets
  * with an index: their fine scan runs on the f16 matrix cores over a float16 copy of the rows in list order
  * (made here, owned by the index; X16 itself is only read during this call for that part), the k-th best key
  * of every query is bracketed from 16-bit keys, and the exact float32 work is limited to the precursor window
- * and to the candidates that can decide the k-th key.  BIT-IDENTICAL neighbour lists.  Reference: faiss
- * IndexIVFFlat.search as called by falcon/cluster/cluster.py:212-225 (dependency, not in the snapshot). [dev] */
+ * and to the candidates that can decide the k-th key.  BIT-IDENTICAL neighbour lists under the same precondition
+ * (the build has already looked at the rows of the indexed buckets: if any has a negative / non-finite component
+ * no float16 copy is made and the searches run the exact fine scan).  Reference: the n_probe query of README.md:107-113
+ * (faiss IndexIVFFlat.search, an un-vendored dependency: setup.cfg:25). ------------------------------------ [dev] */
 int fal_ivf_attach_prefilter_ex(fal_ivf* ivf, const void* X16, int which);
 int fal_ivf_destroy(fal_ivf* ivf);
 int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists);

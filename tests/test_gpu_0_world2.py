@@ -1,0 +1,63 @@
+"""The HIP pipeline under world_size 2 (VERDICT r2 missing #5): two FRESH processes (torch.distributed.run, gloo backend, both
+on GPU 0) run `ClusterPipeline.run_many(shard=(rank, 2))` on their precursor buckets of ONE dataset and the one exchange step
+(`start_graph_exchange` -> `SparseGraphExchange`); the assembled labels and the gathered sparse neighbour graph must equal
+the single-rank result.
+
+This file sorts first among the GPU tests on purpose: the pytest process must not have initialised the GPU when it starts the
+launcher (an exec from a process that owns a GPU context is refused on the GPU boxes); the test itself creates no context."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n_spectra,mz_lo,mz_hi,regime", [
+    (30000, 500.0, 560.0, "flat"),            # ~350-row windows: flat buckets, thousands of units to deal
+    (60000, 600.0, 606.0, "ivf"),             # ~7,000-row windows: k-means index (n_list 128), prefiltered fine scan
+])
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, regime):
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("this pytest process already owns a GPU context: run tests/test_gpu_0_world2.py first / on its own")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "world2_worker.py"), str(tmp_path), str(n_spectra),
+           str(mz_lo), str(mz_hi)]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        log, _ = proc.communicate(timeout=900)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        log, _ = proc.communicate()
+        pytest.fail("world-size-2 job timed out:\n" + log[-3000:])
+    assert proc.returncode == 0, log[-3000:]
+    r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in (0, 1))
+    single = r0["single_labels"]
+    n = len(single)
+    assert (int(r0["single_n_list_max"]) > 1) == (regime == "ivf")
+    # both ranks did real work and between them covered the dataset
+    assert int(r0["rows_local0"]) + int(r1["rows_local0"]) == n and min(int(r0["rows_local0"]), int(r1["rows_local0"])) > n // 4
+    for rep in (0, 1):
+        lab = r0[f"labels{rep}"]
+        assert np.array_equal(lab, r1[f"labels{rep}"])                         # every rank assembled the same global labels
+        assert lab.min() == 0 and len(np.unique(lab)) == lab.max() + 1 == int(r0[f"n_local{rep}"]) + int(r1[f"n_local{rep}"])
+        pairs = np.unique(np.stack([single, lab]), axis=1)
+        assert pairs.shape[1] == len(np.unique(single)) == len(np.unique(lab))    # the same partition as one rank
+        # the gathered sparse graph == the single rank's neighbour lists: same (row, neighbour, distance bits) triples
+        e = r0[f"edges{rep}"]
+        assert np.array_equal(e, r1[f"edges{rep}"])
+        key = lambda t: t[:, np.lexsort((t[2], t[1], t[0]))]
+        assert np.array_equal(key(e), key(r0["single_edges"]))
+    assert (np.bincount(single) > 1).sum() > 20                               # a non-trivial clustering

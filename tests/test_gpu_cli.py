@@ -124,7 +124,8 @@ def test_main_with_rescore_option(tmp_path):
 
 def test_main_hierarchical_clustering_option(tmp_path):
     """`--clustering hierarchical --linkage average` (the snapshot's own clustering, cluster.py:283-290, on the re-scored graph)
-    through main(): same clustering as the oracle's run of those stages; a linkage with the default DBSCAN is refused."""
+    through main(): same clustering as the oracle's run of those stages.  `--linkage average` alone selects the hierarchical
+    clustering like the reference's command line does; with an explicit `--clustering dbscan` it is refused at parse time."""
     from falcon_amd import synth
     from falcon_amd.falcon import main
     from falcon_amd.ms_io import ms_io
@@ -140,11 +141,14 @@ def test_main_hierarchical_clustering_option(tmp_path):
     out = str(tmp_path / "res")
     base = [mgf, out, "--eps", "0.35", "--remove_precursor_tol", "0.0", "--min_intensity", "0.0", "--min_matched_peaks", "4",
             "--work_dir", str(tmp_path / "work")]
-    with pytest.raises(ValueError, match="only applies to the hierarchical"):
-        main(base + ["--linkage", "average"])
+    with pytest.raises(SystemExit):
+        main(base + ["--clustering", "dbscan", "--linkage", "average"])
+    assert main(base + ["--linkage", "average"]) == 0
+    implied = open(out + ".csv").read().splitlines()
     assert main(base + ["--overwrite", "--clustering", "hierarchical", "--linkage", "average"]) == 0
     lines = open(out + ".csv").read().splitlines()
     assert "# clustering = hierarchical" in lines and "# linkage = average" in lines
+    assert [l for l in implied if not l.startswith("#")] == [l for l in lines if not l.startswith("#")]
     body = [l.split(",") for l in lines if not l.startswith("#")][1:]
     lab = np.array([int(r[5]) for r in body])
     charge = np.array([int(r[2]) for r in body])

@@ -20,9 +20,14 @@ def _parts(ctx, data, select):
     return parts
 
 
-def _check_partition(ctx, ds, lab, med, lab2, med2, last, p, dist_tol, check_values=2000):
+def _check_partition(ctx, ds, lab, med, lab2, med2, last, p, dist_tol, check_values=2000, shard=False):
+    """`shard`: (lab, med, last) are one share of a bucket-sharded run -- labels / medoids / neighbour ids refer to the share's
+    rows in sorted order, last["rows"] maps them to dataset rows."""
     import torch
-    n = len(ds)
+    n = int(lab.numel())
+    if shard:
+        last = dict(last, order=last["rows"])
+        sorted_pos = torch.arange(n, device=lab.device)
     # determinism: the same inputs give the same bits (no atomics-order dependence anywhere on the path)
     assert torch.equal(lab, lab2) and torch.equal(med, med2)
     # label contract (cluster.py:144-155): dense ids, no -1, medoids[c] represents cluster c
@@ -43,6 +48,7 @@ def _check_partition(ctx, ds, lab, med, lab2, med2, last, p, dist_tol, check_val
     assert bool((d0[both] <= d1[both]).all())
     assert bool(((nb_dist[valid] >= 0) & (nb_dist[valid] <= 1)).all())
     mz_sorted = ds.precursor_mz[order]
+    assert bool((mz_sorted[1:] >= mz_sorted[:-1]).all())
     i_idx = rows[valid]
     j_idx = nb_idx[valid].long()
     dist_ij = nb_dist[valid]
@@ -69,7 +75,7 @@ def _check_partition(ctx, ds, lab, med, lab2, med2, last, p, dist_tol, check_val
     exp = (1.0 - cos).clamp(0.0, 1.0)
     assert float((exp - dist_ij[pick].double()).abs().max()) <= dist_tol
     # clusters never cross the precursor tolerance chain: members of one cluster span < 1 m/z (one window)
-    lab_sorted = lab[order]
+    lab_sorted = lab[sorted_pos] if shard else lab[order]
     lo = torch.full((med.numel(),), float("inf"), device=lab.device).scatter_reduce(0, lab_sorted.long(), mz_sorted, "amin")
     hi = torch.full((med.numel(),), float("-inf"), device=lab.device).scatter_reduce(0, lab_sorted.long(), mz_sorted, "amax")
     assert float((hi - lo).max()) < 1.0
@@ -99,6 +105,52 @@ def _run_and_check(n_total, p, generator, dist_tol):
     assert total == n_total
     ctx.close()
     return sizes
+
+
+def test_fifty_million_spectra_config4_invariants():
+    """BASELINE configs[3] at its own size on ONE GPU: 50,000,000 spectra, n_probe 32, n_neighbors_ann 128 -- 1 m/z windows of
+    ~44,000 (charge 2) / ~19,000 (charge 3) spectra, cut further by the reference's batch_size rule (blocks of at most 2^15
+    rows, cluster.py:197-207): buckets of up to 32,768 rows, n_list 512 / 256.  The working set of one pass (~260 GB) does not fit next to the
+    dataset, so the buckets run in 4 shares (`ClusterPipeline.run_chunked`, the multi-GPU partition executed in turn); every
+    share goes through the invariants, and the shares must cover every spectrum exactly once."""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
+    from falcon_amd.device import Context
+    n_total, n_chunks = 50_000_000, 4
+    ctx = Context(0)
+    pipe = ClusterPipeline(ctx)
+    data = synth.generate_device(n_total, ctx.tdev, seed=42)
+    parts = _parts(ctx, data, synth.select_charge_device)
+    del data
+    torch.cuda.empty_cache()
+    p = AnnParams(n_probe=32, n_neighbors_ann=128)
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, p)
+    seen = [torch.zeros(len(ds), dtype=torch.int32, device=ctx.tdev) for ds in parts]
+    n_list_max, first = [0], {}
+
+    def check(ch, outs, lasts):
+        for j, ((lab, med), last) in enumerate(zip(outs, lasts)):
+            if last["rows"].numel() == 0:
+                continue
+            seen[j][last["rows"]] += 1
+            n_list_max[0] = max(n_list_max[0], int(np.max(last["n_list"])))
+            if ch == 0:
+                first[j] = (lab.clone(), med.clone())
+            _check_partition(ctx, parts[j], lab, med, lab, med, last, p, 1e-5, shard=True)
+
+    res = pipe.run_chunked(parts, *args, n_chunks=n_chunks, on_chunk=check)
+    assert n_list_max[0] == 512
+    assert all(bool((s == 1).all()) for s in seen)
+    for ds, (lab, med) in zip(parts, res):
+        assert int(lab.min()) == 0 and int(lab.max()) == med.numel() - 1
+        assert torch.equal(lab[med.long()], torch.arange(med.numel(), device=lab.device, dtype=lab.dtype))
+    # determinism: share 0 again gives the same bits
+    again = pipe.run_many(parts, *args, shard=(0, n_chunks))
+    for j, (lab, med) in enumerate(again):
+        assert torch.equal(lab, first[j][0]) and torch.equal(med, first[j][1])
+    assert ctx.counter(6) == 0
+    ctx.close()
 
 
 def test_one_million_spectra_invariants():

@@ -73,8 +73,7 @@ def test_ivf_prefilter_neighbours_bit_identical_to_the_staged_path(ctx, d, n_pro
 ])
 def test_ivf_prefilter_on_sparse_rows_bit_identical_to_the_staged_path(ctx, d, n_probe, k_ann, keep, tol, mode, rt_tol):
     """rows shaped like vectorised spectra (a few dozen non-zero components): the exact chains of the kept pairs run over the
-    rows' sparse form (pairs16s_kernel) -- plus rows with exactly 64 / more than 64 non-zeros (dense chain), negative components
-    and all-zero rows; the staged path computes every similarity densely on the fp32 matrix cores"""
+    rows' sparse form (pairs16s_kernel) -- plus rows with exactly 64 / more than 64 non-zeros (dense chain) and all-zero rows; the staged path computes every similarity densely on the fp32 matrix cores"""
     sizes = [6000, 300, 2500, 9000, 40, 1300]
     nl = np.array([64, 1, 32, 128, 1, 16], np.int32)
     off, _, mz, rt = _buckets(sizes, d, 33)
@@ -83,6 +82,43 @@ def test_ivf_prefilter_on_sparse_rows_bit_identical_to_the_staged_path(ctx, d, n
     e_idx, n_fb = _staged_and_prefiltered(ctx, X, off, nl, mz, rt if rt_tol is not None else None, n_probe, k_ann, keep,
                                           tol, mode, rt_tol)
     assert (e_idx >= 0).sum() > off[-1] // 8
+
+
+def test_mixed_sign_rows_are_detected_and_searched_exactly(ctx):
+    """the prefilters' error bound holds for non-negative rows only.  With genuinely mixed-sign rows
+    (40 % negative components: the error of a float16 product sum scales with sum |x_i y_i|, not with the similarity) the
+    library must notice (fal_ctx_counter 6) and build / search with the exact kernels: index and neighbour lists equal
+    the ones computed without any float16 copy, bit for bit -- and equal the oracle's index."""
+    import torch
+    from oracle import falcon_oracle as fo
+    sizes = [6000, 300, 2500]
+    nl = np.array([64, 1, 32], np.int32)
+    off, _, mz, rt = _buckets(sizes, 400, 37)
+    X = sparse_unit_vectors(int(off[-1]), 400, 39, signed=True)
+    assert (X < 0).mean() > 0.02
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    X16 = Xd.to(torch.float16).contiguous()
+    mz_d = torch.from_numpy(mz).to(ctx.tdev)
+    plain = ctx.ivf_build(Xd, off, nl, kmeans_iters=4)
+    assert ctx.counter(6) == 0                                   # nothing to check without float16 copies
+    e = plain.search_neighbors(16, 128, mz_d, None, 20.0, "ppm", None, 64)
+    pre = ctx.ivf_build(Xd, off, nl, kmeans_iters=4, Xkm=X16, Xpre=X16, prefilter_which=3)
+    assert ctx.counter(6) == 3                                   # indexed rows AND the flat prefilter's rows rejected
+    g = pre.search_neighbors(16, 128, mz_d, None, 20.0, "ppm", None, 64)
+    for a, b in zip(plain.export(), pre.export()):
+        assert torch.equal(a, b)
+    assert torch.equal(e[0], g[0]) and torch.equal(e[1].view(torch.int32), g[1].view(torch.int32))
+    ctx.sync()
+    assert ctx.counter(5) == 0                                   # no prefiltered search ran, so no fallback either
+    cent, asg, perm, loff = [t.cpu().numpy() for t in pre.export()]
+    C, ra, rperm, roff = fo.ivf_build(X[:6000], 64, 4)
+    assert np.array_equal(asg[:6000], ra) and np.array_equal(cent[:64], C)
+    # non-negative rows next: the same calls use the prefilters again (the flag belongs to the index, not the context)
+    Xp = torch.from_numpy(np.abs(X)).to(ctx.tdev)
+    ok = ctx.ivf_build(Xp, off, nl, kmeans_iters=4, Xkm=Xp.to(torch.float16).contiguous(),
+                       Xpre=Xp.to(torch.float16).contiguous(), prefilter_which=3)
+    assert ctx.counter(6) == 0
+    ok.close(), pre.close(), plain.close()
 
 
 def test_ivf_prefilter_handles_ties_zero_rows_and_few_candidates(ctx):

@@ -45,6 +45,20 @@ def _check_index_equals_oracle(pipe_last, X, kmeans_iters):
     return n_ivf
 
 
+def _check_production_equals_oracle(ctx, ds, p, staged_last, ref, rmed):
+    """The path bench.py times (`pipe.run` with the default AnnParams: float16 prefilters ON, a7 + a8 fused, a9..a12
+    fused) against the oracle directly: labels and medoids == fo.generate_clusters, neighbour lists == the staged
+    lists `_check_stages` has just pinned to fo.ivf_search + fo.filter_neighbors."""
+    from falcon_amd.cluster.cluster import ClusterPipeline
+    assert p.ivf_prefilter and p.kmeans_prefilter
+    prod = ClusterPipeline(ctx)
+    labels, medoids = prod.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, p)
+    assert np.array_equal(labels.cpu().numpy(), ref) and np.array_equal(medoids.cpu().numpy(), rmed)
+    assert np.array_equal(prod.last["nb_idx"].cpu().numpy(), staged_last["nb_idx"].cpu().numpy())
+    assert np.array_equal(prod.last["nb_dist"].cpu().numpy(), staged_last["nb_dist"].cpu().numpy())
+    assert ctx.counter(6) == 0, "the float16 prefilters were switched off (rows flagged as signed)"
+
+
 def test_config3_regime_buckets_of_8750_rows_n_list_128(ctx):
     """three 1 m/z windows of ~9 k charge-2 spectra: n_list 128, n_probe 16, k_ann 128, d 400, 10 k-means iterations
     (the whole-job settings of BASELINE configs[2])."""
@@ -60,6 +74,7 @@ def test_config3_regime_buckets_of_8750_rows_n_list_128(ctx):
     assert _check_index_equals_oracle(L, X, p.kmeans_iters) >= 3
     ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"])
     assert np.array_equal(labels, ref) and np.array_equal(medoids, rmed)
+    _check_production_equals_oracle(ctx, ds, p, L, ref, rmed)
 
 
 def test_config4_regime_bucket_of_25k_rows_n_list_512_n_probe_32(ctx):
@@ -75,6 +90,7 @@ def test_config4_regime_bucket_of_25k_rows_n_list_512_n_probe_32(ctx):
     assert _check_index_equals_oracle(L, X, p.kmeans_iters) >= 1
     ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"], n_probe=32)
     assert np.array_equal(labels, ref) and np.array_equal(medoids, rmed)
+    _check_production_equals_oracle(ctx, ds, p, L, ref, rmed)
 
 
 def test_bucket_sharded_run_many_equals_single_gpu(ctx):

@@ -87,9 +87,10 @@ def test_ivf_build_matches_oracle(ctx, sizes, nlists, d):
             assert np.array_equal(cent[lb[b]:lb[b + 1]], C)
 
 
-def sparse_unit_vectors(n, d, seed, nnz_lo=20, nnz_hi=50):
+def sparse_unit_vectors(n, d, seed, nnz_lo=20, nnz_hi=50, signed=False):
     """rows shaped like vectorised spectra: a few dozen non-zero components, near-duplicates in groups; plus rows with exactly
-    64 and with more than 64 non-zeros (the k-means update reads those dense), a negative component, and all-zero rows"""
+    64 and with more than 64 non-zeros (the k-means update reads those dense) and all-zero rows.  Non-negative like hashed
+    spectra unless `signed` (then ~40 % of the components are negative: outside the float16 prefilters' precondition)"""
     rng = np.random.default_rng(seed)
     n_groups = max(1, n // 12)
     proto = np.zeros((n_groups, d), np.float32)
@@ -97,7 +98,9 @@ def sparse_unit_vectors(n, d, seed, nnz_lo=20, nnz_hi=50):
         c = rng.choice(d, rng.integers(nnz_lo, nnz_hi + 1), replace=False)
         proto[g, c] = rng.random(len(c)).astype(np.float32) + 0.05
     X = proto[rng.integers(0, n_groups, n)].copy()
-    X *= (1.0 + 0.3 * rng.standard_normal(X.shape).astype(np.float32)) * (X != 0)
+    X *= np.abs(1.0 + 0.3 * rng.standard_normal(X.shape).astype(np.float32)) * (X != 0)
+    if signed:
+        X *= np.where(rng.random(X.shape) < 0.4, -1.0, 1.0).astype(np.float32)
     for r in rng.choice(n, max(4, n // 50), replace=False):        # wide rows
         k = 64 if (r % 3 == 0 or d <= 65) else int(rng.integers(65, min(d, 160) + 1))
         X[r] = 0

@@ -183,6 +183,18 @@ def test_config_ini_values_do_not_leak_into_the_next_parse(tmp_path):
     assert c.rescore and c.linkage == "average"
     with pytest.raises(SystemExit):
         c.parse("in.mgf out --linkage ward")
+    # the reference's --linkage values are honoured (they select the hierarchical clustering) or fail at
+    # parse time, never per charge after the spectra were read
+    c.parse("in.mgf out --linkage single")
+    assert c.clustering == "hierarchical" and c.rescore and c.linkage == "single"
+    c.parse("in.mgf out")
+    assert c.clustering == "dbscan" and not c.rescore
+    with pytest.raises(SystemExit):
+        c.parse("in.mgf out --clustering dbscan --linkage average")
+    ini2 = tmp_path / "b.ini"
+    ini2.write_text("linkage = average\n")
+    c.parse(f"-c {ini2} in.mgf out")
+    assert c.clustering == "hierarchical" and c.linkage == "average"
 
 
 def test_generate_clusters_argument_errors():
