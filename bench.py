@@ -7,9 +7,11 @@ medoids/labels) on synthetic peak lists, plus the cosine kernel's roofline fract
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-The job is ONE dataset of N x `--spectra` synthetic spectra (N = GPUs; default 1,000,000 per GPU =
-BASELINE.json configs[1] at N = 1), both charge partitions (falcon.py:151-193).  A "step" = one pass of the
-whole hot path over that dataset:
+The job is ONE dataset, both charge partitions (falcon.py:151-193).  `--scaling weak` (default): N x `--spectra`
+synthetic spectra (N = GPUs; 1,000,000 per GPU = BASELINE.json configs[1] at N = 1) with the precursor range widened
+with N (400 .. 400 + 800 N m/z) so that the bucket density -- and with it the work per spectrum -- stays that of the
+1 M workload.  `--scaling strong`: the FIXED `--spectra-total` dataset (default 10,000,000 in 400-1200 m/z =
+BASELINE configs[2]) on N GPUs.  A "step" = one pass of the whole hot path over that dataset:
 
   * every rank sorts the precursors of the whole dataset and derives the SAME precursor buckets (cheap,
     deterministic), buckets are dealt to ranks by longest-processing-time on their scan cost, a rank runs
@@ -19,10 +21,13 @@ whole hot path over that dataset:
     global sparse graph and the globally unique labels (rank-major offsets like falcon.py:189-193), which the
     rank copies to the host.  At N = 1 there is nothing to exchange and the step is the single-GPU pipeline.
 
-Inputs are resident in HBM before the timed region (`value`); `value_host_to_host` times the same step with the
-peak arrays starting in pinned host memory.  Rank 0 prints ONE JSON line; at N = 1 it also carries
-`configs`: the 10 M-spectra float32 run (BASELINE configs[2]'s dataset on one GPU = the north star's target size)
-and the 10 M / low_dim 800 / float16 run (configs[4]), and `cpu_baseline` (the oracle on all host cores).
+Inputs are resident in HBM before the timed region (`value`); `value_host_to_host` is the throughput of the same steps
+with the peak arrays starting in pinned host memory: the upload of step i + 1 travels on a copy stream under
+the kernels of step i (`ms_per_step_host_to_host_latency` = one step alone, upload then compute).  Rank 0 prints ONE JSON
+line; at N = 1 it also carries `configs`: the 10 M-spectra float32 run (BASELINE configs[2]'s dataset on one GPU = the
+north star's target size), the 10 M / low_dim 800 / float16 run (configs[4]), the configs[3] bucket regime at 10 M and
+configs[3] itself (50 M spectra, n_probe 32, in 4 bucket shares), each with its own `roofline`, and `cpu_baseline` (the
+oracle on all host cores).
 """
 import argparse
 import json
@@ -71,22 +76,26 @@ def cpu_baseline(host, params, seconds_hint=20.0):
                       f"buckets on a pool of {cores} threads, {dt:.1f} s"}
 
 
-def pmc_traffic(args):
-    """HBM bytes per step of the cosine kernels from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x 2
-    + WRITE_SIZE, separate passes, MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so the
-    figure is only reported for the workload it was measured on."""
-    default = (args.spectra == 1_000_000 and args.low_dim == 400 and args.n_neighbors_ann == 128
-               and args.mz_interval == 1.0 and args.batch_size == 2 ** 15 and args.scan == "f32" and args.dtype == "f32")
-    if not default:
-        return None, None
-    for fn in ("r2_pmc_hbm_traffic_per_step.json", "r1_pmc_hbm_traffic_per_step.json"):
+def pmc_traffic(workload):
+    """HBM bytes per launch of a workload's dominant cosine kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so
+    the figure is only reported for the workloads it was measured on (profiles/r3_pmc_traffic.json, written by
+    tools/pmc_traffic.sh on the GPU box).  -> (bytes per launch or None, source file or None)"""
+    for fn in ("r3_pmc_traffic.json",):
         path = os.path.join(ROOT, "profiles", fn)
         if os.path.isfile(path):
             try:
                 with open(path) as f:
-                    return float(json.load(f)["scan"]["hbm_bytes_per_launch"]), "profiles/" + fn
+                    e = json.load(f).get(workload)
+                if e:
+                    return float(e["hbm_bytes_per_launch"]), f"profiles/{fn}: {e.get('kernel', '')}"
             except Exception:
                 pass
+    if workload == "headline":
+        path = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic_per_step.json")
+        if os.path.isfile(path):
+            with open(path) as f:
+                return float(json.load(f)["scan"]["hbm_bytes_per_launch"]), "profiles/r2_pmc_hbm_traffic_per_step.json"
     return None, None
 
 
@@ -95,7 +104,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spectra", type=int, default=1_000_000, help="spectra per GPU (the dataset holds gpus x spectra)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: gpus x --spectra spectra, precursor range 400 .. 400 + 800 gpus m/z (constant bucket density); "
+                         "strong: the fixed --spectra-total dataset in 400-1200 m/z on every number of GPUs")
+    ap.add_argument("--spectra", type=int, default=1_000_000, help="weak scaling: spectra per GPU")
+    ap.add_argument("--spectra-total", type=int, default=10_000_000, help="strong scaling: spectra of the dataset")
     ap.add_argument("--low_dim", type=int, default=400)
     ap.add_argument("--n_probe", type=int, default=16)
     ap.add_argument("--n_neighbors", type=int, default=64)
@@ -120,13 +133,17 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange step's device work (CSR packing, payload) at 1 GPU too (no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-configs", action="store_true", help="skip the 10 M-spectra configurations of the `configs` array")
+    ap.add_argument("--no-configs", action="store_true", help="skip the 10 M / 50 M configurations of the `configs` array")
     ap.add_argument("--configs-spectra", type=int, default=10_000_000)
+    ap.add_argument("--big-spectra", type=int, default=50_000_000,
+                    help="BASELINE configs[3] at its own size (n_probe 32, n_neighbors_ann 128), run in --big-chunks bucket shares "
+                         "(ClusterPipeline.run_chunked); 0 = skip")
+    ap.add_argument("--big-chunks", type=int, default=4)
     ap.add_argument("--partitions", choices=["auto", "concurrent", "pipelined"], default="auto",
                     help="how the two charge partitions of a step are scheduled: concurrent = a host thread + HIP stream + context "
                          "each (PartitionRunner; the reference clusters its blocks on a thread pool, cluster.py:115-136), pipelined = "
                          "one stream, the next partition's sort under the current scan (ClusterPipeline.run_many); auto = concurrent "
-                         "on one GPU for the headline workload, pipelined for the 10 M configurations and for N > 1")
+                         "while the buckets are flat (the 1 M-per-GPU workloads), pipelined in the IVF regime (10 M and beyond)")
     ap.add_argument("--serial", action="store_true",
                     help="run the charge partitions strictly one after the other (default: software-pipelined, "
                          "ClusterPipeline.run_many)")
@@ -136,7 +153,7 @@ def main():
     import torch.distributed as dist
     from falcon_amd import synth
     from falcon_amd import distributed as fdist
-    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, PartitionRunner, SpectrumDataset
     from falcon_amd.device import Context
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,7 +186,7 @@ def main():
         return AnnParams(**base)
 
     def make_parts(n_total, first_block=0, mz_lo=400.0, mz_hi=1200.0):
-        """the dataset, split by precursor charge (falcon.py:151-160), resident in HBM -> [SpectrumDataset], host view"""
+        """the dataset, split by precursor charge (falcon.py:151-160), resident in HBM -> [SpectrumDataset]"""
         if args.generator == "device":
             data = synth.generate_device(n_total, dev, seed=42, first_block=first_block, mz_lo=mz_lo, mz_hi=mz_hi)
             sel = lambda c: synth.select_charge_device(data, c)
@@ -191,31 +208,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- the dataset: world x spectra, every rank holds it (a rank only touches the peaks of its own buckets) ----
-    n_total = world * args.spectra
-    parts = make_parts(n_total)
+    # ---- the dataset (every rank holds it; a rank only touches the peaks of its own buckets) ------------------------
+    strong = args.scaling == "strong"
+    n_total = args.spectra_total if strong else world * args.spectra
+    mz_lo, mz_hi = 400.0, (1200.0 if strong else 400.0 + 800.0 * world)
+    parts = make_parts(n_total, mz_lo=mz_lo, mz_hi=mz_hi)
     part_off = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
     p = params()
     run_args = (20.0, "ppm", None, 0.05, args.batch_size, p)
     shard = (rank, world) if world > 1 else None
     exchanging = args.exchange != "none" and (world > 1 or args.force_exchange)
-    keep_nb = args.exchange == "neighbors" and exchanging
     exchange = fdist.SparseGraphExchange(dev)
     pending, csr_buf = [], {}
+    # spectra per 1 m/z window and charge-2 partition: beyond ~1,600 the windows get an index (n_list > n_probe) -- the regime
+    # in which two concurrent partitions evict each other's L2-resident lists (tools/concurrent_parts.py: 2.4x slower at 10 M)
+    ivf_regime = 0.7 * n_total / max(mz_hi - mz_lo, 1.0) > 1600
 
     def collect_stages(n):
-        return ({k: ctx.stage_ms(k) for k in STAGES}
+        return ({k: ctx.stage_ms(k) for k in STAGES + ("kernel",)}
                 | {"pairs": ctx.counter(0), "coarse_pairs": ctx.counter(1), "issued": ctx.counter(4),
                    "scan_launches": ctx.counter(2), "sims_bytes": ctx.counter(3), "n": n})
 
     concurrent = {"on": False}
     runner = None
 
-    def step(parts, run_args, collect=None):
+    def step(parts, run_args, collect=None, chunks=1):
         """one pass of the hot path over the dataset; `collect` != None: serial, per-stage timing, no exchange"""
-        if collect is None and not args.serial and concurrent["on"]:
-            outs = runner.run(parts, *run_args)                                   # partitions on concurrent streams
-            lasts = [dict(pp.last) for pp in runner.last_pipes]
+        if chunks > 1:                                                            # (configs[3] at its own size, one GPU)
+            outs = pipe.run_chunked(parts, *run_args, n_chunks=chunks)
+            lasts = []
+        elif collect is None and not args.serial and concurrent["on"]:
+            outs = runner.run(parts, *run_args, shard=shard)                      # partitions on concurrent streams
+            lasts = runner.lasts
         elif collect is None and not args.serial:
             outs = pipe.run_many(parts, *run_args, shard=shard)                   # partitions software-pipelined
             lasts = pipe.lasts
@@ -231,7 +255,7 @@ def main():
                     lasts.append(dict(pipe.last))
                 if collect is not None:
                     collect.append(collect_stages(int(outs[-1][0].numel())))
-        if not exchanging or collect is not None:
+        if not exchanging or collect is not None or chunks > 1:
             labels_all, current = [], 0
             for labels, medoids in outs:
                 labels_all.append(labels + current)                  # falcon.py:189-193
@@ -255,20 +279,20 @@ def main():
             return fdist.SparseGraphExchange.assemble_labels(g, n_total).cpu()
         return g["labels"][rank].cpu()
 
-    def timed(parts, run_args, steps, warmup, prime=3):
+    def timed(parts, run_args, steps, warmup, prime=3, chunks=1):
         # setup, like the data generation: the first passes grow the library's scratch pool and torch's caching
         # allocator to their steady-state sizes (GB-sized hipMallocs, tens of ms each) -- prime them before the
         # contract's W warmup steps so that neither W nor the timed K steps contain one-off allocations
         for _ in range(prime):
-            step(parts, run_args)
+            step(parts, run_args, chunks=chunks)
         finish_pending()
         for _ in range(warmup):
-            step(parts, run_args)
+            step(parts, run_args, chunks=chunks)
         finish_pending()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(parts, run_args)
+            step(parts, run_args, chunks=chunks)
         finish_pending()                                         # the last exchange lands inside the timed region
         barrier()
         dt = time.perf_counter() - t0
@@ -286,146 +310,197 @@ def main():
         ctx.enable_timing(False)
         return stages
 
-    if args.partitions == "concurrent" or (args.partitions == "auto" and world == 1 and not exchanging and not args.serial):
-        from falcon_amd.cluster.cluster import PartitionRunner
+    want_concurrent = args.partitions == "concurrent" or (args.partitions == "auto" and not ivf_regime and not args.serial)
+    if want_concurrent:
         runner = PartitionRunner(local_rank, 2)
         concurrent["on"] = True
     dt = timed(parts, run_args, args.steps, args.warmup)
     stages = staged(parts, run_args)
 
     # ---- host-to-host: the peak arrays start in pinned host memory, labels end on the host -------
-    h2h = None
+    h2h = h2h_latency = None
     if world == 1:
         pinned = [[t.cpu().pin_memory() for t in (x.precursor_mz, x.retention_time, x.mz, x.intensity, x.indptr)] for x in parts]
+        copy_stream = torch.cuda.Stream(device=dev)
 
-        def upload():
-            return [SpectrumDataset(*[t.to(dev, non_blocking=True) for t in ts]) for ts in pinned]
+        def upload(on=None):
+            """-> the dataset on the device (+ the event that says the bytes have arrived)"""
+            if on is None:
+                return [SpectrumDataset(*[t.to(dev, non_blocking=True) for t in ts]) for ts in pinned], None
+            with torch.cuda.stream(on):
+                up = [SpectrumDataset(*[t.to(dev, non_blocking=True) for t in ts]) for ts in pinned]
+                ev = torch.cuda.Event()
+                ev.record(on)
+            return up, ev
 
         k2 = max(1, min(args.steps, 20))
         for _ in range(2):
-            step(upload(), run_args)
+            step(upload()[0], run_args)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(k2):
-            step(upload(), run_args)
+        for _ in range(k2):                                   # one step alone: upload, then compute (latency)
+            step(upload()[0], run_args)
+        torch.cuda.synchronize()
+        h2h_latency = (time.perf_counter() - t0) / k2
+        # a stream of datasets: the upload of step i + 1 (copy stream, PCIe) under the kernels of step i
+        nxt = upload(copy_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k2):
+            cur, ev = nxt
+            torch.cuda.current_stream(dev).wait_event(ev)
+            for ds in cur:                                    # (allocated on the copy stream, used on the compute streams)
+                for t in (ds.precursor_mz, ds.retention_time, ds.mz, ds.intensity, ds.indptr):
+                    t.record_stream(torch.cuda.current_stream(dev))
+            if i + 1 < k2:
+                nxt = upload(copy_stream)
+            step(cur, run_args)
         torch.cuda.synchronize()
         h2h = (time.perf_counter() - t0) / k2
-        del pinned
+        del pinned, nxt, cur
 
     def summarize(stages, d, p, elem):
         pairs = sum(s["pairs"] for s in stages)
-        ms = {k: round(sum(s[k][0] for s in stages), 3) for k in STAGES}
-        scan_ms = ms["scan"]
+        ms = {k: round(sum(s[k][0] for s in stages), 3) for k in STAGES + ("kernel",)}
         topk_ms = ms["scan"] + ms["select"] + ms["filter"]
         n_rows = sum(s["n"] for s in stages)
-        launches = sum(s["scan"][1] for s in stages)
+        launches = sum(s["kernel"][1] for s in stages)
         flops = 2.0 * d * pairs
         algo_bytes = n_rows * (2 * d * elem + 8 * p.n_neighbors_ann)          # SURVEY 8(d) compulsory bytes
         tf = lambda f, t: f / (t * 1e-3) / 1e12 if t > 0 else 0.0
         gbs = lambda b, t: b / (t * 1e-3) / 1e9 if t > 0 else 0.0
-        build_flops = 2.0 * d * sum(s["coarse_pairs"] for s in stages) * (p.kmeans_iters + 1)
-        return dict(pairs=pairs, stage_ms=ms, scan_ms=scan_ms, topk_ms=topk_ms, n_rows=n_rows, launches=launches,
-                    flops=flops, algo_bytes=algo_bytes, scan_tflops=tf(flops, scan_ms), cosine_tflops=tf(flops, topk_ms),
-                    issued_tflops=tf(2.0 * d * sum(s["issued"] for s in stages), scan_ms),
-                    hbm_gbs_scan=gbs(algo_bytes, scan_ms), hbm_gbs_cosine=gbs(algo_bytes, topk_ms),
-                    build_tflops=tf(build_flops, ms["build"]), build_flops=build_flops,
-                    coarse_tflops=tf(2.0 * d * sum(s["coarse_pairs"] for s in stages), ms["coarse"]))
+        return dict(pairs=pairs, stage_ms={k: v for k, v in ms.items() if k != "kernel"}, kernel_ms=ms["kernel"],
+                    scan_ms=ms["scan"], topk_ms=topk_ms, n_rows=n_rows, launches=launches, flops=flops, algo_bytes=algo_bytes,
+                    kernel_tflops=tf(flops, ms["kernel"]), cosine_tflops=tf(flops, topk_ms),
+                    issued_tflops=tf(2.0 * d * sum(s["issued"] for s in stages), ms["kernel"]),
+                    hbm_gbs_kernel=gbs(algo_bytes, ms["kernel"]), hbm_gbs_cosine=gbs(algo_bytes, topk_ms))
 
-    # ---- the 10 M configurations on ONE GPU (north star target size; BASELINE configs[2] dataset / configs[4]) --
+    def roofline_of(s, kernel, mfma_peak, mfma_name, workload_key, issued_factor=1.0, note=None):
+        """The dominant cosine kernel against the roof that bounds it.  `achieved` = ALGORITHMIC work per launch (2 d flop per
+        (query, candidate) pair the search has to look at; SURVEY 8d's compulsory bytes per spectrum for the HBM view) / the
+        kernel's average launch duration (HIP events on its own stream, `fal_ctx_stage_ms("kernel")`).  Both views are
+        computed; `bound` is the roof the kernel sits closer to."""
+        launches = max(s["launches"], 1)
+        mfma_frac = s["kernel_tflops"] * issued_factor / mfma_peak
+        hbm_frac = s["hbm_gbs_kernel"] / PEAK_HBM_GBS
+        traffic, src = pmc_traffic(workload_key)
+        if hbm_frac >= mfma_frac:
+            r = {"bound": "hbm", "achieved": s["hbm_gbs_kernel"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac}
+        else:
+            r = {"bound": "mfma", "achieved": s["kernel_tflops"] * issued_factor, "peak": mfma_peak, "unit": "TFLOP/s",
+                 "frac": mfma_frac}
+        r.update({"kernel": kernel, "roof": mfma_name if r["bound"] == "mfma" else "HBM3E 8 TB/s",
+                  "traffic": traffic, "traffic_unit": f"HBM bytes per launch (PMC, {src})" if src else None,
+                  "launches": s["launches"], "avg_launch_ms": s["kernel_ms"] / launches,
+                  "pairs_per_launch": s["pairs"] / launches, "flops_per_launch": s["flops"] / launches,
+                  "algorithmic_bytes_per_launch": s["algo_bytes"] / launches,
+                  "frac_of_mfma_peak": mfma_frac, "frac_of_hbm_roof": hbm_frac,
+                  # SURVEY 8d defines the cosine kernel as list scan + top-k: the same algorithmic work over every launch of
+                  # the scan / select / filter stages (exact pair chains and the k-th key resolution included)
+                  "scan_plus_topk": {"ms": s["topk_ms"], "tflops": s["cosine_tflops"],
+                                     "frac_of_mfma_peak": s["cosine_tflops"] * issued_factor / mfma_peak,
+                                     "algorithmic_bytes": s["algo_bytes"], "gbs": s["hbm_gbs_cosine"],
+                                     "frac_of_hbm_roof": s["hbm_gbs_cosine"] / PEAK_HBM_GBS}})
+        if note:
+            r["note"] = note
+        return r
+
+    # ---- the larger configurations on ONE GPU (north star target size; BASELINE configs[2] dataset / [3] / [4]) --------
     extra = []
     if world == 1 and not args.no_configs and rank == 0:
         del parts
         torch.cuda.empty_cache()
+        was_concurrent = concurrent["on"]
         if args.partitions == "auto":
-            concurrent["on"] = False          # 10 M spectra: two concurrent partitions lose (2.4x slower; tools/concurrent_parts.py)
-        big = make_parts(args.configs_spectra)
-        for name, kw in (("f32", dict(low_dim=400, dtype="f32", scan="f32")),
-                         ("f16", dict(low_dim=800, dtype="f16", scan="f32")),
-                         # BASELINE configs[3]'s bucket regime on one GPU: the same number of spectra in a quarter of the precursor
-                         # range (buckets of 20-35 k rows: n_list 512) with that config's n_probe = 32
-                         ("f32-dense", dict(low_dim=400, dtype="f32", scan="f32", n_probe=32))):
-            if name == "f32-dense":
+            concurrent["on"] = False          # IVF regime: two concurrent partitions lose (tools/concurrent_parts.py)
+        plan = [("f32", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 1200.0, 1),
+                ("f16", args.configs_spectra, dict(low_dim=800, dtype="f16", scan="f32"), 1200.0, 1),
+                # BASELINE configs[3]'s bucket regime on one GPU: the same number of spectra in a quarter of the precursor
+                # range (buckets of 20-35 k rows: n_list 512) with that config's n_probe = 32
+                ("f32-dense", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32), 600.0, 1)]
+        if args.big_spectra > 0:
+            # ... and configs[3] itself: 50 M spectra; the working set of one pass (~260 GB) does not fit beside the dataset,
+            # so the precursor buckets run in 4 shares one after the other (ClusterPipeline.run_chunked)
+            plan.append(("f32-50M", args.big_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32, n_neighbors_ann=128),
+                         1200.0, args.big_chunks))
+        big, big_key = None, None
+        for name, n_cfg, kw, hi, chunks in plan:
+            if big_key != (n_cfg, hi):
                 del big
                 torch.cuda.empty_cache()
-                big = make_parts(args.configs_spectra, mz_lo=400.0, mz_hi=600.0)
+                big = make_parts(n_cfg, mz_hi=hi)
+                big_key = (n_cfg, hi)
             pc = params(**kw)
             ra = (20.0, "ppm", None, 0.05, args.batch_size, pc)
+            steps_c = 3 if chunks == 1 else 2
             try:
-                dtc = timed(big, ra, 3, 1, prime=1)
-                sc = summarize(staged(big, ra), pc.low_dim, pc, 2 if name == "f16" else 4)
+                dtc = timed(big, ra, steps_c, 1, prime=1, chunks=chunks)
+                sc = None
+                if chunks == 1:
+                    sc = summarize(staged(big, ra), pc.low_dim, pc, 2 if name == "f16" else 4)
             except Exception as e:                                # pragma: no cover -- reported, never hidden
-                extra.append({"workload": f"{args.configs_spectra} spectra {name}", "error": repr(e)[:300]})
+                extra.append({"workload": f"{n_cfg} spectra {name}", "error": repr(e)[:300]})
                 continue
             n_big = sum(len(x) for x in big)
-            peak = PEAK_MFMA_F16_TFLOPS if name == "f16" else PEAK_MFMA_F32_TFLOPS
-            extra.append({
-                "workload": f"{args.configs_spectra} synthetic spectra on 1 GPU (charges 2+3"
-                            f"{', precursor m/z 400-600' if name == 'f32-dense' else ''}), low_dim={pc.low_dim} {name.split('-')[0]}, "
-                            f"n_neighbors={pc.n_neighbors}, n_neighbors_ann={pc.n_neighbors_ann}, n_probe={pc.n_probe}, "
-                            f"eps={pc.eps}, precursor_tol=20ppm, mz_interval={pc.mz_interval}",
+            entry = {
+                "workload": f"{n_cfg} synthetic spectra on 1 GPU (charges 2+3, precursor m/z 400-{hi:.0f}), low_dim={pc.low_dim} "
+                            f"{name.split('-')[0]}, n_neighbors={pc.n_neighbors}, n_neighbors_ann={pc.n_neighbors_ann}, "
+                            f"n_probe={pc.n_probe}, eps={pc.eps}, precursor_tol=20ppm, mz_interval={pc.mz_interval}"
+                            + (f", precursor buckets in {chunks} shares run one after the other" if chunks > 1 else ""),
                 "baseline_config": {"f32": "configs[2] dataset on one GPU", "f16": "configs[4]",
                                     "f32-dense": "configs[3] regime (n_list 512, n_probe 32, n_neighbors_ann 128) at one GPU's size: "
-                                                 "precursors in 400-600 m/z"}[name],
-                "steps": 3, "ms_per_step": dtc / 3 * 1e3, "value": n_big * 3 / dtc, "unit": "spectra/s", "dtype": name.split("-")[0],
-                "stage_ms": sc["stage_ms"], "pairs_per_step": sc["pairs"],
-                "cosine_kernel": {"scan_ms": sc["scan_ms"], "scan_plus_topk_ms": sc["topk_ms"],
-                                  "scan_tflops": sc["scan_tflops"], "scan_frac_of_mfma_peak": sc["scan_tflops"] / peak,
-                                  "scan_plus_topk_tflops": sc["cosine_tflops"],
-                                  "scan_plus_topk_frac_of_mfma_peak": sc["cosine_tflops"] / peak,
-                                  "algorithmic_bytes": sc["algo_bytes"],
-                                  "scan_plus_topk_frac_of_hbm_roof": sc["hbm_gbs_cosine"] / PEAK_HBM_GBS,
-                                  "mfma_peak_tflops": peak},
-                "kmeans": {"build_ms": sc["stage_ms"]["build"], "algorithmic_tflops": sc["build_tflops"],
-                           "note": "2*d*n_list flop per row and pass, 11 passes; computed on the f16 matrix cores (float16 prefilter) "
-                                   "with exact float32 re-evaluation of close calls: not fp32-MFMA work, the index is identical"},
-                "coarse": {"ms": sc["stage_ms"]["coarse"], "tflops": sc["coarse_tflops"]},
-                "fine_scan": ("float16 rows scanned on the f16 matrix cores (config 5 vectors)" if name == "f16" else
-                              ("exact fp32-MFMA scan of every probed pair + wavefront select" if args.no_ivf_prefilter else
-                               "f16-MFMA list scan to 16-bit keys + k-th key per query (stage scan/select), exact fp32-MFMA "
-                               "similarities of the precursor window + exact resolution of the k-th key: bit-identical to the "
-                               "exact scan (tests/test_gpu_ivf16.py); the TFLOP/s above count the algorithmic 2*d flop per probed "
-                               "pair, most of which run as float16")),
-                "prefilter_fallback_rows": int(ctx.counter(5)),
-            })
+                                                 "precursors in 400-600 m/z",
+                                    "f32-50M": "configs[3] (50 M spectra, n_probe 32, n_neighbors_ann 128) at its own size"}[name],
+                "steps": steps_c, "ms_per_step": dtc / steps_c * 1e3, "value": n_big * steps_c / dtc, "unit": "spectra/s",
+                "dtype": name.split("-")[0]}
+            if sc is not None:
+                entry.update({"stage_ms": sc["stage_ms"], "pairs_per_step": sc["pairs"]})
+                if name == "f16":
+                    entry["roofline"] = roofline_of(sc, "scan16_kernel<50,1> (f16 MFMA 32x32x16, LDS-staged candidates, exhaustive)",
+                                                    PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense", "10M_f16")
+                elif args.no_ivf_prefilter:
+                    entry["roofline"] = roofline_of(sc, "ivf_list4_kernel<50> (fp32 MFMA 32x32x2, list-major)",
+                                                    PEAK_MFMA_F32_TFLOPS, "fp32 MFMA 157.3 TFLOP/s", None)
+                else:
+                    entry["roofline"] = roofline_of(
+                        sc, "list16_kernel<25> (f16 MFMA 32x32x16, list-major: <= 128 rows of a list resident, the queries probing it "
+                            "stream through LDS)", PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense",
+                        {"f32": "10M_f32", "f32-dense": "10M_f32_dense"}[name],
+                        note="the kernel scans every probed (query, candidate) pair on the f16 matrix cores to 16-bit keys; the exact "
+                             "float32 work (pair chains, k-th key resolution: stages scan / select) is in scan_plus_topk")
+                entry["prefilter_fallback_rows"] = int(ctx.counter(5))
+            else:
+                entry["note"] = "per-stage timing and the kernel roofline are those of the configs[3]-regime entry above (same kernels)"
+            extra.append(entry)
         del big
         torch.cuda.empty_cache()
-        parts = make_parts(n_total)
+        concurrent["on"] = was_concurrent
+        parts = make_parts(n_total, mz_lo=mz_lo, mz_hi=mz_hi)
 
     if rank == 0:
         d = args.low_dim
         elem = 2 if args.dtype == "f16" else 4
         s = summarize(stages, d, p, elem)
-        f16_path = args.scan == "f16x3" or args.dtype == "f16"
-        traffic, traffic_src = pmc_traffic(args)
-        if f16_path:
+        if args.dtype == "f16" or args.scan == "f16x3":
             # issued matrix work: 3 f16 MFMAs per k-step for the split, 1 for plain float16 rows
-            issued_tf = s["scan_tflops"] * (3 if args.scan == "f16x3" and args.dtype == "f32" else 1)
-            mfma_frac, hbm_frac = issued_tf / PEAK_MFMA_F16_TFLOPS, s["hbm_gbs_scan"] / PEAK_HBM_GBS
-            if hbm_frac >= mfma_frac:
-                roof = {"bound": "hbm", "achieved": s["hbm_gbs_scan"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac}
-            else:
-                roof = {"bound": "mfma", "achieved": issued_tf, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": mfma_frac}
-            roof.update({"kernel": "scan16_kernel (f16 MFMA 32x32x16, LDS-staged) + dense_kernel for buckets < 64",
-                         "traffic": None, "mfma_f16_frac": mfma_frac, "hbm_frac": hbm_frac,
-                         "algorithmic_tflops": s["scan_tflops"]})
+            roof = roofline_of(s, "scan16_kernel (f16 MFMA 32x32x16, LDS-staged) + dense_kernel for buckets < 64",
+                               PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense", None,
+                               issued_factor=3.0 if (args.scan == "f16x3" and args.dtype == "f32") else 1.0)
+        elif ivf_regime and not args.no_ivf_prefilter:
+            roof = roofline_of(s, "list16_kernel<25> (f16 MFMA 32x32x16, list-major)", PEAK_MFMA_F16_TFLOPS,
+                               "f16 MFMA 2.5 PFLOP/s dense", "10M_f32" if n_total == 10_000_000 and world == 1 else None)
         else:
-            roof = {"kernel": "dense_kernel<.,STORE> (flat buckets) / ivf_list4_kernel (IVF buckets): cosine scan, fp32 MFMA 32x32x2",
-                    "bound": "mfma", "achieved": s["scan_tflops"], "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": s["scan_tflops"] / PEAK_MFMA_F32_TFLOPS, "traffic": traffic,
-                    "traffic_unit": f"HBM bytes per launch (PMC, {traffic_src})" if traffic_src else None,
-                    "flops_per_launch": s["flops"] / max(s["launches"], 1),
-                    # the kernel computes each bucket's similarity matrix on/above the diagonal only (bit-identical by
-                    # symmetry): `issued` = machine flops actually run through the matrix pipe, tile padding included
-                    "issued_tflops": s["issued_tflops"], "issued_frac": s["issued_tflops"] / PEAK_MFMA_F32_TFLOPS}
-        roof.update({"launches": s["launches"], "avg_launch_ms": s["scan_ms"] / max(s["launches"], 1),
-                     "pairs_per_step": s["pairs"],
-                     # SURVEY 8d defines the cosine kernel as list scan + top-k: the same algorithmic work over the
-                     # scan AND the select / filter launches
-                     "scan_plus_topk": {"ms": s["topk_ms"], "tflops": s["cosine_tflops"],
-                                        "frac_of_f32_mfma_peak": s["cosine_tflops"] / PEAK_MFMA_F32_TFLOPS,
-                                        "algorithmic_bytes": s["algo_bytes"], "gbs": s["hbm_gbs_cosine"],
-                                        "frac_of_hbm_roof": s["hbm_gbs_cosine"] / PEAK_HBM_GBS}})
+            default = (n_total == 1_000_000 and world == 1 and d == 400 and args.n_neighbors_ann == 128 and args.mz_interval == 1.0
+                       and args.batch_size == 2 ** 15 and not args.prefilter)
+            roof = roofline_of(s, "dense_kernel<50,STORE> (flat buckets, symmetric): cosine scan, fp32 MFMA 32x32x2",
+                               PEAK_MFMA_F32_TFLOPS, "fp32 MFMA 157.3 TFLOP/s", "headline" if default else None)
+            # the kernel computes each bucket's similarity matrix on/above the diagonal only (bit-identical by symmetry):
+            # `issued` = machine flops actually run through the matrix pipe, tile padding included
+            roof.update({"issued_tflops": s["issued_tflops"], "issued_frac": s["issued_tflops"] / PEAK_MFMA_F32_TFLOPS})
+        roof["profile"] = ("avg_launch_ms comes from a serial per-stage pass (HIP events); it agrees with the kernel's average in "
+                           "profiles/r3_bench_1M_pipelined_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py "
+                           "--partitions pipelined --no-configs --no-cpu-baseline`: one stream); in the default two-stream run "
+                           "(profiles/r3_bench_1M_kernel_stats.csv) the two partitions' kernels overlap and stretch each other")
         out = {
             "metric": "spectra clustered/sec @1/2/4/8 GPU; cosine-kernel HBM GB/s vs roofline",
             "value": n_total * args.steps / dt,
@@ -435,12 +510,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": ("f16" if args.dtype == "f16" else "f16x3 (f32 vectors as hi/lo float16, f32 accumulate)"
                       if args.scan == "f16x3" else "f32"),
             "data": "synthetic",
-            "config": {"workload": f"one dataset of {n_total} synthetic spectra ({args.spectra} per GPU; charges 2+3), low_dim={d}, "
+            "config": {"workload": f"one dataset of {n_total} synthetic spectra "
+                                   + (f"(fixed; {n_total // world} per GPU" if strong else f"({args.spectra} per GPU")
+                                   + f"; charges 2+3; precursor m/z {mz_lo:.0f}-{mz_hi:.0f}), low_dim={d}, "
                                    f"n_neighbors={args.n_neighbors}, n_neighbors_ann={args.n_neighbors_ann}, "
                                    f"n_probe={args.n_probe}, eps={args.eps}, precursor_tol=20ppm, "
                                    f"mz_interval={args.mz_interval}, batch_size={args.batch_size}",
@@ -449,23 +526,31 @@ def main():
                                     "the next step)") if exchanging else "none",
                        "partitions": ("serial" if args.serial else
                                       "concurrent: a host thread + HIP stream + context per charge partition (PartitionRunner)"
-                                      if runner is not None else "software-pipelined (ClusterPipeline.run_many)"),
+                                      if concurrent["on"] else "software-pipelined (ClusterPipeline.run_many)"),
                        "parallelism": (f"precursor buckets of the one dataset dealt to {world} GPUs (LPT), no data-path "
                                        "collective, one all-gatherv") if world > 1 else "1 GPU",
-                       "note": ("weak scaling keeps the spectra per GPU fixed; the dataset's precursor range does not grow, so "
-                                "buckets get denser with N and the work per spectrum rises (flat -> IVF regime)") if world > 1 else None},
+                       "note": (("strong scaling: the dataset is fixed, every GPU takes 1/N of its precursor buckets" if strong else
+                                 "weak scaling: spectra per GPU AND bucket density fixed -- the precursor range grows with N "
+                                 "(400 .. 400 + 800 N m/z), so the work per spectrum is that of the 1 M workload at every N")
+                                if world > 1 else None)},
             "roofline": roof,
             "stage_ms": s["stage_ms"],
         }
         if h2h is not None:
             out["value_host_to_host"] = n_total / h2h
             out["ms_per_step_host_to_host"] = h2h * 1e3
+            out["ms_per_step_host_to_host_latency"] = h2h_latency * 1e3
+            out["host_to_host_note"] = ("throughput of a stream of datasets: peak arrays in pinned host memory, the upload of step "
+                                        "i + 1 on a copy stream under the kernels of step i, labels back on the host; `latency` = "
+                                        "one step alone (upload, then compute)")
         if extra:
             out["configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             host = {k: getattr(parts[0], k).cpu().numpy() for k in ("precursor_mz", "retention_time", "mz", "intensity", "indptr")}
             out["cpu_baseline"] = cpu_baseline(host, p)
         line = json.dumps(out)
+    if runner is not None:
+        runner.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

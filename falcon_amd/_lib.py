@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfalcon_hip.so")
 
 FAL_DTYPE_F32, FAL_DTYPE_F16, FAL_DTYPE_SPLIT16 = 0, 1, 2
-STAGES = {"vectorize": 0, "build": 1, "coarse": 2, "scan": 3, "select": 4, "filter": 5, "dbscan": 6, "tail": 7}
+STAGES = {"vectorize": 0, "build": 1, "coarse": 2, "scan": 3, "select": 4, "filter": 5, "dbscan": 6, "tail": 7,
+          "kernel": 8}     # the cosine kernel's own launches (subset of "scan")
 
 
 class FalconHipError(RuntimeError):

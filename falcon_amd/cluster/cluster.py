@@ -351,22 +351,28 @@ class PartitionRunner:
                 self.pipelines.append(self._tls.pipe)
         return self._tls.pipe, self._tls.stream
 
-    def _run_one(self, ds, args, kwargs):
+    def _run_one(self, ds, args, kwargs, shard):
         import torch
         pipe, stream = self._pipeline()
         with torch.cuda.stream(stream):
-            out = pipe.run(ds, *args, **kwargs)
+            if shard is not None and shard[1] > 1:
+                out = pipe.run_many([ds], *args, shard=shard, **kwargs)[0]       # this rank's buckets of the partition
+                pipe.last = pipe.lasts[0]
+            else:
+                out = pipe.run(ds, *args, **kwargs)
             stream.synchronize()
-        return out, pipe
+        return out, pipe, dict(pipe.last)        # (a snapshot: the same slot may serve another partition next)
 
-    def run(self, datasets, *args, **kwargs):
-        """-> [(labels, medoids), ...] in the order of `datasets` (largest partition is started first)."""
+    def run(self, datasets, *args, shard: Optional[Tuple[int, int]] = None, **kwargs):
+        """-> [(labels, medoids), ...] in the order of `datasets` (largest partition is started first).  `shard = (rank,
+        world)`: every partition is one dataset shared by `world` GPUs, as in `ClusterPipeline.run_many`."""
         import torch
         torch.cuda.current_stream(self.device).synchronize()      # inputs produced on the caller's stream
         order = sorted(range(len(datasets)), key=lambda i: -len(datasets[i]))
-        futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs) for i in order}
+        futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs, shard) for i in order}
         res = [futs[i].result() for i in range(len(datasets))]
         self.last_pipes = [r[1] for r in res]
+        self.lasts = [r[2] for r in res]                           # every partition's `last`, in the order of `datasets`
         return [r[0] for r in res]
 
     def close(self):

@@ -36,9 +36,11 @@ void set_error(const char* fmt, ...);
         if (_r != FAL_OK) return _r;                                                 \
     } while (0)
 
-constexpr int kNumStages = 8;
+constexpr int kNumStages = 9;
 enum Stage { ST_VECTORIZE = 0, ST_BUILD = 1, ST_COARSE = 2, ST_SCAN = 3, ST_SELECT = 4,
-             ST_FILTER = 5, ST_DBSCAN = 6, ST_TAIL = 7 };
+             ST_FILTER = 5, ST_DBSCAN = 6, ST_TAIL = 7,
+             ST_KERNEL = 8 };   // the launches of the cosine kernel alone (dense_kernel / scan16_kernel / list16_kernel / ivf_list4_kernel;
+                                // also counted in ST_SCAN): the per-launch duration behind bench.py's roofline
 
 // A device buffer that only ever grows; lives in the context.
 struct Scratch {
@@ -98,7 +100,8 @@ struct StageScope {
     hipEvent_t stop = nullptr;
     bool on;
     hipStream_t s;
-    StageScope(fal_ctx* ctx, int stage, hipStream_t stream = nullptr) : c(ctx), on(ctx->timing), s(stream) {
+    StageScope(fal_ctx* ctx, int stage, hipStream_t stream = nullptr, bool enable = true)
+        : c(ctx), on(ctx->timing && enable), s(stream) {
         if (on) c->stage_begin(stage, &stop, s);
     }
     ~StageScope() {

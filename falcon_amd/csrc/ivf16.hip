@@ -436,6 +436,7 @@ int launch_list16(fal_ctx* ctx, const List16Args& a) {
     FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
     StageScope ts(ctx, ST_SCAN);
+    StageScope tk(ctx, ST_KERNEL);
     switch (a.d / 16) {
         case 4: hipLaunchKernelGGL((list16_kernel<4>), grid, block, 0, ctx->stream, a); break;
         case 8: hipLaunchKernelGGL((list16_kernel<8>), grid, block, 0, ctx->stream, a); break;

@@ -220,6 +220,7 @@ int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a) {
     const bool shared = a.group_shift == 7;
     dim3 grid((unsigned)(per_xcd * 8)), block(shared ? 256 : 64);
     StageScope ts(ctx, ST_SCAN);
+    StageScope tk(ctx, ST_KERNEL);
 #define FAL_LAUNCH_LIST(DH4)                                                                       \
     do {                                                                                           \
         if (shared) hipLaunchKernelGGL(ivf_list4_kernel<DH4>, grid, block, 0, ctx->stream, a);     \

@@ -143,6 +143,7 @@ static int launch_dense_t(fal_ctx* ctx, int stage, const float* Q, const float* 
     FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
  dim3 grid((unsigned)(per_xcd * 8)), block(64);
     StageScope ts(ctx, stage);
+    StageScope tk(ctx, ST_KERNEL, nullptr, stage == ST_SCAN);      // (a second event pair for the fine scan only)
 #define FAL_LAUNCH_DENSE(DH4)                                                                              \
     hipLaunchKernelGGL((dense_kernel<DH4, EPI>), grid, block, 0, ctx->stream, Q, Cm, d, jobs, n_jobs,      \
                        tile_begin, n_tiles, sims, sims_base, assign, xcd_lists, symmetric)

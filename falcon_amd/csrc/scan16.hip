@@ -198,6 +198,7 @@ int launch_scan16(fal_ctx* ctx, int planes, const void* Xs, int d, const DenseJo
     dim3 grid((unsigned)(list_tiles * 8)), block(256);
     const __half* X = reinterpret_cast<const __half*>(Xs);
     StageScope ts(ctx, ST_SCAN);
+    StageScope tk(ctx, ST_KERNEL);
 #define FAL_LAUNCH16(S, P)                                                                                        \
     do {                                                                                                          \
         FAL_CHECK_HIP(hipFuncSetAttribute((const void*)scan16_kernel<S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, \

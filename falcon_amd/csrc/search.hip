@@ -194,6 +194,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     const int64_t n_buckets = (int64_t)ivf->n_list.size();
     ctx->stage_reset(ST_COARSE);
     ctx->stage_reset(ST_SCAN);
+    ctx->stage_reset(ST_KERNEL);
     ctx->stage_reset(ST_SELECT);
     // fallback queries of this call (fal_ctx_counter 5): reset in stream order -- a previous call's asynchronous copy into
     // the same pinned words may still be in flight

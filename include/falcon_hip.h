@@ -61,7 +61,8 @@ int fal_ctx_sync(fal_ctx* ctx);
 /* Elapsed milliseconds (HIP events on the context's stream) of the kernels the LAST
  * call of the named stage enqueued; used by bench.py for the roofline figure.
  * stage: 0 vectorize, 1 kmeans/ivf build, 2 coarse probe, 3 fine scan (cosine kernel),
- * 4 top-k select, 5 filter, 6 dbscan, 7 tail. */
+ * 4 top-k select, 5 filter, 6 dbscan, 7 tail, 8 the launches of the cosine kernel alone (dense_kernel /
+ * scan16_kernel / list16_kernel / ivf_list4_kernel; a subset of stage 3: the exact pair chains are not in it). */
 int fal_ctx_stage_ms(fal_ctx* ctx, int stage, float* ms, int64_t* launches);
 int fal_ctx_enable_timing(fal_ctx* ctx, int on);
 /* Work counters of the LAST fal_ivf_search_topk on this context (for roofline accounting):

@@ -1,0 +1,29 @@
+#!/bin/bash
+# The round's measurement run on the GPU box: bench (default command), kernel traces of the headline steps in both partition
+# schedules (one stream / two streams), the 10 M float32 kernel trace.  Outputs under gpurun_out/ (copy to profiles/).
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out
+timeout 1200 python bench.py > $O/r3_bench.txt 2>&1
+grep '^{' $O/r3_bench.txt | tail -1 > $O/r3_bench_1M.json
+rm -rf $O/p_trace
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 bench.py --partitions pipelined --no-configs --no-cpu-baseline > $O/r3_bench_pipelined_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r3_bench_1M_pipelined_kernel_stats.csv
+grep '^{' $O/r3_bench_pipelined_under_rocprof.txt | tail -1 > $O/r3_bench_1M_pipelined_under_rocprof.json
+rm -rf $O/p_trace
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 bench.py --no-configs --no-cpu-baseline > $O/r3_bench_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r3_bench_1M_kernel_stats.csv
+grep '^{' $O/r3_bench_under_rocprof.txt | tail -1 > $O/r3_bench_1M_under_rocprof.json
+rm -rf $O/p_trace
+python3 - <<'PY'
+import json
+j = json.load(open('gpurun_out/r3_bench_1M.json'))
+print('value', j['value'], j['ms_per_step'], j['stage_ms'], j.get('value_host_to_host'), j.get('ms_per_step_host_to_host_latency'))
+print('roofline', {k: j['roofline'][k] for k in ('bound', 'frac', 'avg_launch_ms', 'traffic')})
+for c in j.get('configs', []):
+    print(c.get('dtype'), c.get('ms_per_step'), c.get('stage_ms'), c.get('error'), {k: c['roofline'][k] for k in ('bound', 'frac', 'avg_launch_ms')} if 'roofline' in c else None)
+print(j.get('cpu_baseline'))
+j = json.load(open('gpurun_out/r3_bench_1M_pipelined_under_rocprof.json')); print('pipelined under rocprof', j['value'], j['roofline']['avg_launch_ms'])
+PY
+grep "dense_kernel<50, 0>" $O/r3_bench_1M_pipelined_kernel_stats.csv | cut -c1-60,170-260
+grep "dense_kernel<50, 0>" $O/r3_bench_1M_kernel_stats.csv | cut -c1-60,170-260
