@@ -342,21 +342,36 @@ def main():
             step(upload()[0], run_args)
         torch.cuda.synchronize()
         h2h_latency = (time.perf_counter() - t0) / k2
-        # a stream of datasets: the upload of step i + 1 (copy stream, PCIe) under the kernels of step i
-        nxt = upload(copy_stream)
+        # a stream of datasets: the upload of step i + 1 (copy stream, PCIe) under the kernels of step i, into two sets of
+        # device buffers used in turn (no allocation inside the loop)
+        slots = [[[torch.empty_like(t, device=dev) for t in ts] for ts in pinned] for _ in range(2)]
+        free_ev = [None, None]                                # compute of the step that last read slot b has been enqueued ...
+
+        def upload_into(b):
+            with torch.cuda.stream(copy_stream):
+                if free_ev[b] is not None:
+                    copy_stream.wait_event(free_ev[b])        # ... and finished, before the slot is overwritten
+                for dst, src in zip(slots[b], pinned):
+                    for d_t, s_t in zip(dst, src):
+                        d_t.copy_(s_t, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return [SpectrumDataset(*ts) for ts in slots[b]], ev
+
+        nxt = upload_into(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(k2):
             cur, ev = nxt
             torch.cuda.current_stream(dev).wait_event(ev)
-            for ds in cur:                                    # (allocated on the copy stream, used on the compute streams)
-                for t in (ds.precursor_mz, ds.retention_time, ds.mz, ds.intensity, ds.indptr):
-                    t.record_stream(torch.cuda.current_stream(dev))
             if i + 1 < k2:
-                nxt = upload(copy_stream)
-            step(cur, run_args)
+                nxt = upload_into((i + 1) & 1)
+            step(cur, run_args)                               # (ends with the labels on the host: every kernel of it is done)
+            free_ev[i & 1] = torch.cuda.Event()
+            free_ev[i & 1].record(torch.cuda.current_stream(dev))
         torch.cuda.synchronize()
         h2h = (time.perf_counter() - t0) / k2
+        del slots
         del pinned, nxt, cur
 
     def summarize(stages, d, p, elem):
