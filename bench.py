@@ -470,9 +470,14 @@ def main():
                 "dtype": name.split("-")[0]}
             if sc is not None:
                 entry.update({"stage_ms": sc["stage_ms"], "pairs_per_step": sc["pairs"]})
-                if name == "f16":
+                if name == "f16" and not pc.f16_index:
                     entry["roofline"] = roofline_of(sc, "scan16_kernel<50,1> (f16 MFMA 32x32x16, LDS-staged candidates, exhaustive)",
-                                                    PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense", "10M_f16")
+                                                    PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense", None)
+                elif name == "f16":
+                    entry["roofline"] = roofline_of(
+                        sc, "list16_kernel<50> (f16 MFMA 32x32x16, list-major; float16 vectors: n_probe lists per query through the "
+                            "k-means index, exact float32 chains over the vectors' images)", PEAK_MFMA_F16_TFLOPS,
+                        "f16 MFMA 2.5 PFLOP/s dense", "10M_f16")
                 elif args.no_ivf_prefilter:
                     entry["roofline"] = roofline_of(sc, "ivf_list4_kernel<50> (fp32 MFMA 32x32x2, list-major)",
                                                     PEAK_MFMA_F32_TFLOPS, "fp32 MFMA 157.3 TFLOP/s", None)

@@ -19,6 +19,7 @@ from .. import device as _device
 
 logger = logging.getLogger("falcon")
 
+F16_INDEX_DIMS = (64, 128, 256, 400, 800)   # low_dim values the float16 index kernels (assign16 / list16) are instantiated for
 FLAT_MAX = 100           # buckets up to this size use a flat (single list) index
 MIN_PTS_PER_LIST = 39    # [SURVEY App. A] Faiss' minimum points per centroid
 MAX_N_LIST = 1 << 17
@@ -37,7 +38,13 @@ class AnnParams:
     hash_seed: int = 0
     min_mz: float = 101.0
     max_mz: float = 1500.0
-    dtype: str = "f32"            # "f32", or "f16": float16 vectors + f16 MFMA scan (BASELINE config 5)
+    dtype: str = "f32"            # "f32", or "f16": float16 vectors (BASELINE config 5).  The similarity of two float16 vectors is
+                                  # the float32 fmaf chain over their (exact) float32 images: buckets with an index run the
+                                  # float32 IVF path on the images with the float16 rows as prefilter copies -- bit-identical to
+                                  # the oracle's "round to float16, then the float32 path"; flat buckets are scanned on the f16
+                                  # matrix cores (float32 accumulation, within 2e-6 of the chain)
+    f16_index: bool = True        # dtype "f16": buckets with n_list > n_probe get their k-means index (README.md:107-113); off =
+                                  # every bucket exhaustively on the f16 matrix cores (the round-2 behaviour)
     scan: str = "f32"             # flat-bucket scan arithmetic for float32 vectors: "f32" (exact fp32 MFMA) or
                                   # "f16x3" (hi/lo float16 split, 3 f16 MFMAs per step, ~3e-7 absolute error)
     prefilter: bool = False       # float32 flat buckets: keep the top-k on chip (f16-MFMA prefilter + exact float32
@@ -119,9 +126,9 @@ class ClusterPipeline:
         rts = c.gather_f32(ds.retention_time, order) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
         n_list = n_list_rule(np.diff(splits), p.n_probe)
-        if p.dtype == "f16":
-            # float16 vectors (BASELINE config 5): no float32 rows to train an index on, and the f16 matrix cores
-            # scan a whole bucket faster than the fp32 path runs k-means on it -- every bucket is searched exhaustively
+        if p.dtype == "f16" and not (p.f16_index and p.low_dim in F16_INDEX_DIMS):
+            # float16 vectors without an index (AnnParams.f16_index off, or a low_dim the index kernels are not instantiated
+            # for): every bucket is searched exhaustively on the f16 matrix cores -- a superset of what n_probe lists find
             n_list[:] = 1
         return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list)
 
@@ -159,7 +166,14 @@ class ClusterPipeline:
                                      p.hash_seed, True, dt)
         X = X16 = Xpre = Xkm = None
         which = 0
-        if p.dtype == "f16":
+        if p.dtype == "f16" and not all_flat:
+            # float16 vectors with an index: the exact kernels (k-means close calls, coarse quantiser, pair chains) work on the
+            # float32 image of the rounded rows, the float16 rows themselves are every prefilter copy AND the flat buckets' scan
+            X, X16 = vec("f16+image")
+            Xkm = X16 if p.kmeans_prefilter else None
+            if p.ivf_prefilter and not keep_intermediates:
+                which, Xpre = 2, X16
+        elif p.dtype == "f16":
             X16 = vec("f16")
         elif p.scan == "f16x3":
             X16 = vec("split16")
@@ -212,7 +226,8 @@ class ClusterPipeline:
             # production: a9..a12 fused, counts stay on the device, one synchronisation
             labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
                                                     precursor_tol_mode, rt_tol, order, linkage=hier)
-            last = dict(nb_idx=nb_idx, nb_dist=nb_dist, nb_count=st["nb_count"], order=order, n_list=st["n_list"])   # the sparse graph (exchange)
+            last = dict(nb_idx=nb_idx, nb_dist=nb_dist, nb_count=st["nb_count"], order=order, n_list=st["n_list"],
+                        splits=st["splits"])                          # the sparse graph (exchange) + the bucket table
             index.close()
         return labels, medoids, last
 

@@ -62,14 +62,14 @@ struct Assign16Args {
 __device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
 
 template <int STEPS, bool KEYS, bool PARTIAL>
-__global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
+__global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void assign16_kernel(Assign16Args a) {
     constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int RB16 = D / 8;
     constexpr int RS = D * 2 + 16;
     constexpr int PIECES = 32 * RB16;
     constexpr int kStage = (PIECES + 255) / 256;
     constexpr int NB = STEPS < 4 ? STEPS : 4;
-    static_assert(kStage <= 7, "staging registers");
+    static_assert(kStage <= 13, "staging registers");      // (low_dim 800: 13 x 16 bytes per thread and chunk, one workgroup per CU)
     __shared__ __align__(16) unsigned char stage[2 * 32 * RS];
     __shared__ float r_best[2][4][32];       // per chunk parity, wave, row: best / runner-up value and best id
     __shared__ float r_second[2][4][32];
@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256, 2) void assign16_kernel(Assign16Args a) {
         for (int s = 0; s < STEPS; ++s) c16[s] = src[s];
     }
     const __half* rbase = a.X16 + job.row0 * (int64_t)D;
-    uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6;
-#define FAL_FOR_A(M) M(0, sa0) M(1, sa1) M(2, sa2) M(3, sa3) M(4, sa4) M(5, sa5) M(6, sa6)
+    uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sa7, sa8, sa9, sa10, sa11, sa12;
+#define FAL_FOR_A(M) M(0, sa0) M(1, sa1) M(2, sa2) M(3, sa3) M(4, sa4) M(5, sa5) M(6, sa6) M(7, sa7) M(8, sa8) M(9, sa9) \
+    M(10, sa10) M(11, sa11) M(12, sa12)
 #define FAL_LOAD_ONE(I, R)                                                                             \
     if constexpr (I < kStage) {                                                                        \
         const int idx = min((int)threadIdx.x + 256 * I, PIECES - 1);                                   \
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void assign16_merge_kernel(Assign16Args a, int
     }
 }
 
-bool assign16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
+bool assign16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400 || d == 800; }
 
 int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
     if (count <= 0) return FAL_OK;
@@ -422,6 +423,7 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
             case 8: FAL_LAUNCH_A16(8); break;
             case 16: FAL_LAUNCH_A16(16); break;
             case 25: FAL_LAUNCH_A16(25); break;
+            case 50: FAL_LAUNCH_A16(50); break;
             default: set_error("assign16: low_dim %d has no instantiation", d); return FAL_EUNSUPPORTED;
         }
         return FAL_OK;

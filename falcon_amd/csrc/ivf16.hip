@@ -64,8 +64,10 @@ __device__ __forceinline__ uint16_t key16(float v) {
 //     metadata of chunk c + 3.
 // ------------------------------------------------------------------------------------------------------------
 template <int STEPS>
-__global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
+__global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16Args a) {
     constexpr int D = STEPS * 16, DH = D / 2;
+    constexpr int RD = (D / 8 + 63) / 64;                 // DMA instructions per row (64 x 16 bytes each): 2 for low_dim 800
+    constexpr int kRowOps = 8 * RD;                       // row DMAs per step and wave
     constexpr int NB = STEPS < 4 ? STEPS : 4;             // LDS operand reads in flight ahead of the MFMAs
     constexpr int RS = D * 2 + 16;                        // LDS row stride in bytes
     __shared__ __attribute__((aligned(16))) unsigned char sbuf0[32 * RS];
@@ -124,12 +126,16 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
         uint32_t rows[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) rows[i] = min((uint32_t)__builtin_amdgcn_readlane(ids, 8 * w + i), row_max);
-        if (lane < D / 8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const void* g = reinterpret_cast<const uint4*>(a.Xl16 + (int64_t)rows[i] * D) + lane;
-                const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lb + (uint32_t)(8 * w + i) * (uint32_t)RS));
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+        for (int part = 0; part < RD; ++part) {
+            if (lane + 64 * part < D / 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const void* g = reinterpret_cast<const uint4*>(a.Xl16 + (int64_t)rows[i] * D) + lane + 64 * part;
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)(lb + (uint32_t)(8 * w + i) * (uint32_t)RS + (uint32_t)(1024 * part)));
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+                }
             }
         }
     };
@@ -178,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
     // was the computation of chunk c - 1), the metadata DMA of chunk c + 3 to the ring
 #define FAL_STEP(CUR, FILL, C)                                                                             \
     {                                                                                                      \
-        if (active) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                      \
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                              \
+        if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps + 16) : "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps) : "memory");                                \
         __builtin_amdgcn_s_barrier();                                                                      \
         asm volatile("" ::: "memory");                                                                     \
         issue_meta((C) + 3);                                                                               \
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void list16_kernel(List16Args a) {
     asm volatile("" ::: "memory");
     issue_rows(0, sbuf0);
     issue_rows(1, sbuf1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // chunk 0 has landed (the first step's own wait is a no-op)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps) : "memory");       // chunk 0 has landed (the first step's own wait is a no-op)
     const int n_chunks = (nq + 31) >> 5;
     for (int c = 0;; c += 3) {
         FAL_STEP(sbuf0, sbuf2, c)
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256) void gather_rows16_kernel(const __half* __rest
     }
 }
 
-bool ivf16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
+bool ivf16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400 || d == 800; }
 
 int launch_gather16(fal_ctx* ctx, const void* X16, const int32_t* perm, int64_t n, int d, void* out, int32_t* pos_of_row) {
     if (n <= 0) return FAL_OK;
@@ -430,11 +436,12 @@ int launch_gather16(fal_ctx* ctx, const void* X16, const int32_t* perm, int64_t 
     return FAL_OK;
 }
 
-int launch_list16(fal_ctx* ctx, const List16Args& a) {
-    if (a.n_tiles_max <= 0) return FAL_OK;
-    const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
+int launch_list16(fal_ctx* ctx, const List16Args& a_in) {
+    if (a_in.n_tiles_max <= 0) return FAL_OK;
+    const int64_t per_xcd = (a_in.n_tiles_max + 7) / 8;
     FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
+    const List16Args& a = a_in;
     StageScope ts(ctx, ST_SCAN);
     StageScope tk(ctx, ST_KERNEL);
     switch (a.d / 16) {
@@ -442,6 +449,7 @@ int launch_list16(fal_ctx* ctx, const List16Args& a) {
         case 8: hipLaunchKernelGGL((list16_kernel<8>), grid, block, 0, ctx->stream, a); break;
         case 16: hipLaunchKernelGGL((list16_kernel<16>), grid, block, 0, ctx->stream, a); break;
         case 25: hipLaunchKernelGGL((list16_kernel<25>), grid, block, 0, ctx->stream, a); break;
+        case 50: hipLaunchKernelGGL((list16_kernel<50>), grid, block, 0, ctx->stream, a); break;
         default:
             set_error("IVF prefilter: low_dim %d has no instantiation (64, 128, 256, 400)", a.d);
             return FAL_EUNSUPPORTED;

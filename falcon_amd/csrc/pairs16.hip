@@ -440,10 +440,11 @@ int launch_kept16(fal_ctx* ctx, const Kept16Args& a_in, int64_t n_tiles) {
 int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32) {
     if (list_tiles32 <= 0) return FAL_OK;
     StageScope ts(ctx, ST_SCAN);
-    if (a.sp_cols != nullptr && a.sp_vals != nullptr && d <= 512) {
+    if (a.sp_cols != nullptr && a.sp_vals != nullptr && d <= 832) {        // (32 query rows of d floats + 28 KB must fit 160 KB of LDS)
         const size_t lds = (size_t)32 * d * 4 + 4 * 64 * 112 + 34 * 4;
         // (per launch: the attribute is per device, and two partition threads may launch at once)
-        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)pairs16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)pairs16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)std::max<size_t>(96 * 1024, lds)));
         hipLaunchKernelGGL(pairs16s_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), lds, ctx->stream, a, d);
     } else {
         hipLaunchKernelGGL(pairs16_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);

@@ -276,7 +276,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     std::vector<FlatBatch> flat_batches;
     size_t need_flat = 0;
     const bool have16 = ivf->X16 != nullptr;
-    const int64_t thr16 = ivf->X ? 64 : 0;           // without float32 rows everything takes the f16 kernel
+    const int64_t thr16 = (ivf->X && d <= 512) ? 64 : 0;   // without float32 rows (or beyond the fp32 kernel's low_dim) everything takes the f16 kernel
     FAL_REQUIRE(have16 || ivf->X || border.empty(), FAL_EINVAL, "fal_ivf_search_topk: the index has no vectors to scan");
     {
         FlatBatch cur{0, 0, 0, 0, 0, 0, 0};

