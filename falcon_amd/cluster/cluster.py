@@ -132,6 +132,40 @@ class ClusterPipeline:
             n_list[:] = 1
         return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list)
 
+    def _front_windows(self, c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p, shard):
+        """The front end of ONE rank of a job that shares a dataset among `world` GPUs, without the replicated
+        sort: buckets never cross a precursor window floor(mz / mz_interval) and a window's buckets depend on its own spectra
+        only (`fal_precursor_splits`), so whole WINDOWS are the unit that is dealt out.  Every rank histograms the window of
+        every spectrum (one pass over 4 bytes per spectrum), derives the same deal from the counts
+        (`distributed.window_costs` / `deal_units`), and sorts / buckets only its own spectra.  The buckets -- hence neighbour
+        lists and clusters -- are exactly those of the single-GPU pass.  Reference analogue: blocks are clustered
+        independently and only their labels are offset afterwards (cluster.py:107-155).
+        -> the state `_restrict` returns: order = rows = dataset rows of this rank's spectra in precursor order, ..."""
+        import torch
+        from .. import distributed as fdist
+        rank, world = shard
+        pmz = c.to_dev(ds.precursor_mz, torch.float32)
+        n = int(pmz.numel())
+        win = torch.floor(pmz.double() / float(p.mz_interval)).to(torch.int64)     # (the arithmetic of split_flags_kernel)
+        lo, hi = (int(x) for x in torch.aminmax(win)[0:2]) if n else (0, 0)
+        win -= lo
+        counts = torch.bincount(win, minlength=hi - lo + 1).cpu().numpy()
+        owner = fdist.deal_units(fdist.window_costs(counts, batch_size, p.n_probe), world)
+        mine = c.to_dev(owner == rank, torch.bool)[win]
+        rows = torch.nonzero(mine).flatten()                                         # ascending dataset rows: the sort stays stable
+        if rows.numel() == 0:
+            e = rows.new_zeros(0)
+            return dict(order=e, mzs=pmz[:0], rts=None, splits=np.zeros(1, np.int64), n_list=np.zeros(0, np.int32), rows=e,
+                        n_total=n)
+        order_sub, mzs = c.sort_by_precursor(pmz[rows])
+        rows_sorted = rows[order_sub]
+        rts = c.gather_f32(ds.retention_time, rows_sorted) if (rt_tol is not None and ds.retention_time is not None) else None
+        splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
+        n_list = n_list_rule(np.diff(splits), p.n_probe)
+        if p.dtype == "f16" and not (p.f16_index and p.low_dim in F16_INDEX_DIMS):
+            n_list[:] = 1
+        return dict(order=rows_sorted, mzs=mzs, rts=rts, splits=splits, n_list=n_list, rows=rows_sorted, n_total=n)
+
     def _restrict(self, c, st, p, shard):
         """One dataset on several GPUs (reference analogue: blocks are clustered independently and only
         their labels are offset afterwards, cluster.py:115-155).  Every rank derived the SAME buckets in `_front`;
@@ -268,9 +302,13 @@ class ClusterPipeline:
 
         def front(i):
             with torch.cuda.stream(self._front_stream):
-                st = self._front(self._front_ctx, datasets[i], *args, batch_size, p)
+                if sharded and p.mz_interval and p.mz_interval > 0:
+                    st = self._front_windows(self._front_ctx, datasets[i], *args, batch_size, p, shard)
+                else:
+                    st = self._front(self._front_ctx, datasets[i], *args, batch_size, p)
+                    if sharded:                                                # no windows: whole buckets of the sorted dataset
+                        st = self._restrict(self._front_ctx, st, p, shard)
                 if sharded:
-                    st = self._restrict(self._front_ctx, st, p, shard)
                     # labels refer to the subset's own rows; `rows` maps them to dataset rows
                     st["order"] = torch.arange(st["rows"].numel(), dtype=torch.int64, device=c.tdev)
                 states[i] = st

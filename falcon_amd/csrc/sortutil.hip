@@ -284,19 +284,19 @@ int fal_precursor_splits(fal_ctx* ctx, const float* mz, int64_t n, double tol, i
         for (int64_t c = 0; c < block % n_chunks; ++c) splits.push_back(splits.back() + chunk + 1);
         for (int64_t c = 0; c < n_chunks - (block % n_chunks); ++c) splits.push_back(splits.back() + chunk);
     };
+    // [build rule] fixed windows: the reference's rule runs INSIDE every window floor(mz / mz_interval) -- a window boundary
+    // ends a block like a gap does, and the chunk rule applies to the window's last block too -- so the buckets of a window
+    // depend on that window's spectra alone (what lets GPUs take whole windows without seeing the rest of the dataset).
+    // Without windows (mz_interval = 0) this is cluster.py:183-208 unchanged (+ the chunked last block).
     for (size_t g = 0; g < gap_idx.size(); ++g) {
-        if (!(gap_flag[g] & 1)) continue;
         const int64_t i = gap_idx[g], block = i - splits.back();
-        if (block < batch_size) splits.push_back(i); else chunk_block(block);
+        const bool window_end = (gap_flag[g] & 2) != 0;      // = the end of the array the reference's loop sees
+        if (block < batch_size || (window_end && !chunk_last)) splits.push_back(i);
+        else chunk_block(block);
     }
     if (chunk_last && n - splits.back() >= batch_size) chunk_block(n - splits.back());   // [build rule]
     if (splits.back() != n || n == 0) splits.push_back(n);
-    // [build rule] fixed windows
     std::vector<int64_t> all(splits);
-    for (size_t g = 0; g < gap_idx.size(); ++g)
-        if (gap_flag[g] & 2) all.push_back(gap_idx[g]);
-    std::sort(all.begin(), all.end());
-    all.erase(std::unique(all.begin(), all.end()), all.end());
     FAL_REQUIRE((int64_t)all.size() <= max_splits, FAL_EINVAL, "fal_precursor_splits: %zu boundaries do not fit max_splits %lld",
                 all.size(), (long long)max_splits);
     memcpy(splits_out, all.data(), sizeof(int64_t) * all.size());

@@ -191,9 +191,21 @@ def bucket_splits(precursor_mzs: np.ndarray, tol: float, mode: str, batch_size: 
                   mz_interval: float = 1.0, chunk_last: bool = True) -> np.ndarray:
     """Bucket boundaries the ANN path uses = reference splits (above)
     + [build rule] the same chunk formula applied to the last block too
-    + [build rule, SURVEY 8(d)] fixed precursor windows floor(mz / mz_interval)."""
+    + [build rule, SURVEY 8(d)] fixed precursor windows floor(mz / mz_interval), the two rules above applied inside
+      every window (round 3; before, the reference rule ran over the whole array and the window cuts were added to it:
+      the two differ only where a gap-free run of >= batch_size spectra crosses a window boundary)."""
     mz = np.asarray(precursor_mzs, f32)
     n = len(mz)
+    if mz_interval and mz_interval > 0 and n > 1:
+        # [build rule] fixed precursor windows: the reference's rule (+ the chunked last block) runs INSIDE every window, so a
+        # window's buckets depend on its own spectra only (the unit the multi-GPU job deals out, SURVEY 8e)
+        w = np.floor(mz.astype(f64) / f64(mz_interval))
+        edges = np.concatenate([[0], np.flatnonzero(w[1:] != w[:-1]) + 1, [n]])
+        if len(edges) > 2:
+            cuts = set()
+            for a, b in zip(edges[:-1], edges[1:]):
+                cuts.update(int(a) + int(x) for x in bucket_splits(mz[a:b], tol, mode, batch_size, 0.0, chunk_last))
+            return np.asarray(sorted(cuts), np.int64)
     base = get_precursor_mz_splits(mz, tol, mode, batch_size)
     cuts = set(int(x) for x in base)
     if chunk_last and len(base) >= 2:

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 export PYTHONPATH=$R
 rm -rf /tmp/prof_shard
-rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -o shard -- python3 $R/tools/shard_share.py ${1:-8} 1000000 0 > /tmp/o.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_shard -o shard -- python3 $R/tools/shard_share.py ${1:-8} ${2:-1250000} 0 > /tmp/o.txt 2>&1
 grep "^rank" /tmp/o.txt
 python3 $R/profiles/summarize.py stats /tmp/prof_shard/shard_results.db /tmp/k.csv
 cp /tmp/k.csv $R/gpurun_out/shard${1:-8}_rank0_kernel_stats.csv
