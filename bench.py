@@ -143,7 +143,7 @@ def main():
                     help="how the two charge partitions of a step are scheduled: concurrent = a host thread + HIP stream + context "
                          "each (PartitionRunner; the reference clusters its blocks on a thread pool, cluster.py:115-136), pipelined = "
                          "one stream, the next partition's sort under the current scan (ClusterPipeline.run_many); auto = concurrent "
-                         "while the buckets are flat (the 1 M-per-GPU workloads), pipelined in the IVF regime (10 M and beyond)")
+                         "(the 50 M configuration runs its bucket shares pipelined: ClusterPipeline.run_chunked)")
     ap.add_argument("--serial", action="store_true",
                     help="run the charge partitions strictly one after the other (default: software-pipelined, "
                          "ClusterPipeline.run_many)")
@@ -220,8 +220,7 @@ def main():
     exchanging = args.exchange != "none" and (world > 1 or args.force_exchange)
     exchange = fdist.SparseGraphExchange(dev)
     pending, csr_buf = [], {}
-    # spectra per 1 m/z window and charge-2 partition: beyond ~1,600 the windows get an index (n_list > n_probe) -- the regime
-    # in which two concurrent partitions evict each other's L2-resident lists (tools/concurrent_parts.py: 2.4x slower at 10 M)
+    # spectra per 1 m/z window and charge-2 partition: beyond ~1,600 the windows get an index (n_list > n_probe)
     ivf_regime = 0.7 * n_total / max(mz_hi - mz_lo, 1.0) > 1600
 
     def collect_stages(n):
@@ -310,7 +309,9 @@ def main():
         ctx.enable_timing(False)
         return stages
 
-    want_concurrent = args.partitions == "concurrent" or (args.partitions == "auto" and not ivf_regime and not args.serial)
+    # two charge partitions on concurrent streams win in both regimes once the pools are warm (tools/concurrent_parts.py: 1 M
+    # 6.0 vs 6.7 ms, 10 M 137 vs 145 ms; a rank's share of the 10 M job at 8 GPUs 19.9 vs 23.9 ms, tools/shard_share.py)
+    want_concurrent = args.partitions == "concurrent" or (args.partitions == "auto" and not args.serial)
     if want_concurrent:
         runner = PartitionRunner(local_rank, 2)
         concurrent["on"] = True
@@ -426,8 +427,6 @@ def main():
         del parts
         torch.cuda.empty_cache()
         was_concurrent = concurrent["on"]
-        if args.partitions == "auto":
-            concurrent["on"] = False          # IVF regime: two concurrent partitions lose (tools/concurrent_parts.py)
         plan = [("f32", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 1200.0, 1),
                 ("f16", args.configs_spectra, dict(low_dim=800, dtype="f16", scan="f32"), 1200.0, 1),
                 # BASELINE configs[3]'s bucket regime on one GPU: the same number of spectra in a quarter of the precursor
@@ -449,7 +448,7 @@ def main():
             ra = (20.0, "ppm", None, 0.05, args.batch_size, pc)
             steps_c = 3 if chunks == 1 else 2
             try:
-                dtc = timed(big, ra, steps_c, 1, prime=1, chunks=chunks)
+                dtc = timed(big, ra, steps_c, 1, prime=2, chunks=chunks)
                 sc = None
                 if chunks == 1:
                     sc = summarize(staged(big, ra), pc.low_dim, pc, 2 if name == "f16" else 4)

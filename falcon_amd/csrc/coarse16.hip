@@ -27,8 +27,8 @@ namespace fal {
 
 // KPL keys per lane (8: buckets with <= 128 lists, 32: <= 512), 16 lanes per query, QPW queries per workgroup
 // (the workgroup-level form: every query keeps room for ALL its keys as members.  It serves the queries coarse16w_kernel
-// hands over -- more than 16 members: many equal similarities --, or everything with FALCON_COARSE16_WG.)
-template <int KPL, int QPW, bool LIST>
+// hands over -- more than 16 members: many equal similarities.)
+template <int KPL, int QPW>
 __global__ __launch_bounds__(16 * QPW) void coarse16_kernel(Coarse16Args a) {
     constexpr int kMem = 16 * KPL;                         // members a query can hold (every key, in the worst case)
     constexpr int kThreads = 16 * QPW;
@@ -37,10 +37,10 @@ __global__ __launch_bounds__(16 * QPW) void coarse16_kernel(Coarse16Args a) {
     __shared__ int32_t q_cnt[QPW];
     __shared__ int64_t q_row[QPW], q_cbase[QPW];
     const int tid = threadIdx.x, lane = tid & 63, grp = lane >> 4, sub = lane & 15, qw = tid >> 4;
-    const int64_t n_items = LIST ? (int64_t)min(*a.ovf_count, a.ovf_cap) : 32 * a.n_tiles;
+    const int64_t n_items = (int64_t)min(*a.ovf_count, a.ovf_cap);
   for (int64_t item0 = (int64_t)blockIdx.x * QPW; item0 < n_items; item0 += (int64_t)gridDim.x * QPW) {
     const int64_t item = item0 + qw;
-    const int64_t g = LIST ? (item < n_items ? (int64_t)a.ovf_list[item] : (int64_t)-1) : item;   // tile-order slot of the group's query
+    const int64_t g = item < n_items ? (int64_t)a.ovf_list[item] : (int64_t)-1;   // tile-order slot of the group's query
     const int64_t t = g >> 5;
     const int ql = (int)(g & 31);
     bool live = g >= 0 && t < a.n_tiles;
@@ -323,20 +323,13 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
     a.ovf_list = a.ovf_count + 16;
     a.ovf_cap = (int)std::min<int64_t>(32 * a.n_tiles, INT32_MAX);
     FAL_CHECK_HIP(hipMemsetAsync(a.ovf_count, 0, sizeof(int32_t), ctx->stream));
-    static const bool wg_form = getenv("FALCON_COARSE16_WG") != nullptr;      // (A/B runs: the workgroup-level kernel for everything)
     const unsigned list_grid = (unsigned)std::min<int64_t>(a.n_tiles * 4, (int64_t)ctx->num_cus * 16);
     if (a.stride <= 128) {
-        if (wg_form) hipLaunchKernelGGL((coarse16_kernel<8, 16, false>), dim3((unsigned)(a.n_tiles * 2)), dim3(256), 0, ctx->stream, a);
-        else {
-            hipLaunchKernelGGL((coarse16w_kernel<8>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
-            hipLaunchKernelGGL((coarse16_kernel<8, 16, true>), dim3(list_grid), dim3(256), 0, ctx->stream, a);
-        }
+        hipLaunchKernelGGL((coarse16w_kernel<8>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((coarse16_kernel<8, 16>), dim3(list_grid), dim3(256), 0, ctx->stream, a);
     } else {
-        if (wg_form) hipLaunchKernelGGL((coarse16_kernel<32, 8, false>), dim3((unsigned)(a.n_tiles * 4)), dim3(128), 0, ctx->stream, a);
-        else {
-            hipLaunchKernelGGL((coarse16w_kernel<32>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
-            hipLaunchKernelGGL((coarse16_kernel<32, 8, true>), dim3(list_grid), dim3(128), 0, ctx->stream, a);
-        }
+        hipLaunchKernelGGL((coarse16w_kernel<32>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((coarse16_kernel<32, 8>), dim3(list_grid), dim3(128), 0, ctx->stream, a);
     }
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;

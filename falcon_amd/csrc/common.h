@@ -54,9 +54,6 @@ struct fal_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t aux = nullptr;            // second stream: top-k select of batch i under the scan of batch i+1
-    hipEvent_t ev_scan[2] = {nullptr, nullptr}, ev_sel[2] = {nullptr, nullptr};
-    int ensure_aux();
     void* pinned = nullptr;               // small pinned host staging buffer (single-sync readbacks)
     size_t pinned_cap = 0;
     int pinned_reserve(size_t bytes, void** out);

@@ -92,16 +92,6 @@ int fal_ctx::upload(void* dst, const void* src, size_t bytes) {
     return FAL_OK;
 }
 
-int fal_ctx::ensure_aux() {
-    if (aux) return FAL_OK;
-    FAL_CHECK_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-        FAL_CHECK_HIP(hipEventCreateWithFlags(&ev_scan[i], hipEventDisableTiming));
-        FAL_CHECK_HIP(hipEventCreateWithFlags(&ev_sel[i], hipEventDisableTiming));
-    }
-    return FAL_OK;
-}
-
 int fal_ctx::stage_begin(int stage, hipEvent_t* stop_out, hipStream_t on) {
     StageTimer& t = timers[stage];
     if (t.used == t.ev.size()) {
@@ -194,14 +184,6 @@ int fal_ctx_destroy(fal_ctx* c) {
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
-    if (c->aux) {
-        (void)hipStreamSynchronize(c->aux);
-        (void)hipStreamDestroy(c->aux);
-        for (int i = 0; i < 2; ++i) {
-            (void)hipEventDestroy(c->ev_scan[i]);
-            (void)hipEventDestroy(c->ev_sel[i]);
-        }
-    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FAL_OK;
@@ -229,7 +211,6 @@ int fal_ctx_counter(fal_ctx* c, int which, int64_t* value) {
 int fal_ctx_stage_ms(fal_ctx* c, int stage, float* ms, int64_t* launches) {
     FAL_REQUIRE(c && ms && stage >= 0 && stage < fal::kNumStages, FAL_EINVAL, "fal_ctx_stage_ms: bad argument");
     FAL_CHECK_HIP(hipStreamSynchronize(c->stream));
-    if (c->aux) FAL_CHECK_HIP(hipStreamSynchronize(c->aux));
     float total = 0.f;
     auto& t = c->timers[stage];
     for (size_t i = 0; i < t.used; ++i) {

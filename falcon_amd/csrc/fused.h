@@ -47,7 +47,6 @@ struct FusedArgs {
     int32_t* fb_list;            // (row, job) pairs of the queries left to the exact fallback
     int32_t* fb_count;
     int fb_cap;
-    int dbg;                     // FALCON_FUSED_DBG: experiment bits (results invalid when set)
     // IVF buckets (ivf16.hip): the candidates of a query are the rows of its probed lists; thr / gmem_* come from
     // select16_kernel instead of approx_kernel
     int ivf;                     // 1: jobs32 are IVF buckets (c_row0 = global id of the bucket's list 0); 2: the same, and the kept

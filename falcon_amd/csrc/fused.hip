@@ -120,7 +120,6 @@ __global__ __launch_bounds__(256, 2) void approx_kernel(FusedArgs a) {
     const int nqw = min(32, nc - 32 * tile32);      // <= 0: the wave only helps with staging
     const bool active = nqw > 0;
     const int qbase = 32 * tile32;                  // first query of this wave inside the bucket
-    const int dbg = a.dbg;
 
     unsigned char* whist = lds + kStageBytes + w * kWaveHist;                  // histogram, then the member lists
     unsigned char* wsmall = lds + kStageBytes + 4 * kWaveHist + w * kWaveSmall;
@@ -245,10 +244,10 @@ __global__ __launch_bounds__(256, 2) void approx_kernel(FusedArgs a) {
 
     // ---- pass 1: histogram of the approximate similarities ---------------------------------------------------------
     unsigned char* hrow_b = whist + r * kHistStride;
-    if (!(dbg & 256)) run_pass([&](int, float v, int, bool valid) {
+    run_pass([&](int, float v, int, bool valid) {
         const uint32_t b = bin_of(v);
         const uint32_t inc = (b & 1) ? 0x10000u : 1u;
-        atomicAdd(reinterpret_cast<unsigned*>(hrow_b + ((b >> 1) << 2)), (valid && !(dbg & 1)) ? inc : 0u);
+        atomicAdd(reinterpret_cast<unsigned*>(hrow_b + ((b >> 1) << 2)), valid ? inc : 0u);
     });
     // ---- the bin of the k-th best approximate value: suffix sums from the top, lane = query (reads in batches of 8:
     //      one wave per SIMD, every dependent LDS round trip is exposed) ------------------------------------------------
@@ -296,8 +295,8 @@ __global__ __launch_bounds__(256, 2) void approx_kernel(FusedArgs a) {
         int cnt = 0;
         float* mv = mem_v + r * kMemStride + h * kMemSlot;
         uint32_t* mi = mem_id + r * kMemStride + h * kMemSlot;
-        if (!(dbg & 512)) run_pass([&](int, float v, int c, bool valid) {
-            const bool hit = valid && v >= lo_q && v <= hi_q && !(dbg & 2);
+        run_pass([&](int, float v, int c, bool valid) {
+            const bool hit = valid && v >= lo_q && v <= hi_q;
             const int at = min(cnt, kMemHalf);
             mv[at] = v;
             mi[at] = (uint32_t)c;
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void approx_kernel(FusedArgs a) {
     __syncthreads();
     // ---- T~ = the (k - n_above)-th best approximate value inside bin b*: lane (r, h) tries the members of ITS half as
     //      pivots and ranks each against all members of the query (a handful); exact k-th value in [T~ - eps, T~ + eps] ----
-    if (!(dbg & 4)) {
+    {
         const int m0 = q_mcnt[r * 2], m1 = q_mcnt[r * 2 + 1];
         const int bstar = q_bstar[r], need = k - q_nabove[r];
         const float bhi = bin_hi(bstar);
@@ -812,10 +811,6 @@ static float float_le_bound(double tol, double scale) {
 
 int fused_prepare(fal_ctx* ctx, FusedArgs* ap, int64_t n_rows) {
     FusedArgs& a = *ap;
-    {
-        const char* e = getenv("FALCON_FUSED_DBG");
-        a.dbg = e ? atoi(e) : 0;
-    }
     a.tol_f = float_le_bound(a.tol, a.is_da ? 1.0 : 1e6);
     a.rt_f = float_le_bound(a.rt_tol, 1.0);
     // hand-off buffers, indexed by sorted row
@@ -842,22 +837,6 @@ int fused_prepare(fal_ctx* ctx, FusedArgs* ap, int64_t n_rows) {
 int launch_fused_ivf_tail(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32, int64_t max_cand) {
     if (a.n_jobs32 <= 0 || list_tiles32 <= 0) return FAL_OK;
     FAL_REQUIRE(list_tiles32 * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
-    const int steps = d / 16;
-    if (a.ivf != 2) {
-        StageScope ts(ctx, ST_SCAN);
-        dim3 grid((unsigned)(list_tiles32 * 8)), block(64);
-        const size_t lds = sizeof(uint32_t) * 32 * (size_t)a.mask_words;
-        switch (steps) {
-            case 4: hipLaunchKernelGGL((band_kernel<8, true>), grid, block, lds, ctx->stream, a); break;
-            case 8: hipLaunchKernelGGL((band_kernel<16, true>), grid, block, lds, ctx->stream, a); break;
-            case 16: hipLaunchKernelGGL((band_kernel<32, true>), grid, block, lds, ctx->stream, a); break;
-            case 25: hipLaunchKernelGGL((band_kernel<50, true>), grid, block, lds, ctx->stream, a); break;
-            default:
-                set_error("IVF prefilter: low_dim %d has no instantiation (64, 128, 256, 400)", d);
-                return FAL_EUNSUPPORTED;
-        }
-        FAL_CHECK_HIP(hipGetLastError());
-    }
     StageScope ts(ctx, ST_SELECT);
     hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
     FAL_CHECK_HIP(hipGetLastError());
@@ -891,11 +870,8 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
     float* scratch = nullptr;
     FAL_TRY(ctx->reserve(SLOT_FUSED2, sizeof(float) * (size_t)fb_grid * (size_t)stride, (void**)&scratch));
     const int steps = d / 16;
-    static const bool split = getenv("FALCON_FUSED_SPLIT_TIMERS") != nullptr;
-    if (split) { ctx->stage_reset(ST_BUILD); ctx->stage_reset(ST_FILTER); }
-      // experiments: approx -> build, band -> scan, resolve -> select, fallback -> filter
     {
-        StageScope ts(ctx, split ? ST_BUILD : ST_SCAN);
+        StageScope ts(ctx, ST_SCAN);
         if (a.n_jobs128 > 0 && list_tiles128 > 0) {
             const size_t lds = (size_t)32 * ((size_t)d * 2 + 16) + 4 * kWaveHist + 4 * kWaveSmall;
             dim3 grid((unsigned)(list_tiles128 * 8)), block(256);
@@ -935,7 +911,7 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
         FAL_CHECK_HIP(hipGetLastError());
     }
     {
-        StageScope ts(ctx, split ? ST_FILTER : ST_SELECT);
+        StageScope ts(ctx, ST_SELECT);
         SelectArgs sa{};
         sa.k = a.k;
         sa.f_pmz = a.pmz; sa.f_rt = a.rt; sa.f_tol = a.tol; sa.f_rt_tol = a.rt_tol; sa.f_is_da = a.is_da;

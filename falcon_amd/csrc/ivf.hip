@@ -532,7 +532,6 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         // Buckets with few lists (<= kAssignMaxLists) are assigned by the shared-stream kernel (assign.hip): jobs =
         // (row segment) x (group of <= 128 centroids).  Buckets with many lists keep the row-resident kernel, whose
         // 32-row tile is amortised over their many centroid chunks.
-        static const bool row_major = getenv("FALCON_ASSIGN_ROWMAJOR") != nullptr;    // force the row-resident form (A/B runs)
         constexpr int kAssignMaxLists = 512;
         std::vector<AssignJob> ajobs;
         std::vector<DenseJob> djobs;
@@ -541,17 +540,16 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         // segments leave most CUs idle -- aim for >= 4 workgroups per CU, between 256 and kAssignSeg rows
         int64_t work_rows = 0;
         for (const BucketDev& b : bk)
-            if (!row_major && b.n_list > 64 && b.n_list <= kAssignMaxLists) work_rows += (int64_t)b.n * ceil_div(b.n_list, kAssignGroup);
+            if (b.n_list > 64 && b.n_list <= kAssignMaxLists) work_rows += (int64_t)b.n * ceil_div(b.n_list, kAssignGroup);
         const int64_t seg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(work_rows, (int64_t)ctx->num_cus * 4 * 32) * 32));
         // buckets with one or two centroid tiles take one-wave jobs (a 4-wave workgroup would idle most of its waves)
         std::vector<AssignJob> wjobs;
         int64_t wave_rows = 0;
         for (const BucketDev& b : bk)
-            if (!row_major && b.n_list <= 64) wave_rows += (int64_t)b.n * ceil_div(b.n_list, 32);
+            if (b.n_list <= 64) wave_rows += (int64_t)b.n * ceil_div(b.n_list, 32);
         const int64_t wseg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(wave_rows, (int64_t)ctx->num_cus * 16 * 32) * 32));
         // buckets with <= 128 lists and float16 rows at hand: the prefiltered assignment (assign16.hip; identical results)
-        static const bool no_a16 = getenv("FALCON_NO_ASSIGN16") != nullptr;
-        const bool use16 = X16 != nullptr && assign16_supports(low_dim) && !no_a16 && !row_major && ivf->rows_signed == 0;
+        const bool use16 = X16 != nullptr && assign16_supports(low_dim) && ivf->rows_signed == 0;
         std::vector<AssignJob> hjobs, mjobs, gjobs;    // single-group jobs; merge jobs and their group jobs (129..512 lists)
         for (const BucketDev& b : bk) {
             if (use16 && b.n_list <= kAssignGroup) {
@@ -564,12 +562,12 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                     for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)      // the groups of a segment next to each other: they
                         gjobs.push_back({b.row0 + s0, b.list0 + t0, nr, std::min(kAssignGroup, b.n_list - t0), t0, 0});   // share its rows in L2
                 }
-            } else if (!row_major && b.n_list <= 64) {
+            } else if (b.n_list <= 64) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += wseg)
                     for (int t0 = 0; t0 < b.n_list; t0 += 32)
                         wjobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(wseg, b.n - s0),
                                          std::min(32, b.n_list - t0), t0, 0});
-            } else if (!row_major && b.n_list <= kAssignMaxLists) {
+            } else if (b.n_list <= kAssignMaxLists) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += seg)
                     for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)
                         ajobs.push_back({b.row0 + s0, b.list0 + t0, (int32_t)std::min<int64_t>(seg, b.n - s0),
@@ -621,8 +619,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                     B_TRY(launch_cvt_f16(ctx, ivf->centroids, C16, total * low_dim));
                 }
                 // the final pass leaves its approximate similarities behind for the coarse quantiser (coarse16.hip)
-                static const bool no_ckeys = getenv("FALCON_NO_COARSE16") != nullptr;
-                if (it == kmeans_iters && !no_ckeys && djobs.empty() && ajobs.empty()) {
+                if (it == kmeans_iters && djobs.empty() && ajobs.empty()) {
                     int max_nl = 0;
                     for (const BucketDev& b : bk) max_nl = std::max(max_nl, (int)b.n_list);
                     ivf->ckeys_stride = kAssignGroup * (int)ceil_div(max_nl, kAssignGroup);

@@ -23,7 +23,6 @@
 
 namespace fal {
 
-constexpr int32_t kNotProbed = INT_MIN;
 
 // pmz_l[pos] = pmz[perm[pos]]: precursor m/z in list order (inside a list the rows keep their sorted order: ascending)
 __global__ void gather_pmz_kernel(const float* __restrict__ pmz, const int32_t* __restrict__ perm, int64_t n, float* __restrict__ out) {

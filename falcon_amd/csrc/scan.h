@@ -78,7 +78,7 @@ struct ListScanArgs {
     const int64_t* list_off;     // [total_lists + 1] rows of every list (positions in Xl)
     const int64_t* inv_off;      // [total_lists + 1] entries of every list in the inverted probe table
     const int64_t* ltile_off;    // [total_lists + 1] tiles of every list, prefix (tile = 2^group_shift list rows)
-    int group_shift;             // 5: one wave per 32-row slice (ivf_list_kernel); 7: 4-wave groups (ivf_list4_kernel)
+    int group_shift;             // 7: tiles = 4-wave groups of four 32-row list slices (ivf_list4_kernel)
     const int32_t* inv_q;        // [pairs] query position (row of Xl)
     const int64_t* inv_dest;     // [pairs] float index in `sims` where that query's sims for this list start
     int64_t list_begin, list_end;   // lists of this launch

@@ -134,8 +134,7 @@ static int launch_dense_t(fal_ctx* ctx, int stage, const float* Q, const float* 
                           int32_t* assign, int64_t xcd_list_tiles) {
     if (n_tiles <= 0) return FAL_OK;
     // a flat bucket against itself (XCD-list mode is only used for that): exploit the symmetry
-    static const bool no_sym = getenv("FALCON_NO_SYMMETRY") != nullptr;
-    const int symmetric = (EPI == EPI_STORE && xcd_list_tiles > 0 && Q == Cm && !no_sym) ? 1 : 0;
+    const int symmetric = (EPI == EPI_STORE && xcd_list_tiles > 0 && Q == Cm) ? 1 : 0;
     const int dh4 = d / 8;
     const int xcd_lists = xcd_list_tiles > 0;
     // XCD-list mode: n_tiles is unused, the grid is 8 x (longest list)

@@ -61,14 +61,13 @@ __global__ void probe_hist_kernel(const int32_t* __restrict__ probes, int np, co
     }
 }
 
-// tiles of a list = 32-row slices of the LIST (each streams all queries probing the list); a list
+// tiles of a list = groups of 2^shift rows of the LIST (each streams all queries probing the list); a list
 // nobody probes needs none
-// ... restricted to the lists with lo < rows <= hi (the short lists take the one-wave kernel, the others the 4-wave one)
 __global__ void list_tiles_kernel(const int32_t* __restrict__ cnt, const int64_t* __restrict__ list_off, int64_t n,
-                                  int shift, int64_t lo, int64_t hi, int32_t* __restrict__ tiles) {
+                                  int shift, int32_t* __restrict__ tiles) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t rows = list_off[i + 1] - list_off[i];
-        tiles[i] = (cnt[i] > 0 && rows > lo && rows <= hi) ? (int32_t)((rows + (1 << shift) - 1) >> shift) : 0;
+        tiles[i] = (cnt[i] > 0 && rows > 0) ? (int32_t)((rows + (1 << shift) - 1) >> shift) : 0;
     }
 }
 
@@ -231,8 +230,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     std::vector<DenseJob> flat, coarse;    // coarse doubles as the IVF tile table
     flat.reserve(border.size());
     // Flat buckets with the top-k kept on chip (fused.hip): needs the float16 prefilter rows and the fused a8 output
-    static const bool no_fused = getenv("FALCON_NO_FUSED") != nullptr;
-    const bool fused = nf && ivf->Xpre && ivf->X && fused_supports(d) && !no_fused && !border.empty() &&
+    const bool fused = nf && ivf->Xpre && ivf->X && fused_supports(d) && !border.empty() &&
                        (ivf->bucket_off[border[0] + 1] - ivf->bucket_off[border[0]]) < 65536;
     if (fused) {
         // two tables over the same buckets (sorted by decreasing size, dealt to the 8 XCD lists round-robin): 32-query
@@ -376,28 +374,15 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     float* sims = nullptr;
     const size_t sims_floats = std::max(need_flat, need_coarse);
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (sims_floats + kSimsSlack), (void**)&sims));   // slack: scan16 sink, select over-reads
-    // scan || select: the top-k select of batch i runs on the auxiliary stream out of buffer i & 1 while
-    // the (matrix-pipe bound) scan of batch i + 1 fills the other buffer on the main stream
-    static const bool overlap = getenv("FALCON_OVERLAP") != nullptr;   // measured: no gain (the scan stretches), opt-in
-    float* sims2 = sims;
-    if (overlap && flat_batches.size() > 1) {
-        FAL_TRY(ctx->ensure_aux());
-        FAL_TRY(ctx->reserve(SLOT_SIMS2, sizeof(float) * (need_flat + kSimsSlack), (void**)&sims2));
-    }
-    const bool ov = sims2 != sims;
-    bool sel_pending[2] = {false, false};
-
     // ---- A. flat buckets ---------------------------------------------------------------------
     for (size_t bi = 0; bi < flat_batches.size(); ++bi) {
         const FlatBatch& fb = flat_batches[bi];
-        const int b = ov ? (int)(bi & 1) : 0;
-        float* buf = b ? sims2 : sims;
+        float* buf = sims;
         const DenseJob* jb = flat_dev + fb.j0;
         const int nj = (int)(fb.j1 - fb.j0);
-        if (ov && sel_pending[b]) FAL_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_sel[b], 0));   // buffer free again
         if (fb.jm > fb.j0)
             FAL_TRY(launch_scan16(ctx, ivf->x16_planes, ivf->X16, d, jb, (int)(fb.jm - fb.j0), fb.list_tiles16, buf, 0,
-                                  buf + (b ? need_flat : sims_floats)));
+                                  buf + sims_floats));
         if (fb.j1 > fb.jm)
             // (flat buckets keep their rows' positions in list order: the sorted rows serve)
             FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->X, ivf->X, d, flat_dev + fb.jm, (int)(fb.j1 - fb.jm), 0,
@@ -406,18 +391,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         sa.sims = buf; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = jb; sa.n_jobs = nj; sa.tile_begin = 0; sa.ids_are_rows = 1;
         set_filter(sa, nf);
-        if (ov) {
-            FAL_CHECK_HIP(hipEventRecord(ctx->ev_scan[b], st));
-            FAL_CHECK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_scan[b], 0));
-            FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, fb.tiles * 32, ctx->aux));
-            FAL_CHECK_HIP(hipEventRecord(ctx->ev_sel[b], ctx->aux));
-            sel_pending[b] = true;
-        } else {
-            FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, fb.tiles * 32));
-        }
+        FAL_TRY(launch_select(ctx, ST_SELECT, MODE_DENSE, sa, fb.tiles * 32));
     }
-    for (int b = 0; b < 2; ++b)
-        if (sel_pending[b]) FAL_CHECK_HIP(hipStreamWaitEvent(st, ctx->ev_sel[b], 0));     // join
     if (!fused) {
         ctx->counters[0] = 0;
         ctx->counters[4] = 0;                  // inner products the matrix cores actually computed (incl. padding)
@@ -449,8 +424,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (size_t)(n_slots + 2), (void**)&totals));
     FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(n_slots + 2), st));
     // the final k-means pass left the (row, centroid) similarities behind as 16-bit keys: no second scan (coarse16.hip)
-    static const bool no_c16 = getenv("FALCON_NO_COARSE16") != nullptr;
-    const bool from_keys = ivf->ckeys != nullptr && ivf->X != nullptr && !no_c16 && ivf->ckeys_stride <= 512;
+    const bool from_keys = ivf->ckeys != nullptr && ivf->X != nullptr && ivf->ckeys_stride <= 512;
     if (from_keys) {
         Coarse16Args ca{ivf->ckeys, ivf->ckeys_stride, ivf->X, ivf->centroids, d, coarse_dev, (int)coarse.size(), ivf_tiles, nullptr,
                         ivf->perm, np, probes};
@@ -473,27 +447,16 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                            coarse_dev, (int)coarse.size(), ivf_tiles, ivf->list_off, totals);
         FAL_TRY(device_scan_i64(ctx, totals, n_slots, q_sim_off, SLOT_MISC2));      // (millions of slots: multi-block)
     }
-    // fine-scan tiles: groups of four 32-row list slices for the 4-wave shared-stream kernel (ivf_fine.hip)
-    static const bool single_wave = getenv("FALCON_FINE_SINGLEWAVE") != nullptr;      // the one-wave-per-slice form (A/B runs)
-    const int group_shift = single_wave ? 5 : 7;
-    // Hybrid (opt-in, FALCON_FINE_SHORT_ROWS = r): lists of <= r rows -- which fill at most r / 32 of the 4-wave kernel's waves
-    // while its 100 kB of stream buffers keep a second workgroup off the CU -- take the one-wave kernel (no LDS, four independent
-    // workgroups per CU), the longer ones the shared-stream kernel.  Measured at 10 M spectra: fine scan 173.2 ms (off),
-    // 174.5 (r = 64), 192.6 (r = 96): the idle waves are not what bounds the kernel; kept for A/B runs only.
-    static const int64_t short_rows = [] {
-        const char* e = getenv("FALCON_FINE_SHORT_ROWS");
-        return e ? (int64_t)atoll(e) : (int64_t)0;
-    }();
-    const bool hybrid = !single_wave && short_rows > 0;
+    // fine-scan tiles: groups of four 32-row list slices for the 4-wave shared-stream kernels (ivf_fine.hip, ivf16.hip)
+    const int group_shift = 7;
     // ---- inverted probe table (list -> queries probing it) ------------------------------------
     const int64_t TL = ivf->total_lists;
     const int64_t n_pairs_max = ivf->n * (int64_t)np;
     int32_t *cnt = nullptr, *inv_q = nullptr;
     int64_t *inv_off = nullptr, *inv_dest = nullptr;
-    FAL_TRY(ctx->reserve(SLOT_INVCNT, sizeof(int32_t) * (size_t)(3 * TL + 3) + sizeof(int64_t) * (size_t)(3 * TL + 6), (void**)&inv_off));
+    FAL_TRY(ctx->reserve(SLOT_INVCNT, sizeof(int32_t) * (size_t)(3 * TL + 3) + sizeof(int64_t) * (size_t)(2 * TL + 4), (void**)&inv_off));
     int64_t* ltile_off = inv_off + (TL + 2);
-    int64_t* stile_off = ltile_off + (TL + 2);            // tiles of the short lists (one-wave kernel)
-    cnt = reinterpret_cast<int32_t*>(stile_off + (TL + 2));
+    cnt = reinterpret_cast<int32_t*>(ltile_off + (TL + 2));
     int32_t* cursor = cnt + (TL + 1);
     int32_t* ltiles = cursor + (TL + 1);
     FAL_TRY(ctx->reserve(SLOT_INV, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)n_pairs_max + 512, (void**)&inv_dest));   // (slack: list16_kernel reads whole chunks of row ids)
@@ -502,8 +465,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     {
         StageScope ts(ctx, ST_COARSE);
         const unsigned pg = (unsigned)ceil_div(n_slots, 256);
-        static const bool unordered_hist = getenv("FALCON_PROBE_TABLE_UNORDERED") != nullptr;
-        if (max_n_list <= 16384 && !unordered_hist)
+        if (max_n_list <= 16384)
             hipLaunchKernelGGL(probe_hist_bucket_kernel, dim3((unsigned)coarse.size()), dim3(1024), sizeof(int32_t) * (size_t)max_n_list,
                                st, probes, np, coarse_dev, cnt);
         else
@@ -511,15 +473,9 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                                ivf_tiles, cnt);
         FAL_TRY(device_scan_i32(ctx, cnt, TL, inv_off, SLOT_MISC2));
         const dim3 tg((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024));
-        hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, group_shift,
-                           hybrid ? short_rows : (int64_t)0, (int64_t)1 << 40, ltiles);
+        hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, group_shift, ltiles);
         FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
-        if (hybrid) {
-            hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, 5, (int64_t)0, short_rows, ltiles);
-            FAL_TRY(device_scan_i32(ctx, ltiles, TL, stile_off, SLOT_MISC2));
-        }
-        static const bool unordered = getenv("FALCON_PROBE_TABLE_UNORDERED") != nullptr;      // (A/B runs)
-        if (max_n_list <= 16384 && !unordered)
+        if (max_n_list <= 16384)
             hipLaunchKernelGGL(probe_scatter_bucket_kernel, dim3((unsigned)coarse.size()), dim3(1024), sizeof(int32_t) * (size_t)max_n_list,
                                st, probes, np, coarse_dev, ivf->list_off, q_sim_off, inv_off, inv_q, inv_dest);
         else
@@ -528,12 +484,10 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     }
     FAL_CHECK_HIP(hipGetLastError());
     // per-tile sims prefix and per-list tile prefix back to the host to cut bucket-sized batches
-    std::vector<int64_t> qoff((size_t)ivf_tiles + 1), lt_host((size_t)TL + 1), st_host(hybrid ? (size_t)TL + 1 : 0);
+    std::vector<int64_t> qoff((size_t)ivf_tiles + 1), lt_host((size_t)TL + 1);
     FAL_CHECK_HIP(hipMemcpy2DAsync(qoff.data(), sizeof(int64_t), q_sim_off, 32 * sizeof(int64_t), sizeof(int64_t),
                                    (size_t)ivf_tiles + 1, hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipMemcpyAsync(lt_host.data(), ltile_off, sizeof(int64_t) * (size_t)(TL + 1), hipMemcpyDeviceToHost, st));
-    if (hybrid)
-        FAL_CHECK_HIP(hipMemcpyAsync(st_host.data(), stile_off, sizeof(int64_t) * (size_t)(TL + 1), hipMemcpyDeviceToHost, st));
     int64_t max_total = 0;                                   // the most candidates any query has
     FAL_CHECK_HIP(hipMemcpyAsync(&max_total, totals + n_slots + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipStreamSynchronize(st));
@@ -559,11 +513,9 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     ctx->counters[3] = std::max<int64_t>(ctx->counters[3], (int64_t)(sizeof(float) * need_fine));
     FAL_REQUIRE(need_fine + kSimsSlack < ((size_t)1 << 32), FAL_EUNSUPPORTED, "sims batch too large (lower FALCON_SIMS_MB)");
     // ---- C'. fine scan with the float16 prefilter (ivf16.hip): f16-MFMA scan to 16-bit keys, k-th key per query, exact tail
-    static const bool no_ivf16 = getenv("FALCON_NO_IVF16") != nullptr;
     // (select16_kernel holds at most 4,096 keys of a query in registers; coarser indexes keep the exact staged scan rather
     // than sending every query through the exact fallback)
-    if (nf && ivf->Xl16 && ivf->pos_of_row && ivf->X && ivf16_supports(d) && !no_ivf16 && group_shift == 7 && !hybrid &&
-        max_total <= 4096) {
+    if (nf && ivf->Xl16 && ivf->pos_of_row && ivf->X && ivf16_supports(d) && max_total <= 4096) {
         // the IVF buckets in sorted-row order, 32-query tiles, sorted by decreasing size and dealt to the 8 XCD lists
         std::vector<size_t> ord(coarse.size());
         for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;
@@ -585,21 +537,15 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         fa.keep = nf->keep; fa.nb_idx = nf->nb_idx; fa.nb_dist = nf->nb_dist; fa.nb_count = nf->nb_count;
         fa.ivf = 1; fa.assign = ivf->assign; fa.pos_of_row = ivf->pos_of_row; fa.probes = probes; fa.n_probe = np;
         fa.mask_words = (max_n_list + 31) / 32; fa.list_off = ivf->list_off; fa.perm = ivf->perm;
-        static const bool dense_pairs = getenv("FALCON_PAIRS16_DENSE") != nullptr;     // exact chains over the dense rows (A/B runs)
-        if (!dense_pairs) { fa.sp_cols = ivf->sp_cols; fa.sp_vals = ivf->sp_vals; }
+        fa.sp_cols = ivf->sp_cols; fa.sp_vals = ivf->sp_vals;
         FAL_TRY(fused_prepare(ctx, &fa, ivf->n));
-        // the exact part: only the (query, candidate) pairs that can matter (pairs16.hip); with FALCON_IVF16_BAND the whole
-        // precursor window on the fp32 matrix cores (band_kernel: A/B runs)
-        static const bool force_band = getenv("FALCON_IVF16_BAND") != nullptr;
-        const bool pairs = !force_band;
+        // the exact part: only the (query, candidate) pairs that can matter (pairs16.hip)
         int2* gsel = nullptr;
         float* pmz_l = nullptr;
-        if (pairs) {
-            fa.ivf = 2;
-            FAL_TRY(ctx->reserve(SLOT_WIN, (sizeof(int2) + sizeof(float)) * (size_t)ivf->n, (void**)&gsel));
-            pmz_l = reinterpret_cast<float*>(gsel + ivf->n);
-            FAL_TRY(launch_gather_pmz(ctx, nf->pmz, ivf->perm, ivf->n, pmz_l));
-        }
+        fa.ivf = 2;
+        FAL_TRY(ctx->reserve(SLOT_WIN, (sizeof(int2) + sizeof(float)) * (size_t)ivf->n, (void**)&gsel));
+        pmz_l = reinterpret_cast<float*>(gsel + ivf->n);
+        FAL_TRY(launch_gather_pmz(ctx, nf->pmz, ivf->perm, ivf->n, pmz_l));
         uint16_t* keys = nullptr;
         FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(uint16_t) * (need_fine + 2 * kSimsSlack), (void**)&keys));
         int64_t max_cand = 0;
@@ -622,7 +568,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             sa.max_keys = max_total;
             sa.gsel = gsel;
             FAL_TRY(launch_select16(ctx, sa, t1 - t0));
-            if (pairs) {
+            {
                 Kept16Args ka{};
                 ka.keys = keys; ka.keys_base = base; ka.jobs = coarse_dev; ka.tile_begin = t0; ka.n_probe = np;
                 ka.probes = probes; ka.list_off = ivf->list_off; ka.q_sim_off = q_sim_off; ka.perm = ivf->perm; ka.pmz_l = pmz_l;
@@ -631,7 +577,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                 FAL_TRY(launch_kept16(ctx, ka, t1 - t0));
             }
         }
-        if (pairs) FAL_TRY(launch_pairs16(ctx, fa, d, *std::max_element(xt32, xt32 + 8)));
+        FAL_TRY(launch_pairs16(ctx, fa, d, *std::max_element(xt32, xt32 + 8)));
         FAL_TRY(launch_fused_ivf_tail(ctx, fa, d, *std::max_element(xt32, xt32 + 8), max_cand));
         FAL_CHECK_HIP(hipStreamSynchronize(st));
         return FAL_OK;
@@ -649,13 +595,6 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
         la.sims = sims; la.sims_base = base; la.sink = sims + need_fine;
         FAL_TRY(launch_list_scan(ctx, la));
-        if (hybrid) {                                            // the short lists of the same buckets
-            la.ltile_off = stile_off;
-            la.group_shift = 5;
-            la.tile_begin = st_host[(size_t)L0];
-            la.n_tiles_max = st_host[(size_t)L1] - st_host[(size_t)L0];
-            FAL_TRY(launch_list_scan(ctx, la));
-        }
         SelectArgs sa{};
         sa.sims = sims; sa.sims_base = base; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;
         sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size(); sa.tile_begin = t0;

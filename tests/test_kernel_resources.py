@@ -34,7 +34,6 @@ def _kernel_scratch(src, tmp_path):
 @pytest.mark.parametrize("src,pattern,expected", [
     ("scan.hip", "dense_kernel", 10),          # DH4 in {8,16,32,50,64} x {store, arg-max}
     ("scan16.hip", "scan16_kernel", 10),
-    ("ivf_fine.hip", "ivf_list_kernel", 5),
     ("ivf_fine.hip", "ivf_list4_kernel", 5),
     ("assign.hip", "assign_kernel", 5),
     ("assign.hip", "assign_wave_kernel", 5),
