@@ -45,9 +45,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-__device__ __forceinline__ uint16_t key16(float v) {
-    return (uint16_t)__float2uint_rn(__builtin_amdgcn_fmed3f(v, 0.f, 1.f) * 65535.f);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // list16_kernel: tile = (one inverted list, 128 of its rows); see ivf_list4_kernel for the structure.  Two things bound the
@@ -102,6 +99,12 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
         const half8* src = reinterpret_cast<const half8*>(a.Xl16 + rr * D + h * DH);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) q[s] = src[s];
+        // The resident rows must be COMPLETE here, as far as hipcc's wait-count bookkeeping goes: left pending, their first
+        // use sits inside the stream loop and hipcc guards every MFMA of every chunk with `s_waitcnt vmcnt(24 - s)` for them
+        // -- counts that know nothing of the loop's hand-counted DMAs and stores and therefore drained the whole pipeline
+        // (down to vmcnt(0)) once per 32-query chunk: an HBM round trip per 0.33 us of matrix work (round 2's 25 ms).
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) asm volatile("" : "+v"(q[s]));
     }
     const int pos = 32 * slice + r;                        // position inside the list = offset inside a query's segment
     const bool rvalid = active && r < nrow;
@@ -139,30 +142,49 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
             }
         }
     };
-    f32x16 prev;
+    // The keys of the last finished chunk wait here, two per register (v_cvt_pknorm_u16_f32: round(clamp(v, 0, 1) * 65535),
+    // within half a key step of v like key16 -- probed on the GPU, tools/probes/pknorm.hip), and leave during the NEXT
+    // chunk's matrix work.  D[query][list row]: lane = list row (column), registers = 16 streamed queries; every store
+    // instruction writes 32 consecutive keys of ONE query's segment for this list.
+    // The epilogue used to be 250 VALU instructions per chunk and wave (float -> key conversions one value at a time, 64-bit
+    // pointer arithmetic and pointer selects per store) against 25 MFMAs: the kernel was bound by issuing them.  Now: 8
+    // conversions, and per store one shift-add (32-bit byte offset from the keys base in SGPRs) + one select.
+    uint32_t pk[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) prev[i] = 0.f;
-    int prev_c = 0;                                        // chunk whose results sit in `prev`
-    // D[query][list row]: lane = list row (column), registers = 16 streamed queries; every store instruction writes 32
-    // consecutive keys of ONE query's segment for this list
-    auto epilogue = [&]() {
+    for (int j = 0; j < 8; ++j) pk[j] = 0u;
+    int prev_c = 0;                                        // chunk whose keys sit in `pk`
+    const uint32_t k2 = 2u * ((uint32_t)pos - base_lo);    // byte offset of this lane's column inside a query's segment, less the base
+    const uint32_t sink_off = 2u * ((uint32_t)(a.sink - a.keys) + (uint32_t)lane);
+    // (the 16 destinations of a chunk are read from the ring as four 16-byte pieces in front of the matrix work: read one by
+    // one between the stores -- which the stores' "memory" clobbers enforce -- every store waited for an LDS round trip with
+    // lgkmcnt(0), draining the operand ring with it)
+    int4 mdv[4];
+    auto load_dest = [&]() {
         const int32_t* md = &meta[prev_c & 7][32 + 4 * h];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mdv[g] = *reinterpret_cast<const int4*>(md + 8 * g);
+    };
+    auto epilogue = [&]() {
+        const int left = nq - 32 * prev_c - 4 * h;         // queries q0 < left of this chunk exist (all 32, except in a list's last chunk)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int q0 = (i & 3) + 8 * (i >> 2);
-            const uint32_t dest = (uint32_t)md[q0] - base_lo;
-            uint16_t* p = (rvalid && 32 * prev_c + q0 + 4 * h < nq) ? a.keys + dest + pos : a.sink + lane;
-            *p = key16(prev[i]);
+            const int4 m4 = mdv[i >> 2];
+            const int32_t mdq = (i & 3) == 0 ? m4.x : (i & 3) == 1 ? m4.y : (i & 3) == 2 ? m4.z : m4.w;
+            uint32_t off = ((uint32_t)mdq << 1) + k2;
+            off = (rvalid && q0 < left) ? off : sink_off;
+            if (i & 1) asm volatile("global_store_short_d16_hi %0, %1, %2" ::"v"(off), "v"(pk[i >> 1]), "s"(a.keys) : "memory");
+            else asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(pk[i >> 1]), "s"(a.keys) : "memory");
         }
-        __builtin_amdgcn_sched_group_barrier(0x040, 16, 0);
     };
     auto compute = [&](const unsigned char* buf, int c) {
         constexpr int kMid = STEPS / 2;
         const unsigned char* sb = buf + r * RS + h * (DH * 2);
         half8 ring[NB];
+        load_dest();
 #pragma unroll
         for (int j = 0; j < NB; ++j) ring[j] = *reinterpret_cast<const half8*>(sb + j * 16);
-        __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);      // the whole ring in front of the first MFMA (fused.hip)
+        __builtin_amdgcn_sched_group_barrier(0x100, NB + 4, 0);  // the destinations and the whole ring in front of the first MFMA (fused.hip)
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -177,24 +199,45 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
             if (s == kMid) epilogue();
         }
         asm volatile("s_nop 15" : "+a"(acc));              // MFMA -> accumulator read behind a taken branch (simtile.h)
-        prev = acc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            const us2 two = __builtin_amdgcn_cvt_pknorm_u16(acc[2 * j], acc[2 * j + 1]);
+            pk[j] = (uint32_t)two.x | ((uint32_t)two.y << 16);
+        }
         prev_c = c;
     };
     // step c: chunk c (in CUR) is computed; the row DMA of chunk c + 2 goes to FILL (free since the barrier: its last reader
-    // was the computation of chunk c - 1), the metadata DMA of chunk c + 3 to the ring
-#define FAL_STEP(CUR, FILL, C)                                                                             \
+    // was the computation of chunk c - 1); the metadata DMA of chunk c + 5 goes to the ring LAST.  Issue order per step and
+    // wave: kRowOps row DMAs, 16 key stores (inside the computation), 1 metadata DMA.  vmcnt counts in order, so the wait in
+    // front of step c + 1 -- which needs the rows of chunk c + 1, issued first thing in step c - 1 -- may leave everything
+    // issued after them outstanding: (16 + 1) + (kRowOps + 16 + 1) operations.  That keeps the metadata of chunk c + 5 (read
+    // by the row DMAs of step c + 3: two whole steps later, 2 (kRowOps + 17) > the allowance) and the key stores off the
+    // critical path.  (Round 2 issued the metadata FIRST and waited with vmcnt(kRowOps + 16): every step then waited for a
+    // metadata fetch issued one step earlier -- an HBM round trip per 0.33 us of matrix work; it, not the gather or the
+    // matrix pipe, set the kernel's time: profiles/NOTES.md.)  The first two steps have less in front of them and wait
+    // strictly.
+    constexpr int kAllow = (16 + 1) + (kRowOps + 16 + 1), kAllowIdle = 1 + (kRowOps + 1);
+#define FAL_STEP(CUR, FILL, C, STRICT)                                                                     \
     {                                                                                                      \
-        if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps + 16) : "memory");                    \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps) : "memory");                                \
+        if (STRICT) {                                                                                      \
+            if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps + 16 + 1) : "memory");            \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps + 1) : "memory");                        \
+        } else {                                                                                           \
+            if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAllow) : "memory");                      \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAllowIdle) : "memory");                         \
+        }                                                                                                  \
         __builtin_amdgcn_s_barrier();                                                                      \
         asm volatile("" ::: "memory");                                                                     \
-        issue_meta((C) + 3);                                                                               \
         issue_rows((C) + 2, FILL);                                                                         \
         if (active) compute(CUR, C);                                                                       \
+        issue_meta((C) + 5);                                                                               \
     }
     issue_meta(0);
     issue_meta(1);
     issue_meta(2);
+    issue_meta(3);
+    issue_meta(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -202,17 +245,28 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
     issue_rows(1, sbuf1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps) : "memory");       // chunk 0 has landed (the first step's own wait is a no-op)
     const int n_chunks = (nq + 31) >> 5;
-    for (int c = 0;; c += 3) {
-        FAL_STEP(sbuf0, sbuf2, c)
-        if (c + 1 >= n_chunks) break;
-        FAL_STEP(sbuf1, sbuf0, c + 1)
-        if (c + 2 >= n_chunks) break;
-        FAL_STEP(sbuf2, sbuf1, c + 2)
-        if (c + 3 >= n_chunks) break;
+    // (strict waits: in front of step 1 only the operations of step 0 lie behind the rows of chunk 1, in front of step 2 those
+    // of steps 0 and 1 behind the rows of chunk 2: the steady-state allowance starts with step 2)
+    FAL_STEP(sbuf0, sbuf2, 0, true)
+    if (1 < n_chunks) {
+        FAL_STEP(sbuf1, sbuf0, 1, true)
+        if (2 < n_chunks) {
+            FAL_STEP(sbuf2, sbuf1, 2, false)
+            for (int c = 3; c < n_chunks; c += 3) {
+                FAL_STEP(sbuf0, sbuf2, c, false)
+                if (c + 1 >= n_chunks) break;
+                FAL_STEP(sbuf1, sbuf0, c + 1, false)
+                if (c + 2 >= n_chunks) break;
+                FAL_STEP(sbuf2, sbuf1, c + 2, false)
+            }
+        }
     }
 #undef FAL_STEP
     // (outstanding DMAs target this workgroup's LDS: the hardware holds the allocation until they retire)
-    if (active) epilogue();
+    if (active) {
+        load_dest();
+        epilogue();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -547,6 +547,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         pmz_l = reinterpret_cast<float*>(gsel + ivf->n);
         FAL_TRY(launch_gather_pmz(ctx, nf->pmz, ivf->perm, ivf->n, pmz_l));
         uint16_t* keys = nullptr;
+        // (list16_kernel addresses a batch's keys by 32-bit byte offsets from the buffer's base)
+        FAL_REQUIRE(need_fine + 2 * kSimsSlack < ((size_t)1 << 31), FAL_EUNSUPPORTED, "key batch too large (lower FALCON_SIMS_MB)");
         FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(uint16_t) * (need_fine + 2 * kSimsSlack), (void**)&keys));
         int64_t max_cand = 0;
         for (int64_t t = 0; t < ivf_tiles; ++t) max_cand = std::max(max_cand, qoff[(size_t)t + 1] - qoff[(size_t)t]);
