@@ -37,8 +37,9 @@ struct fal_ivf {
     // searches use the exact kernels; 0 = none; -1 = not read back yet (neg_dev holds the flag on the device)
     int rows_signed = 0;
     int32_t* neg_dev = nullptr;
-    void* Xl16 = nullptr;            // float16 rows in list order: prefilter of the IVF fine scan (ivf16.hip), owned
-    int32_t* pos_of_row = nullptr;   // [n] sorted row -> list-order position (with Xl16), owned
+    const void* X16pre = nullptr;    // float16 rows (sorted order) the IVF fine scan gathers its list rows and queries from
+                                     // (ivf16.hip), borrowed: fal_ivf_attach_prefilter_ex(which & 2)
+    int32_t* pos_of_row = nullptr;   // [n] sorted row -> list-order position (with X16pre), owned
     int ckeys_stride = 0;            // columns of ckeys: 128 x (groups of the bucket with the most lists)
     uint16_t* ckeys = nullptr;       // [n, ckeys_stride] approximate (row, centroid) similarities of the final k-means pass as 16-bit keys,
                                      // by sorted row: the coarse quantiser reads them instead of scanning again; only when EVERY

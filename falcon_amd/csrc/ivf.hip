@@ -311,7 +311,7 @@ extern "C" {
 int fal_ivf_destroy(fal_ivf* ivf) {
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
-                    ivf->Xl16, ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals, ivf->neg_dev};
+                    ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals, ivf->neg_dev};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -360,12 +360,14 @@ int fal_ivf_attach_prefilter_ex(fal_ivf* ivf, const void* X16, int which) {
         ivf->rows_signed = ctx->fb_host[4] != 0 ? 1 : 0;
         ctx->counters[6] |= ivf->rows_signed;
     }
-    if ((which & 2) && ivf->n_ivf_buckets > 0 && !ivf->Xl16 && ivf->rows_signed == 0) {
+    if ((which & 2) && ivf->n_ivf_buckets > 0 && !ivf->X16pre && ivf->rows_signed == 0) {
         FAL_REQUIRE(ivf16_supports(ivf->d), FAL_EUNSUPPORTED,
                     "fal_ivf_attach_prefilter_ex: the IVF prefilter is instantiated for low_dim 64, 128, 256, 400 (got %d)", ivf->d);
-        FAL_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)ivf->n * ivf->d, &ivf->Xl16));
+        // (round 2 made a list-order copy of the float16 rows here: 16 GB of traffic at 10 M spectra for rows the scan gathers
+        // at random inside a bucket either way; now the scan reads X16[perm[position]] and only the inverse of perm is made)
         FAL_TRY(ctx->pool_alloc(sizeof(int32_t) * (size_t)ivf->n, (void**)&ivf->pos_of_row));
-        FAL_TRY(launch_gather16(ctx, X16, ivf->perm, ivf->n, ivf->d, ivf->Xl16, ivf->pos_of_row));
+        FAL_TRY(launch_pos_of_row(ctx, ivf->perm, ivf->n, ivf->pos_of_row));
+        ivf->X16pre = X16;
     }
     return FAL_OK;
 }

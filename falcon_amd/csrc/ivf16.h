@@ -9,19 +9,20 @@
 namespace fal {
 
 struct List16Args {              // cf. ListScanArgs (scan.h); tiles = groups of four 32-row list slices
-    const __half* Xl16;          // float16 rows in (bucket, list, row) order
+    const __half* X16;           // float16 rows in sorted-row order
+    const int32_t* perm;         // [n] list-order position -> sorted row (the resident rows of a list)
     int d;
     const int64_t* list_off;
     const int64_t* inv_off;
     const int64_t* ltile_off;
-    const int32_t* inv_q;
+    const int32_t* inv_row;      // [entries] sorted row of the query of every probe-table entry
     const int64_t* inv_dest;     // element index in `keys` where that query's segment for this list starts
     int64_t list_begin, list_end;
     int64_t tile_begin, n_tiles_max;
     uint16_t* keys;              // round(approximate similarity * 65535)
     int64_t keys_base;
     uint16_t* sink;              // >= 64 entries of scratch for masked stores
-    int64_t n_rows;              // rows of Xl16 (row ids read past a list's end are clamped)
+    int64_t n_rows;              // rows of X16 (row ids read past a list's end are clamped)
 };
 
 struct Select16Args {
@@ -71,7 +72,7 @@ bool ivf16_supports(int d);
 int launch_gather_pmz(fal_ctx* ctx, const float* pmz, const int32_t* perm, int64_t n, float* out);
 int launch_kept16(fal_ctx* ctx, const Kept16Args& a, int64_t n_tiles);        // right after launch_select16 on the same tiles
 int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32);
-int launch_gather16(fal_ctx* ctx, const void* X16, const int32_t* perm, int64_t n, int d, void* out, int32_t* pos_of_row);
+int launch_pos_of_row(fal_ctx* ctx, const int32_t* perm, int64_t n, int32_t* pos_of_row);
 int launch_list16(fal_ctx* ctx, const List16Args& a);
 int launch_select16(fal_ctx* ctx, const Select16Args& a, int64_t n_tiles);
 

@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
 
     half8 q[STEPS];                                        // the resident operand: list row 32*slice + r, k-half h
     {
-        const int64_t rr = l_row0 + min(32 * slice + min(r, max(nrow, 1) - 1), l_rows - 1);
-        const half8* src = reinterpret_cast<const half8*>(a.Xl16 + rr * D + h * DH);
+        const int64_t rr = a.perm[l_row0 + min(32 * slice + min(r, max(nrow, 1) - 1), l_rows - 1)];
+        const half8* src = reinterpret_cast<const half8*>(a.X16 + rr * D + h * DH);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) q[s] = src[s];
         // The resident rows must be COMPLETE here, as far as hipcc's wait-count bookkeeping goes: left pending, their first
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
     // metadata of chunk c (queries c*32 + r): lanes of the lower half fetch the row id, the upper half the destination
     auto issue_meta = [&](int c) {
         const int64_t e = e0 + min(32 * c + r, nq - 1);
-        const void* g = h ? (const void*)(a.inv_dest + e) : (const void*)(a.inv_q + e);
+        const void* g = h ? (const void*)(a.inv_dest + e) : (const void*)(a.inv_row + e);
         const uint32_t l = lds_addr(&meta[c & 7][0]);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(l) : "memory", "m0");
     };
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
             if (lane + 64 * part < D / 8) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const void* g = reinterpret_cast<const uint4*>(a.Xl16 + (int64_t)rows[i] * D) + lane + 64 * part;
+                    const void* g = reinterpret_cast<const uint4*>(a.X16 + (int64_t)rows[i] * D) + lane + 64 * part;
                     const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane(
                         (int)(lb + (uint32_t)(8 * w + i) * (uint32_t)RS + (uint32_t)(1024 * part)));
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
@@ -465,27 +465,19 @@ __global__ void tile_job16_kernel(const DenseJob* __restrict__ jobs, int n_jobs,
     if (i < n_tiles) tile_job[i] = find_job(jobs, n_jobs, tile_begin + i);
 }
 
-// Xl16[p] = X16[perm[p]], pos_of_row[perm[p]] = p   (one wave per row, 16 B per lane)
-__global__ __launch_bounds__(256) void gather_rows16_kernel(const __half* __restrict__ X16, const int32_t* __restrict__ perm,
-                                                            int64_t n, int d, __half* __restrict__ out,
-                                                            int32_t* __restrict__ pos_of_row) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t p = blockIdx.x * 4ll + (threadIdx.x >> 6); p < n; p += (int64_t)gridDim.x * 4) {
-        const int64_t src = perm[p];
-        const uint4* s = reinterpret_cast<const uint4*>(X16 + src * d);
-        uint4* o = reinterpret_cast<uint4*>(out + p * d);
-        for (int e = lane; e < d / 8; e += 64) o[e] = s[e];
-        if (lane == 0) pos_of_row[src] = (int32_t)p;
-    }
+// pos_of_row[perm[p]] = p
+__global__ void pos_of_row_kernel(const int32_t* __restrict__ perm, int64_t n, int32_t* __restrict__ pos_of_row) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x)
+        pos_of_row[perm[p]] = (int32_t)p;
 }
 
 bool ivf16_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400 || d == 800; }
 
-int launch_gather16(fal_ctx* ctx, const void* X16, const int32_t* perm, int64_t n, int d, void* out, int32_t* pos_of_row) {
+int launch_pos_of_row(fal_ctx* ctx, const int32_t* perm, int64_t n, int32_t* pos_of_row) {
     if (n <= 0) return FAL_OK;
     StageScope ts(ctx, ST_BUILD);
-    hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), ctx->num_cus * 16)), dim3(256), 0,
-                       ctx->stream, reinterpret_cast<const __half*>(X16), perm, n, d, reinterpret_cast<__half*>(out), pos_of_row);
+    hipLaunchKernelGGL(pos_of_row_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), ctx->num_cus * 16)), dim3(256), 0,
+                       ctx->stream, perm, n, pos_of_row);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

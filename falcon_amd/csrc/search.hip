@@ -122,7 +122,8 @@ __global__ __launch_bounds__(1024) void probe_scatter_bucket_kernel(const int32_
                                                                     const int64_t* __restrict__ list_off,
                                                                     const int64_t* __restrict__ q_sim_off,
                                                                     const int64_t* __restrict__ inv_off, int32_t* __restrict__ inv_q,
-                                                                    int64_t* __restrict__ inv_dest) {
+                                                                    int64_t* __restrict__ inv_dest, const int32_t* __restrict__ perm,
+                                                                    int32_t* __restrict__ inv_row) {
     extern __shared__ int32_t cur[];                         // entries written so far, per list of the bucket
     const DenseJob job = jobs[blockIdx.x];
     const int nl = job.nc;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(1024) void probe_scatter_bucket_kernel(const int32_
                 const int64_t e = inv_off[G] + atomicAdd(&cur[l], 1);
                 inv_q[e] = (int32_t)p;
                 inv_dest[e] = dest;
+                if (inv_row) inv_row[e] = perm[p];           // (the f16 list scan gathers its queries by sorted row)
                 dest += list_off[G + 1] - list_off[G];
             }
         }
@@ -459,8 +461,11 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     cnt = reinterpret_cast<int32_t*>(ltile_off + (TL + 2));
     int32_t* cursor = cnt + (TL + 1);
     int32_t* ltiles = cursor + (TL + 1);
-    FAL_TRY(ctx->reserve(SLOT_INV, (sizeof(int64_t) + sizeof(int32_t)) * (size_t)n_pairs_max + 512, (void**)&inv_dest));   // (slack: list16_kernel reads whole chunks of row ids)
+    // (the probe table by sorted row as well when the f16 list scan may follow: ordered table + float16 rows attached)
+    const bool want_rows = nf && ivf->X16pre && ivf->pos_of_row && max_n_list <= 16384;
+    FAL_TRY(ctx->reserve(SLOT_INV, (sizeof(int64_t) + (want_rows ? 2 : 1) * sizeof(int32_t)) * (size_t)n_pairs_max + 1024, (void**)&inv_dest));   // (slack: list16_kernel reads whole chunks of row ids)
     inv_q = reinterpret_cast<int32_t*>(inv_dest + n_pairs_max);
+    int32_t* inv_row = want_rows ? inv_q + n_pairs_max + 64 : nullptr;
     FAL_CHECK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(2 * TL + 2), st));     // cnt, cursor
     {
         StageScope ts(ctx, ST_COARSE);
@@ -477,7 +482,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
         if (max_n_list <= 16384)
             hipLaunchKernelGGL(probe_scatter_bucket_kernel, dim3((unsigned)coarse.size()), dim3(1024), sizeof(int32_t) * (size_t)max_n_list,
-                               st, probes, np, coarse_dev, ivf->list_off, q_sim_off, inv_off, inv_q, inv_dest);
+                               st, probes, np, coarse_dev, ivf->list_off, q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
         else
             hipLaunchKernelGGL(probe_scatter_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
                                ivf_tiles, ivf->list_off, q_sim_off, inv_off, cursor, inv_q, inv_dest);
@@ -515,7 +520,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     // ---- C'. fine scan with the float16 prefilter (ivf16.hip): f16-MFMA scan to 16-bit keys, k-th key per query, exact tail
     // (select16_kernel holds at most 4,096 keys of a query in registers; coarser indexes keep the exact staged scan rather
     // than sending every query through the exact fallback)
-    if (nf && ivf->Xl16 && ivf->pos_of_row && ivf->X && ivf16_supports(d) && max_total <= 4096) {
+    if (want_rows && ivf->X && ivf16_supports(d) && max_total <= 4096) {
         // the IVF buckets in sorted-row order, 32-query tiles, sorted by decreasing size and dealt to the 8 XCD lists
         std::vector<size_t> ord(coarse.size());
         for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;
@@ -558,8 +563,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             const int64_t L0 = first.c_row0, L1 = last.c_row0 + last.nc;
             const int64_t base = qoff[(size_t)t0];
             List16Args la{};
-            la.Xl16 = reinterpret_cast<const __half*>(ivf->Xl16); la.d = d; la.list_off = ivf->list_off; la.inv_off = inv_off;
-            la.ltile_off = ltile_off; la.inv_q = inv_q; la.inv_dest = inv_dest; la.list_begin = L0; la.list_end = L1;
+            la.X16 = reinterpret_cast<const __half*>(ivf->X16pre); la.perm = ivf->perm; la.d = d; la.list_off = ivf->list_off; la.inv_off = inv_off;
+            la.ltile_off = ltile_off; la.inv_row = inv_row; la.inv_dest = inv_dest; la.list_begin = L0; la.list_end = L1;
             la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
             la.keys = keys; la.keys_base = base; la.sink = keys + need_fine; la.n_rows = ivf->n;
             FAL_TRY(launch_list16(ctx, la));

@@ -165,8 +165,8 @@ int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes);
  * synchronisation, and rows that fail it make the searches ignore the prefilter (exact staged scan). ---- [dev] */
 int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16);
 /* The same with a choice of where the prefilter is used: which & 1 = flat buckets (as above), which & 2 = buckets
- * with an index: their fine scan runs on the f16 matrix cores over a float16 copy of the rows in list order
- * (made here, owned by the index; X16 itself is only read during this call for that part), the k-th best key
+ * with an index: their fine scan runs on the f16 matrix cores over X16 itself (gathered through the index's row
+ * permutation; the buffer is borrowed and must outlive the index for this part too), the k-th best key
  * of every query is bracketed from 16-bit keys, and the exact float32 work is limited to the precursor window
  * and to the candidates that can decide the k-th key.  BIT-IDENTICAL neighbour lists under the same precondition
  * (the build has already looked at the rows of the indexed buckets: if any has a negative / non-finite component
