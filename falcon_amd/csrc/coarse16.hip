@@ -254,8 +254,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 6
         if (live && !handed)
             for (int i = wnt + sub; i < np; i += 16) a.probes[p * np + i] = -1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     {
         int off[17];
         off[0] = 0;
@@ -269,8 +268,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 6
             m_val[k][mm] = exact_dot(a.X + q_row[k] * a.d, a.C + (q_cbase[k] + m_id[k][mm]) * (int64_t)a.d, a.d);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
         const int qi = 4 * rd + grp;

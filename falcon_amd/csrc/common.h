@@ -108,4 +108,16 @@ struct StageScope {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// LDS hand-off between the lanes of ONE wave: every lane's LDS writes in front, the reads of other lanes' data behind.
+// LDS operations of a wave execute in order, so no hardware wait is needed beyond the release fence's; what is also needed
+// is that hipcc keeps the reads behind the barrier.  Rounds 1-2 wrote `fence(release) + wave_barrier` only -- a release orders
+// nothing that FOLLOWS it, so a later LDS read of another lane's data could legally be scheduled above that lane's write.  No
+// miscompiled instance was found, but the pattern sits in 17 places that decide parity; the empty asm with a memory clobber pins
+// every memory access on its side of the barrier at no cost.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 }  // namespace fal

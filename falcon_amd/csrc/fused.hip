@@ -365,8 +365,7 @@ __global__ __launch_bounds__(256, 2) void approx_kernel(FusedArgs a) {
         const bool any = ((fm >> r) & 1ull) || ((fm >> (r + 32)) & 1ull);
         if (!any) q_flag[r * 2 + h] = 2;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     // ---- hand-off: thresholds and member lists of the wave's queries --------------------------------------------------
     if (!active) return;
     if (lane < nqw) {
@@ -636,8 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     }
                     run += __shfl(incl, 63, 64);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
                 if (have) {
                     const int pp = (int)mid;
                     int lo = 0, hi = np - 1;                     // last probe slot with seg_off <= pp
@@ -647,8 +645,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     }
                     mid = (uint32_t)a.perm[seg_src[lo] + (pp - seg_off[lo])] - (uint32_t)row0;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_sync();
             }
             const bool inE = have && fabsf(v - t.T) <= 2.f * t.eps;
             const int n_bin_above = __popcll(__ballot(have && (int)bin_of(v) > t.bstar));
@@ -704,12 +701,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             s_lo[at] = ~id;
         }
         const int c = __popcll(km);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         if (a.nb_count && lane == 0) a.nb_count[row] = min(c, a.keep);
         sort_and_store_nb<1>(s_u, s_lo, c, a.keep, lane, a.nb_idx + row * a.keep, a.nb_dist + row * a.keep);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
 }
 

@@ -311,15 +311,13 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
     {
         auto level = [&](auto bin_of_key, int kk, int* above) -> int {        // -> bin of the kk-th largest, *above = keys in higher bins
             hist[lane] = 0u; hist[lane + 64] = 0u; hist[lane + 128] = 0u; hist[lane + 192] = 0u; hist[lane + 256] = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const int b = bin_of_key(u[i]);
                 if (b >= 0) __hip_atomic_fetch_add(&hist[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             uint32_t c[5];                                                    // bins 5 lane .. 5 lane + 4
 #pragma unroll
             for (int j = 0; j < 5; ++j) c[j] = hist[5 * lane + j];
@@ -340,8 +338,7 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
             }
             *above = __shfl(acc, L, 64);
             const int res = __shfl(bin, L, 64);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             return res;
         };
         int above1 = 0, above2 = 0;

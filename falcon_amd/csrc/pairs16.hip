@@ -232,8 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 *reinterpret_cast<float4*>(slot) = sl[g];
                 *reinterpret_cast<float4*>(slot + 80) = sh[g];
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             const unsigned char* mine = tb + lane * kSlot;
 #pragma unroll
             for (int t = 0; t < U; ++t) {
@@ -250,8 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     acc = __builtin_fmaf(qh[t].w, ch.w, acc);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         }
         if (live) a.gkept_u[row * FAL_FUSED_KEEP + j] = max(f32_sortable(acc), 1u);
     }
@@ -366,8 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             *reinterpret_cast<float4*>(wv + 48 * kSlot) = s3;
             *reinterpret_cast<uint4*>(wc) = t0;
             *reinterpret_cast<uint4*>(wc + 32 * kSlot) = t1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             const unsigned char* mine = tb + lane * kSlot;
             const uint4 c0 = *reinterpret_cast<const uint4*>(mine), c1 = *reinterpret_cast<const uint4*>(mine + 16);
             const float4 v0 = *reinterpret_cast<const float4*>(mine + 32), v1 = *reinterpret_cast<const float4*>(mine + 48);
@@ -383,8 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             term(c0.z & 0xFFFFu, v1.x); term(c0.z >> 16, v1.y); term(c0.w & 0xFFFFu, v1.z); term(c0.w >> 16, v1.w);
             term(c1.x & 0xFFFFu, v2.x); term(c1.x >> 16, v2.y); term(c1.y & 0xFFFFu, v2.z); term(c1.y >> 16, v2.w);
             term(c1.z & 0xFFFFu, v3.x); term(c1.z >> 16, v3.y); term(c1.w & 0xFFFFu, v3.z); term(c1.w >> 16, v3.w);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             // entries are packed: a row whose last entry of this step is unused has none in the next
             more = __ballot((c1.w >> 16) < (uint32_t)kColDense) != 0ull;
         };

@@ -91,14 +91,12 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
             const uint32_t dmask = (1u << wbits) - 1u;
             const uint32_t himask = hi >= 32 ? 0u : ~0u << hi;
             *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0u, 0u, 0u, 0u);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
 #pragma unroll
             for (int i = 0; i < R; ++i)
                 if (u[i] != 0u && (u[i] & himask) == prefix)
                     __hip_atomic_fetch_add(&hist[(u[i] >> shift) & dmask], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             const uint4 cv = *reinterpret_cast<const uint4*>(hist + 4 * lane);      // bins 4 lane .. 4 lane + 3
             const int c[4] = {(int)cv.x, (int)cv.y, (int)cv.z, (int)cv.w};
             const int own = c[0] + c[1] + c[2] + c[3];
@@ -122,8 +120,7 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
             prefix |= (uint32_t)bin << shift;
             exact = cj == kk;
             eq = cj;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         }
         T = prefix;
         if (!exact) {
