@@ -279,7 +279,10 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
  *          put the exact matched-peak distances into it.  method: 0 single, 1 complete, 2 average; threshold < 1.
  *          Same output contract as fal_dbscan (clusters numbered by lowest row, groups of one row = -1), so
  *          fal_refine_clusters / fal_finalize follow unchanged; fal_cluster_graph_linkage is the fused a9..a12
- *          form.  Tie order between equal merge heights is the build's own (PARITY UNPINNED: fastcluster absent). [dev] */
+ *          form.  Tie order between equal merge heights is the build's own (PARITY UNPINNED: fastcluster absent).
+ *          The complete / average forms synchronise the stream once more than fal_dbscan does (the sizes of the connected
+ *          groups decide their scratch) and agglomerate one group per wave in O(m^3 / 64): a connected group of more than
+ *          2,048 rows within the threshold is refused with FAL_EUNSUPPORTED (single linkage and DBSCAN have no such limit). [dev] */
 int fal_linkage_cluster(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k,
                         float threshold, int method, int32_t* labels, int64_t* n_clusters /*[host]*/);
 int fal_cluster_graph_linkage(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k,

@@ -32,6 +32,29 @@ def test_linkage_matches_reference_golden(ctx, method):
         assert n_cl == exp.max() + 1
 
 
+def test_linkage_refuses_a_connected_group_beyond_its_cap(ctx):
+    """the complete / average agglomeration is one wave per connected group and cubic in its size; a chain of 3,000
+    rows within the threshold (what single-linkage chaining produces on dense precursor regions) must be refused with a
+    clear error instead of running for minutes.  Single linkage takes the same graph."""
+    import torch
+    from falcon_amd._lib import FalconHipError
+    n, k = 3000, 4
+    idx = np.full((n, k), -1, np.int32)
+    dist = np.full((n, k), np.inf, np.float32)
+    idx[:-1, 0] = np.arange(1, n)                               # a chain 0 - 1 - 2 - ... inside the threshold
+    dist[:-1, 0] = 0.05
+    ti, td = torch.from_numpy(idx).to(ctx.tdev), torch.from_numpy(dist).to(ctx.tdev)
+    for method in ("complete", "average"):
+        with pytest.raises(FalconHipError, match="connected group of 3000 spectra"):
+            ctx.linkage_cluster(ti, td, 0.1, method)
+    lab, n_cl = ctx.linkage_cluster(ti, td, 0.1, "single")
+    assert n_cl == 1 and bool((lab == 0).all())
+    # a group below the cap still runs
+    m = 1500
+    lab, n_cl = ctx.linkage_cluster(ti[:m].clone().clamp(max=m - 1), td[:m].clone(), 0.1, "complete")
+    assert n_cl >= 1
+
+
 def test_linkage_large_component_and_ties(ctx):
     """a component of several hundred rows (the global-memory matrix) and exact zero distances (duplicates)"""
     import torch

@@ -49,7 +49,6 @@ for rank in only:
 worst = max(r["ms"] for r in out["ranks"])
 out["slowest_rank_ms"] = worst
 out["projected_spectra_per_s"] = world * per_gpu / (worst * 1e-3)
-out["note"] = ("one GPU running every rank's shard in turn: the compute side of the bucket-sharded job only (every rank also sorts the "
-               "whole dataset's precursors and derives all buckets, as in the real run); the all-gatherv of the neighbour lists is not "
-               "included")
+out["note"] = ("one GPU running every rank's share in turn: the compute side of the window-sharded job, every phase of the rank "
+               "included (window histogram, deal, its own sort, the path); the all-gatherv of the neighbour lists is not included")
 print(json.dumps(out))
