@@ -7,16 +7,20 @@ medoids/labels) on synthetic peak lists, plus the cosine kernel's roofline fract
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-The job is ONE dataset, both charge partitions (falcon.py:151-193).  `--scaling weak` (default): N x `--spectra`
-synthetic spectra (N = GPUs; 1,000,000 per GPU = BASELINE.json configs[1] at N = 1) with the precursor range widened
-with N (400 .. 400 + 800 N m/z) so that the bucket density -- and with it the work per spectrum -- stays that of the
-1 M workload.  `--scaling strong`: the FIXED `--spectra-total` dataset (default 10,000,000 in 400-1200 m/z =
-BASELINE configs[2]) on N GPUs.  A "step" = one pass of the whole hot path over that dataset:
+The job is ONE dataset, all its charge partitions (falcon.py:151-193).  `--scaling weak` (default): N x `--spectra`
+synthetic spectra (N = GPUs; 1,000,000 per GPU = BASELINE.json configs[1] at N = 1): N statistically identical blocks
+of the configs[1] workload (same 400-1200 m/z precursor range, different random templates), block k's charges
+relabelled (2, 3) -> (2 + 2k, 3 + 2k) -- a dataset of 2 N charge partitions whose work per spectrum is that of the
+1 M workload by construction.  (Widening the precursor range with N instead does NOT keep the work per spectrum: the
+20 ppm tolerance grows with m/z, the gap rule cuts less often, buckets and pair counts grow -- measured, profiles/NOTES.md.)
+`--scaling strong`: the FIXED `--spectra-total` dataset (default 10,000,000 in 400-1200 m/z = BASELINE configs[2]) on
+N GPUs.  A "step" = one pass of the whole hot path over that dataset:
 
-  * every rank sorts the precursors of the whole dataset and derives the SAME precursor buckets (cheap,
-    deterministic), buckets are dealt to ranks by longest-processing-time on their scan cost, a rank runs
-    vectorise -> ... -> labels on its own buckets (no data-path collective: no neighbour pair crosses a bucket,
-    reference cluster.py:107-141);
+  * every rank histograms the 1-m/z precursor windows of every partition (4 bytes per spectrum) and derives the SAME
+    deal (`distributed.deal_job`): whole charge partitions by longest-processing-time where that balances (many like
+    partitions), otherwise every (charge, window) unit on its own; it sorts, buckets and runs vectorise -> ... -> labels
+    on its own spectra only (no data-path collective: a window's buckets depend on its own spectra only, and no
+    neighbour pair crosses a bucket, reference cluster.py:107-141);
   * ONE all-gatherv (RCCL over xGMI) of the CSR neighbour lists + labels + dataset rows gives every rank the
     global sparse graph and the globally unique labels (rank-major offsets like falcon.py:189-193), which the
     rank copies to the host.  At N = 1 there is nothing to exchange and the step is the single-GPU pipeline.
@@ -54,7 +58,7 @@ def cpu_baseline(host, params, seconds_hint=20.0):
     so the work per spectrum) of the full run."""
     from oracle import falcon_oracle as fo
     pm = host["precursor_mz"]
-    lo, width = 600.0, 120.0          # >= 100 k spectra at the default density
+    lo, width = 600.0, 400.0          # ~350 k spectra at the default density: ~10 s on the GPU box's host cores
     sel = np.flatnonzero((pm >= lo) & (pm < lo + width))
     if len(sel) < 256:
         sel = np.arange(min(len(pm), 20000))
@@ -105,7 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: gpus x --spectra spectra, precursor range 400 .. 400 + 800 gpus m/z (constant bucket density); "
+                    help="weak: gpus x --spectra spectra = gpus blocks of the 1 M workload as 2 x gpus charge partitions; "
                          "strong: the fixed --spectra-total dataset in 400-1200 m/z on every number of GPUs")
     ap.add_argument("--spectra", type=int, default=1_000_000, help="weak scaling: spectra per GPU")
     ap.add_argument("--spectra-total", type=int, default=10_000_000, help="strong scaling: spectra of the dataset")
@@ -185,21 +189,27 @@ def main():
         base.update(kw)
         return AnnParams(**base)
 
-    def make_parts(n_total, first_block=0, mz_lo=400.0, mz_hi=1200.0):
-        """the dataset, split by precursor charge (falcon.py:151-160), resident in HBM -> [SpectrumDataset]"""
-        if args.generator == "device":
-            data = synth.generate_device(n_total, dev, seed=42, first_block=first_block, mz_lo=mz_lo, mz_hi=mz_hi)
-            sel = lambda c: synth.select_charge_device(data, c)
-        else:
-            data = synth.generate(n_total, seed=42, first_block=first_block, mz_lo=mz_lo, mz_hi=mz_hi)
-            sel = lambda c: synth.select_charge(data, c)
+    def make_parts(n_total, first_block=0, mz_lo=400.0, mz_hi=1200.0, replicas=1):
+        """the dataset, split by precursor charge (falcon.py:151-160), resident in HBM -> [SpectrumDataset].
+        `replicas` = R > 1: R statistically identical blocks of n_total / R spectra each (generator blocks first_block,
+        first_block + 1, ...), block k's charges relabelled (2, 3) -> (2 + 2k, 3 + 2k): a dataset of 2R charge partitions"""
         parts = []
-        for charge in (2, 3):
-            c = sel(charge)
-            parts.append(SpectrumDataset(ctx.to_dev(c["precursor_mz"], torch.float32),
-                                         ctx.to_dev(c["retention_time"], torch.float32),
-                                         ctx.to_dev(c["mz"], torch.float32), ctx.to_dev(c["intensity"], torch.float32),
-                                         ctx.to_dev(c["indptr"], torch.int64)))
+        per = n_total // replicas
+        for k in range(replicas):
+            fb = first_block + k * ((per + synth.BLOCK - 1) // synth.BLOCK)
+            if args.generator == "device":
+                data = synth.generate_device(per, dev, seed=42, first_block=fb, mz_lo=mz_lo, mz_hi=mz_hi)
+                sel = lambda c: synth.select_charge_device(data, c)
+            else:
+                data = synth.generate(per, seed=42, first_block=fb, mz_lo=mz_lo, mz_hi=mz_hi)
+                sel = lambda c: synth.select_charge(data, c)
+            for charge in (2, 3):
+                c = sel(charge)
+                parts.append(SpectrumDataset(ctx.to_dev(c["precursor_mz"], torch.float32),
+                                             ctx.to_dev(c["retention_time"], torch.float32),
+                                             ctx.to_dev(c["mz"], torch.float32), ctx.to_dev(c["intensity"], torch.float32),
+                                             ctx.to_dev(c["indptr"], torch.int64)))
+            del data
         return parts
 
     def barrier():
@@ -211,8 +221,9 @@ def main():
     # ---- the dataset (every rank holds it; a rank only touches the peaks of its own buckets) ------------------------
     strong = args.scaling == "strong"
     n_total = args.spectra_total if strong else world * args.spectra
-    mz_lo, mz_hi = 400.0, (1200.0 if strong else 400.0 + 800.0 * world)
-    parts = make_parts(n_total, mz_lo=mz_lo, mz_hi=mz_hi)
+    mz_lo, mz_hi = 400.0, 1200.0
+    replicas = 1 if strong else world
+    parts = make_parts(n_total, mz_lo=mz_lo, mz_hi=mz_hi, replicas=replicas)
     part_off = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
     p = params()
     run_args = (20.0, "ppm", None, 0.05, args.batch_size, p)
@@ -221,7 +232,7 @@ def main():
     exchange = fdist.SparseGraphExchange(dev)
     pending, csr_buf = [], {}
     # spectra per 1 m/z window and charge-2 partition: beyond ~1,600 the windows get an index (n_list > n_probe)
-    ivf_regime = 0.7 * n_total / max(mz_hi - mz_lo, 1.0) > 1600
+    ivf_regime = 0.7 * (n_total // replicas) / max(mz_hi - mz_lo, 1.0) > 1600
 
     def collect_stages(n):
         return ({k: ctx.stage_ms(k) for k in STAGES + ("kernel",)}
@@ -244,9 +255,10 @@ def main():
             lasts = pipe.lasts
         else:
             outs, lasts = [], []
-            for ds in parts:
+            owners = pipe.plan_shards(ctx, parts, run_args[4], run_args[5], world) if shard is not None else None
+            for j, ds in enumerate(parts):
                 if shard is not None:
-                    o = pipe.run_many([ds], *run_args, shard=shard)
+                    o = pipe.run_many([ds], *run_args, shard=(rank, world, [owners[j]]))
                     outs.append(o[0])
                     lasts.append(pipe.lasts[0])
                 else:
@@ -494,7 +506,7 @@ def main():
         del big
         torch.cuda.empty_cache()
         concurrent["on"] = was_concurrent
-        parts = make_parts(n_total, mz_lo=mz_lo, mz_hi=mz_hi)
+        parts = make_parts(n_total, mz_lo=mz_lo, mz_hi=mz_hi, replicas=replicas)
 
     if rank == 0:
         d = args.low_dim
@@ -546,11 +558,14 @@ def main():
                        "partitions": ("serial" if args.serial else
                                       "concurrent: a host thread + HIP stream + context per charge partition (PartitionRunner)"
                                       if concurrent["on"] else "software-pipelined (ClusterPipeline.run_many)"),
-                       "parallelism": (f"precursor buckets of the one dataset dealt to {world} GPUs (LPT), no data-path "
-                                       "collective, one all-gatherv") if world > 1 else "1 GPU",
-                       "note": (("strong scaling: the dataset is fixed, every GPU takes 1/N of its precursor buckets" if strong else
-                                 "weak scaling: spectra per GPU AND bucket density fixed -- the precursor range grows with N "
-                                 "(400 .. 400 + 800 N m/z), so the work per spectrum is that of the 1 M workload at every N")
+                       "parallelism": (f"(charge, precursor window) units of the one dataset dealt to {world} GPUs "
+                                       "(distributed.deal_job: whole charge partitions where that balances, else window by window), "
+                                       "no data-path collective, one all-gatherv")
+                                      if world > 1 else "1 GPU",
+                       "note": (("strong scaling: the dataset is fixed, every GPU takes 1/N of its (charge, window) units" if strong
+                                 else f"weak scaling: the dataset is {world} statistically identical blocks of the 1 M BASELINE "
+                                      "configs[1] workload (same precursor range), block k's charges relabelled (2, 3) -> (2 + 2k, "
+                                      f"3 + 2k): {2 * world} charge partitions, per-GPU work fixed by construction")
                                 if world > 1 else None)},
             "roofline": roof,
             "stage_ms": s["stage_ms"],

@@ -132,32 +132,45 @@ class ClusterPipeline:
             n_list[:] = 1
         return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list)
 
-    def _front_windows(self, c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p, shard):
+    def plan_shards(self, c, datasets, batch_size, p, world):
+        """The deal of a multi-partition job to `world` GPUs (`distributed.deal_job`): -> [owner int32[windows] per dataset]
+        (an empty array for an empty dataset).  One pass over every partition's precursor column, one wait."""
+        from .. import distributed as fdist
+        counts = c.window_counts([ds.precursor_mz for ds in datasets], p.mz_interval)
+        costs = fdist.window_costs(counts.ravel(), batch_size, p.n_probe).reshape(counts.shape)
+        return fdist.deal_job(list(costs), world)
+
+    def _front_windows(self, c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p, shard, owner=None):
         """The front end of ONE rank of a job that shares a dataset among `world` GPUs, without the replicated
         sort: buckets never cross a precursor window floor(mz / mz_interval) and a window's buckets depend on its own spectra
         only (`fal_precursor_splits`), so whole WINDOWS are the unit that is dealt out.  Every rank histograms the window of
         every spectrum (one pass over 4 bytes per spectrum), derives the same deal from the counts
-        (`distributed.window_costs` / `deal_units`), and sorts / buckets only its own spectra.  The buckets -- hence neighbour
+        (`plan_shards`: `distributed.window_costs` / `deal_job` over all partitions of the job; `owner` = this partition's
+        part of it), and sorts / buckets only its own spectra.  The buckets -- hence neighbour
         lists and clusters -- are exactly those of the single-GPU pass.  Reference analogue: blocks are clustered
         independently and only their labels are offset afterwards (cluster.py:107-155).
         -> the state `_restrict` returns: order = rows = dataset rows of this rank's spectra in precursor order, ..."""
         import torch
         from .. import distributed as fdist
-        rank, world = shard
+        rank, world = shard[0], shard[1]
         pmz = c.to_dev(ds.precursor_mz, torch.float32)
         n = int(pmz.numel())
-        win = torch.floor(pmz.double() / float(p.mz_interval)).to(torch.int64)     # (the arithmetic of split_flags_kernel)
-        lo, hi = (int(x) for x in torch.aminmax(win)[0:2]) if n else (0, 0)
-        win -= lo
-        counts = torch.bincount(win, minlength=hi - lo + 1).cpu().numpy()
-        owner = fdist.deal_units(fdist.window_costs(counts, batch_size, p.n_probe), world)
-        mine = c.to_dev(owner == rank, torch.bool)[win]
-        rows = torch.nonzero(mine).flatten()                                         # ascending dataset rows: the sort stays stable
+        if owner is None:
+            owner = self.plan_shards(c, [ds], batch_size, p, world)[0]
+        if len(owner) and (owner == rank).all():
+            # the whole partition is this rank's: the single-GPU front end, every dataset row in precursor order
+            st = self._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p)
+            st.update(rows=st["order"], n_total=n)
+            return st
+        if not (owner == rank).any():
+            rows = torch.zeros(0, dtype=torch.int64, device=c.tdev)
+        else:
+            rows, mz_sub = c.window_select(pmz, p.mz_interval, owner, rank)         # ascending dataset rows: the sort stays stable
         if rows.numel() == 0:
             e = rows.new_zeros(0)
             return dict(order=e, mzs=pmz[:0], rts=None, splits=np.zeros(1, np.int64), n_list=np.zeros(0, np.int32), rows=e,
                         n_total=n)
-        order_sub, mzs = c.sort_by_precursor(pmz[rows])
+        order_sub, mzs = c.sort_by_precursor(mz_sub)
         rows_sorted = rows[order_sub]
         rts = c.gather_f32(ds.retention_time, rows_sorted) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
@@ -292,22 +305,37 @@ class ClusterPipeline:
         import torch
         c = self.ctx
         args = (precursor_tol_mass, precursor_tol_mode, rt_tol)
-        if not hasattr(self, "_front_ctx"):
+        live = [i for i, ds in enumerate(datasets) if len(ds) > 0]
+        if len(live) > 1 and not hasattr(self, "_front_ctx"):
             self._front_stream = torch.cuda.Stream(device=c.tdev)
             with torch.cuda.stream(self._front_stream):
                 self._front_ctx = _device.Context(c.device)               # bound to the front stream
-        live = [i for i, ds in enumerate(datasets) if len(ds) > 0]
+        # one partition: nothing to overlap -- its front end runs on the pipeline's own stream (a `PartitionRunner` slot must
+        # not spread over more streams than it has to: HIP folds streams onto a few hardware queues, and a front end queued
+        # behind another slot's scan kernel waits for it)
+        front_stream = self._front_stream if len(live) > 1 else torch.cuda.current_stream(c.tdev)
+        front_ctx = self._front_ctx if len(live) > 1 else c
         states = {}
         sharded = shard is not None and shard[1] > 1
+        windows = sharded and bool(p.mz_interval and p.mz_interval > 0)
+        owners = None
+        if windows:
+            # the deal covers ALL partitions of the job (a rank owns whole partitions where it can); a caller that runs the
+            # partitions of one job through several pipelines (PartitionRunner) plans once and passes every call its part
+            owners = shard[2] if len(shard) > 2 else None
+            if owners is None:
+                front_stream.wait_stream(torch.cuda.current_stream(c.tdev))
+                with torch.cuda.stream(front_stream):
+                    owners = self.plan_shards(front_ctx, datasets, batch_size, p, shard[1])
 
         def front(i):
-            with torch.cuda.stream(self._front_stream):
-                if sharded and p.mz_interval and p.mz_interval > 0:
-                    st = self._front_windows(self._front_ctx, datasets[i], *args, batch_size, p, shard)
+            with torch.cuda.stream(front_stream):
+                if windows:
+                    st = self._front_windows(front_ctx, datasets[i], *args, batch_size, p, shard, owner=owners[i])
                 else:
-                    st = self._front(self._front_ctx, datasets[i], *args, batch_size, p)
+                    st = self._front(front_ctx, datasets[i], *args, batch_size, p)
                     if sharded:                                                # no windows: whole buckets of the sorted dataset
-                        st = self._restrict(self._front_ctx, st, p, shard)
+                        st = self._restrict(front_ctx, st, p, shard[:2])
                 if sharded:
                     # labels refer to the subset's own rows; `rows` maps them to dataset rows
                     st["order"] = torch.arange(st["rows"].numel(), dtype=torch.int64, device=c.tdev)
@@ -315,14 +343,14 @@ class ClusterPipeline:
 
         if live:
             # inputs may have been produced on the caller's stream
-            self._front_stream.wait_stream(torch.cuda.current_stream(c.tdev))
+            front_stream.wait_stream(torch.cuda.current_stream(c.tdev))
             front(live[0])
         for pos, i in enumerate(live):
             if states[i]["order"].numel() > 0:
                 if sharded:
                     # the subset's rows in sorted order = dataset rows `rows`: vectorise gathers them from the CSR
                     st = dict(states[i], order=states[i]["rows"])
-                    torch.cuda.current_stream(c.tdev).wait_stream(self._front_stream)
+                    torch.cuda.current_stream(c.tdev).wait_stream(front_stream)
                     self._search(datasets[i], st, *args, fragment_tol, p, False)
                     st["order"] = states[i]["order"]
                     states[i] = st
@@ -409,7 +437,7 @@ class PartitionRunner:
         pipe, stream = self._pipeline()
         with torch.cuda.stream(stream):
             if shard is not None and shard[1] > 1:
-                out = pipe.run_many([ds], *args, shard=shard, **kwargs)[0]       # this rank's buckets of the partition
+                out = pipe.run_many([ds], *args, shard=shard, **kwargs)[0]       # this rank's windows of the partition
                 pipe.last = pipe.lasts[0]
             else:
                 out = pipe.run(ds, *args, **kwargs)
@@ -422,10 +450,21 @@ class PartitionRunner:
         import torch
         torch.cuda.current_stream(self.device).synchronize()      # inputs produced on the caller's stream
         order = sorted(range(len(datasets)), key=lambda i: -len(datasets[i]))
-        futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs, shard) for i in order}
-        res = [futs[i].result() for i in range(len(datasets))]
-        self.last_pipes = [r[1] for r in res]
-        self.lasts = [r[2] for r in res]                           # every partition's `last`, in the order of `datasets`
+        shards = [shard] * len(datasets)
+        p = args[5]
+        if shard is not None and shard[1] > 1 and p.mz_interval and p.mz_interval > 0:
+            # one deal for the whole job (`distributed.deal_job` over every partition's windows), then a slot per partition
+            if not hasattr(self, "_planner"):
+                self._planner = ClusterPipeline(device=self.device)
+            owners = self._planner.plan_shards(self._planner.ctx, datasets, args[4], p, shard[1])      # (waits for the counts)
+            shards = [(shard[0], shard[1], [owners[i]]) for i in range(len(datasets))]
+            order = [i for i in order if (owners[i] == shard[0]).any()]        # partitions this rank has windows of
+        futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs, shards[i]) for i in order}
+        dev = torch.device("cuda", self.device)
+        nothing = lambda: ((torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev)),
+                           {"rows": torch.empty(0, dtype=torch.int64, device=dev)})
+        res = [futs[i].result()[::2] if i in futs else nothing() for i in range(len(datasets))]
+        self.lasts = [r[1] for r in res]                           # every partition's `last`, in the order of `datasets`
         return [r[0] for r in res]
 
     def close(self):

@@ -185,6 +185,84 @@ __global__ void compact_flags_kernel(const int32_t* __restrict__ flag, const int
     }
 }
 
+// ---- multi-GPU front: whole precursor windows are the unit dealt to ranks -------------------------------------
+__device__ __forceinline__ int64_t window_of(float mz, double interval, int64_t n_windows) {
+    const double w = floor((double)mz / interval);                      // (the arithmetic of split_flags_kernel)
+    return w >= 0.0 ? (w < (double)(n_windows - 1) ? (int64_t)w : n_windows - 1) : 0;      // (NaN -> 0)
+}
+
+// the partitions of one job (precursor charges) are counted by ONE pair of launches: blockIdx.y = partition
+constexpr int kWindowParts = 64;
+struct WindowParts {
+    const float* mz[kWindowParts];
+    int64_t n[kWindowParts];
+};
+
+// lo_hi[2 p] = smallest, lo_hi[2 p + 1] = largest window of partition p that holds a spectrum (one atomic pair per wave)
+__global__ void window_range_kernel(WindowParts parts, double interval, int64_t n_windows, int32_t* __restrict__ lo_hi) {
+    const float* __restrict__ mz = parts.mz[blockIdx.y];
+    const int64_t n = parts.n[blockIdx.y];
+    lo_hi += 2 * blockIdx.y;
+    int32_t lo = INT32_MAX, hi = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t w = (int32_t)window_of(mz[i], interval, n_windows);
+        lo = min(lo, w);
+        hi = max(hi, w);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, 64));
+        hi = max(hi, __shfl_xor(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&lo_hi[0], lo);
+        atomicMax(&lo_hi[1], hi);
+    }
+}
+
+// counts[w] += spectra of window w.  The windows in use span a few hundred to a few thousand counters -- a few dozen cache
+// lines: counted by global atomics directly, 10 M increments serialise on those lines (measured 2 ms at 10 M spectra).  Every
+// workgroup counts its share of the spectra in LDS first (when the span fits) and adds only its non-zero bins.
+constexpr int kWindowBins = 12288;
+__global__ __launch_bounds__(1024) void window_counts_kernel(WindowParts parts, double interval, int64_t n_windows,
+                                                             const int32_t* __restrict__ lo_hi, int32_t* __restrict__ counts) {
+    __shared__ int32_t bins[kWindowBins];
+    const float* __restrict__ mz = parts.mz[blockIdx.y];
+    const int64_t n = parts.n[blockIdx.y];
+    lo_hi += 2 * blockIdx.y;
+    counts += n_windows * blockIdx.y;
+    const int32_t lo = lo_hi[0], span = lo_hi[1] - lo_hi[0] + 1;
+    const bool local = span >= 1 && span <= kWindowBins;
+    if (local) {
+        for (int i = threadIdx.x; i < span; i += blockDim.x) bins[i] = 0;
+        __syncthreads();
+    }
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t w = (int32_t)window_of(mz[i], interval, n_windows);
+        if (local) atomicAdd(&bins[w - lo], 1); else atomicAdd(&counts[w], 1);
+    }
+    if (local) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < span; i += blockDim.x)
+            if (bins[i]) atomicAdd(&counts[lo + i], bins[i]);
+    }
+}
+
+__global__ void window_flags_kernel(const float* __restrict__ mz, int64_t n, double interval, int64_t n_windows,
+                                    const int32_t* __restrict__ owner, int rank, int32_t* __restrict__ flag) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        flag[i] = owner[window_of(mz[i], interval, n_windows)] == rank;
+}
+
+__global__ void window_compact_kernel(const float* __restrict__ mz, const int32_t* __restrict__ flag, const int64_t* __restrict__ pos,
+                                      int64_t n, int64_t* __restrict__ rows_out, float* __restrict__ mz_out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (flag[i]) {
+            rows_out[pos[i]] = i;
+            mz_out[pos[i]] = mz[i];
+        }
+}
+
 __global__ void nonzero_i32_kernel(const int32_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = in[i] != 0;
@@ -225,6 +303,70 @@ int fal_gather_f32(fal_ctx* ctx, const float* src, const int64_t* order, int64_t
     const int grid = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
     hipLaunchKernelGGL(gather_f32_kernel, dim3(grid), dim3(256), 0, ctx->stream, src, order, n, out);
     FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+int fal_window_counts(fal_ctx* ctx, const float* const* precursor_mz, const int64_t* n, int n_parts, double mz_interval,
+                      int64_t n_windows, int32_t* counts, int32_t* counts_host) {
+    FAL_REQUIRE(ctx && n_parts >= 0 && mz_interval > 0.0 && n_windows >= 1 && (n_parts == 0 || (precursor_mz && n && counts)),
+                FAL_EINVAL, "fal_window_counts: bad argument");
+    if (n_parts == 0) return FAL_OK;
+    FAL_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)n_windows * n_parts, ctx->stream));
+    int32_t* lo_hi_all = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int32_t) * 2 * (size_t)(n_parts + kWindowParts), (void**)&lo_hi_all));
+    for (int p0 = 0; p0 < n_parts; p0 += kWindowParts) {
+        int32_t* lo_hi = lo_hi_all + 2 * p0;
+        const int np = std::min(kWindowParts, n_parts - p0);
+        WindowParts parts;
+        int32_t init[2 * kWindowParts];
+        int64_t n_max = 0;
+        for (int p = 0; p < kWindowParts; ++p) {
+            parts.mz[p] = p < np ? precursor_mz[p0 + p] : nullptr;
+            parts.n[p] = p < np ? n[p0 + p] : 0;
+            FAL_REQUIRE(parts.n[p] >= 0 && (parts.n[p] == 0 || parts.mz[p]), FAL_EINVAL, "fal_window_counts: NULL array");
+            n_max = std::max(n_max, parts.n[p]);
+            init[2 * p] = INT32_MAX;
+            init[2 * p + 1] = 0;
+        }
+        FAL_TRY(ctx->upload(lo_hi, init, sizeof(init)));
+        if (n_max == 0) continue;
+        // the CUs are shared by the partitions of the launch
+        const int per = std::max(1, (2 * ctx->num_cus + np - 1) / np);
+        const dim3 grid((unsigned)std::min<int64_t>(ceil_div(n_max, 1024), per), (unsigned)np);
+        int32_t* c = counts + (int64_t)p0 * n_windows;
+        hipLaunchKernelGGL(window_range_kernel, grid, dim3(1024), 0, ctx->stream, parts, mz_interval, n_windows, lo_hi);
+        hipLaunchKernelGGL(window_counts_kernel, grid, dim3(1024), 0, ctx->stream, parts, mz_interval, n_windows, lo_hi, c);
+        FAL_CHECK_HIP(hipGetLastError());
+    }
+    if (counts_host) {
+        FAL_CHECK_HIP(hipMemcpyAsync(counts_host, counts, sizeof(int32_t) * (size_t)n_windows * n_parts, hipMemcpyDeviceToHost,
+                                     ctx->stream));
+        FAL_CHECK_HIP(hipMemcpyAsync(counts_host + n_windows * n_parts, lo_hi_all, sizeof(int32_t) * 2 * (size_t)n_parts,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return FAL_OK;
+}
+
+int fal_window_select(fal_ctx* ctx, const float* precursor_mz, int64_t n, double mz_interval, int64_t n_windows,
+                      const int32_t* owner, int rank, int64_t* rows_out, float* mz_out, int64_t* count) {
+    FAL_REQUIRE(ctx && n >= 0 && mz_interval > 0.0 && n_windows >= 1 && owner && count, FAL_EINVAL, "fal_window_select: bad argument");
+    *count = 0;
+    if (n == 0) return FAL_OK;
+    FAL_REQUIRE(precursor_mz && rows_out && mz_out, FAL_EINVAL, "fal_window_select: NULL array");
+    int32_t* flag = nullptr;
+    int64_t* pos = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int32_t) * (size_t)n, (void**)&flag));
+    FAL_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * (size_t)(n + 1), (void**)&pos));
+    const int grid = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(window_flags_kernel, dim3(grid), dim3(256), 0, ctx->stream, precursor_mz, n, mz_interval, n_windows, owner, rank, flag);
+    FAL_TRY(device_scan_i32(ctx, flag, n, pos, SLOT_SORT));
+    hipLaunchKernelGGL(window_compact_kernel, dim3(grid), dim3(256), 0, ctx->stream, precursor_mz, flag, pos, n, rows_out, mz_out);
+    FAL_CHECK_HIP(hipGetLastError());
+    int64_t* h = nullptr;
+    FAL_TRY(ctx->pinned_reserve(sizeof(int64_t), (void**)&h));
+    FAL_CHECK_HIP(hipMemcpyAsync(h, pos + n, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *count = *h;
     return FAL_OK;
 }
 

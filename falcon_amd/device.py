@@ -177,6 +177,49 @@ class Context:
               "fal_gather_f32")
         return out
 
+    N_WINDOWS = 1 << 14           # windows the multi-GPU front end counts (m/z < 16,383 x mz_interval; beyond: one shared window)
+
+    def window_counts(self, precursor_mzs, mz_interval: float):
+        """spectra per precursor window floor(mz / mz_interval) of every partition of a job (`fal_window_counts`: one pair of
+        launches, one copy to pinned host memory, one wait) -> int64 counts [n_parts, windows] (host), the all-zero trailing
+        windows cut"""
+        torch = _torch()
+        pmz = [self.to_dev(x, torch.float32) for x in precursor_mzs]
+        n_parts = len(pmz)
+        if n_parts == 0:
+            return np.zeros((0, 0), np.int64)
+        counts = self.empty((n_parts, self.N_WINDOWS), torch.int32)
+        if getattr(self, "_wc_host", None) is None or self._wc_host.numel() < n_parts * (self.N_WINDOWS + 2):
+            self._wc_host = torch.empty(n_parts * (self.N_WINDOWS + 2), dtype=torch.int32, pin_memory=True)
+        host = self._wc_host
+        ptrs = (C.c_void_p * n_parts)(*[x.data_ptr() if x.numel() else None for x in pmz])
+        ns = (C.c_int64 * n_parts)(*[x.numel() for x in pmz])
+        check(self.lib.fal_window_counts(self._h, ptrs, ns, n_parts, float(mz_interval), self.N_WINDOWS, self._p(counts),
+                                         C.c_void_p(host.data_ptr())), "fal_window_counts")
+        self.sync()
+        h = host.numpy()
+        last = h[n_parts * self.N_WINDOWS: n_parts * (self.N_WINDOWS + 2)].reshape(n_parts, 2)
+        last = last[last[:, 0] <= last[:, 1], 1]                                  # (empty partitions: INT32_MAX, 0)
+        width = int(last.max()) + 1 if len(last) else 0
+        return h[: n_parts * self.N_WINDOWS].reshape(n_parts, self.N_WINDOWS)[:, :width].astype(np.int64)
+
+    def window_select(self, precursor_mz, mz_interval: float, owner: np.ndarray, rank: int):
+        """the spectra whose window is dealt to `rank` (`fal_window_select`) -> rows i64[m] (ascending dataset rows), mz f32[m]"""
+        torch = _torch()
+        pmz = self.to_dev(precursor_mz, torch.float32)
+        n = pmz.numel()
+        own = np.full(self.N_WINDOWS, -1, np.int32)
+        own[:len(owner)] = owner
+        if len(owner):
+            own[len(owner):] = owner[-1]                  # (windows behind the counted ones hold no spectrum)
+        own_d = self.to_dev(own, torch.int32)
+        rows = self.empty((max(n, 1),), torch.int64)
+        mzs = self.empty((max(n, 1),), torch.float32)
+        m = C.c_int64()
+        check(self.lib.fal_window_select(self._h, self._p(pmz), n, float(mz_interval), self.N_WINDOWS, self._p(own_d), int(rank),
+                                         self._p(rows), self._p(mzs), C.byref(m)), "fal_window_select")
+        return rows[: m.value], mzs[: m.value]
+
     def precursor_splits(self, mz_sorted, tol: float, mode: str, batch_size: int, mz_interval: float = 1.0,
                          chunk_last: bool = True) -> np.ndarray:
         """reference cluster.py:159-209 (+ the build's two extra rules) -> int64 boundaries (host)"""

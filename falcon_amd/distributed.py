@@ -58,29 +58,70 @@ def shard_units(costs: np.ndarray, world_size: int) -> np.ndarray:
 
 def deal_units(costs: np.ndarray, world_size: int) -> np.ndarray:
     """Many units (precursor windows: hundreds to thousands per partition) dealt to ranks in one vectorised step: units by
-    decreasing cost, ranks in boustrophedon order (0 .. w-1, w-1 .. 0, ...).  Within a fraction of a per cent of the LPT
-    deal when costs vary smoothly, and O(n log n) in numpy where the heap loop of `shard_units` costs milliseconds of
-    Python per pass.  Deterministic: every rank derives the same deal from the same counts."""
+    decreasing cost, ranks in boustrophedon order (0 .. w-1, w-1 .. 0, ...).  Every rank gets the same MIX of units, so an
+    error of the cost model (per-spectrum cost drifts with m/z and charge) hits all ranks alike.  Within a fraction of a per
+    cent of the LPT deal when costs vary smoothly, and O(n log n) in numpy where the heap loop of `shard_units` costs
+    milliseconds of Python per pass.  Deterministic: every rank derives the same deal from the same counts."""
     costs = np.asarray(costs, np.float64)
     if world_size <= 1 or len(costs) == 0:
-        return np.zeros(len(costs), np.int64)
+        return np.zeros(len(costs), np.int32)
     order = np.argsort(-costs, kind="stable")
     i = np.arange(len(costs))
     r = i % (2 * world_size)
-    owner = np.empty(len(costs), np.int64)
+    owner = np.empty(len(costs), np.int32)
     owner[order] = np.where(r < world_size, r, 2 * world_size - 1 - r)
     return owner
+
+
+def deal_job(costs_list, world_size: int, tol: float = 0.03):
+    """The deal of a job of several partitions (precursor charges, falcon.py:151-160) to `world_size` GPUs; units = the
+    (partition, precursor window) blocks, `costs_list[j]` = the window costs of partition j.
+      * whole partitions, by longest-processing-time, when that balances within `tol` of the mean load: a rank then runs its
+        partitions exactly as one GPU would, with no per-partition work for the others (many similar partitions);
+      * otherwise every window of every partition is dealt on its own (`deal_units` over all of them): every rank gets a
+        like mix of windows of every partition.
+    Deterministic: every rank derives the same deal from the same counts.  -> [owner int32[n_windows_j] per partition]"""
+    sizes = [len(c) for c in costs_list]
+    totals = np.array([float(np.sum(c)) for c in costs_list], np.float64)
+    if world_size <= 1 or totals.sum() <= 0:
+        return [np.zeros(n, np.int32) for n in sizes]
+    whole = shard_units(totals, world_size)
+    loads = np.bincount(whole, weights=totals, minlength=world_size)
+    if loads.max() <= (1.0 + tol) * loads.mean():
+        return [np.full(n, whole[j], np.int32) for j, n in enumerate(sizes)]
+    owner = deal_units(np.concatenate([np.asarray(c, np.float64) for c in costs_list]), world_size)
+    out, at = [], 0
+    for n in sizes:
+        out.append(owner[at:at + n].copy())
+        at += n
+    return out
 
 
 def window_costs(counts: np.ndarray, batch_size: int, n_probe: int) -> np.ndarray:
     """Estimated cost of every precursor window from its spectrum count alone: the window becomes ceil(count / batch_size)
     buckets (the chunk rule of cluster.py:197-207; gaps inside a window, which would split it further, are not known
     before the window is sorted -- they only make the estimate pessimistic), each costed like `bucket_costs`."""
-    from .cluster.cluster import n_list_rule
     counts = np.asarray(counts, np.int64)
     chunks = np.maximum(1, -(-counts // max(int(batch_size), 1)))
-    size = counts // chunks
-    return chunks * bucket_costs(size, n_list_rule(size, n_probe), n_probe)
+    size = counts // chunks                                                   # <= batch_size
+    if batch_size > (1 << 20):
+        from .cluster.cluster import n_list_rule
+        return chunks * bucket_costs(size, n_list_rule(size, n_probe), n_probe)
+    return chunks * _bucket_cost_table(int(batch_size), int(n_probe))[size]
+
+
+_cost_tables = {}
+
+
+def _bucket_cost_table(batch_size: int, n_probe: int) -> np.ndarray:
+    """`bucket_costs` of a bucket of 0 .. batch_size spectra with the lists `n_list_rule` gives it (the plan of a multi-GPU
+    step looks tens of thousands of windows up per step)"""
+    key = (batch_size, n_probe)
+    if key not in _cost_tables:
+        from .cluster.cluster import n_list_rule
+        size = np.arange(max(batch_size, 1) + 1, dtype=np.int64)
+        _cost_tables[key] = bucket_costs(size, n_list_rule(size, n_probe), n_probe)
+    return _cost_tables[key]
 
 
 def allgather_counts(n_local: int, device) -> List[int]:

@@ -126,6 +126,21 @@ int fal_precursor_splits(fal_ctx* ctx, const float* precursor_mz_sorted /*[dev]*
                          double mz_interval, int chunk_last,
                          int64_t* splits_out /*[host]*/, int64_t max_splits, int64_t* n_splits);
 
+/* ---- e   the multi-GPU front end: whole precursor windows floor(mz / mz_interval) are the unit dealt to GPUs (buckets never
+ *          cross a window and a window's buckets depend on its own spectra only; reference analogue: blocks are
+ *          clustered independently, cluster.py:107-141).  fal_window_counts: all n_parts partitions (precursor charges) of a
+ *          job in one call -- precursor_mz[p] [host array of device pointers], n[p] [host] spectra of partition p,
+ *          counts[p * n_windows + w] [dev] = spectra of partition p in window w (windows >= n_windows - 1 share the last
+ *          counter; the call zeroes counts first); counts_host (optional, pinned host memory, n_parts * (n_windows + 2)
+ *          int32): the same table, then (first, last) occupied window of every partition (INT32_MAX, 0 for an empty
+ *          one), copied stream-ordered (valid after fal_ctx_sync).  fal_window_select: the spectra whose
+ *          window belongs to `rank` (owner[w], int32 per window) -- rows_out i64 ascending dataset rows, mz_out their
+ *          precursor m/z; *count [host] how many (synchronises).  Buffers need room for n entries. ------------- [dev] */
+int fal_window_counts(fal_ctx* ctx, const float* const* precursor_mz /*[host]*/, const int64_t* n /*[host]*/, int n_parts,
+                      double mz_interval, int64_t n_windows, int32_t* counts, int32_t* counts_host /*[pinned host] or NULL*/);
+int fal_window_select(fal_ctx* ctx, const float* precursor_mz, int64_t n, double mz_interval, int64_t n_windows,
+                      const int32_t* owner, int rank, int64_t* rows_out, float* mz_out, int64_t* count /*[host]*/);
+
 /* ---- a6  IVF build per bucket (k-means + inverted lists); the reference's only
  *          statement is README.md:134-136 (Faiss IndexIVFFlat, un-vendored dep
  *          setup.cfg:25).  X [dev] is [n, low_dim] float32 in precursor-sorted row order;

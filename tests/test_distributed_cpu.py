@@ -157,9 +157,9 @@ def test_shard_rows_and_merge_shards():
 
 
 def test_window_deal_is_balanced_and_deterministic():
-    """the multi-GPU front end deals whole precursor windows from their spectrum counts (`window_costs` + `deal_units`):
-    every unit gets exactly one owner, the deal is a pure function of the counts, and the estimated loads balance within 1 %
-    in both bucket regimes (flat 1 M-per-GPU windows, indexed 10 M windows, windows beyond batch_size)"""
+    """the multi-GPU front end deals (charge, precursor window) units from their spectrum counts (`window_costs` +
+    `deal_job`): every unit gets exactly one owner, the deal is a pure function of the counts, and the estimated loads balance
+    within 1 % in both bucket regimes (flat 1 M windows, indexed 10 M windows, windows beyond batch_size)"""
     from falcon_amd import distributed as fd
     rng = np.random.default_rng(5)
     for counts in (rng.integers(300, 1300, 800), rng.integers(7000, 10000, 800), rng.integers(30000, 70000, 800),
@@ -167,14 +167,40 @@ def test_window_deal_is_balanced_and_deterministic():
         costs = fd.window_costs(counts, 2 ** 15, 16)
         assert costs.shape == counts.shape and (costs >= 0).all()
         for world in (1, 2, 3, 8):
-            owner = fd.deal_units(costs, world)
-            assert owner.shape == counts.shape and ((owner >= 0) & (owner < world)).all()
-            assert np.array_equal(owner, fd.deal_units(costs.copy(), world))
+            parts = [costs, costs[: len(costs) // 3] * 0.4]                      # two unlike charge partitions of one dataset
+            owners = fd.deal_job(parts, world)
+            assert [o.shape for o in owners] == [c.shape for c in parts]
+            flat = np.concatenate(owners)
+            assert ((flat >= 0) & (flat < world)).all()
+            again = fd.deal_job([c.copy() for c in parts], world)
+            assert all(np.array_equal(x, y) for x, y in zip(owners, again))
             if len(counts) >= 100:
-                loads = np.array([costs[owner == r].sum() for r in range(world)])
+                loads = np.array([sum(c[o == r].sum() for c, o in zip(parts, owners)) for r in range(world)])
                 assert loads.max() <= 1.01 * loads.mean()
+                if world > 1:
+                    assert all(len(np.unique(o)) == world for o in owners)       # window by window: every rank, every partition
     # a window larger than batch_size is costed as its chunks (cluster.py:197-207)
     assert fd.window_costs(np.array([70000]), 2 ** 15, 16)[0] == 3 * fd.window_costs(np.array([23333]), 2 ** 15, 16)[0]
+
+
+def test_weak_scaling_deal_gives_every_rank_whole_partitions():
+    """bench.py --scaling weak: N statistically identical blocks as 2 N charge partitions -> every rank owns two WHOLE
+    partitions (a charge-2-sized and a charge-3-sized one), i.e. it runs them exactly as a single GPU would"""
+    from falcon_amd import distributed as fd
+    rng = np.random.default_rng(11)
+    for world in (2, 4, 8):
+        costs = []
+        for _ in range(world):
+            for mean in (875, 375):                                              # charge 2 (70 %), charge 3 (30 %)
+                c = np.zeros(1201, np.int64)
+                c[400:1200] = rng.poisson(mean, 800)
+                costs.append(fd.window_costs(c, 2 ** 15, 16))
+        owners = fd.deal_job(costs, world)
+        assert all(len(np.unique(o)) == 1 for o in owners)
+        whole = np.array([o[0] for o in owners])
+        for r in range(world):
+            mine = np.flatnonzero(whole == r)
+            assert len(mine) == 2 and sorted(mine % 2) == [0, 1]
 
 
 # ---------------------------------------------------------------------------------------------

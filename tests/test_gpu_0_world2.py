@@ -61,3 +61,34 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, 
         key = lambda t: t[:, np.lexsort((t[2], t[1], t[0]))]
         assert np.array_equal(key(e), key(r0["single_edges"]))
     assert (np.bincount(single) > 1).sum() > 20                               # a non-trivial clustering
+
+
+@pytest.mark.parametrize("scaling,extra", [
+    ("weak", ["--spectra", "150000"]),                   # 2 blocks -> 4 charge partitions, whole partitions per rank
+    ("strong", ["--spectra-total", "300000"]),           # one dataset, window by window
+])
+def test_bench_runs_as_a_two_rank_job(scaling, extra):
+    """bench.py's own N > 1 control flow (dataset of the scaling mode, the deal, the overlapped exchange, label assembly, max
+    over ranks) as two fresh ranks on GPU 0 -- its test hooks swap RCCL for gloo and pin both ranks to one device"""
+    import json
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("this pytest process already owns a GPU context: run tests/test_gpu_0_world2.py first / on its own")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", FALCON_BENCH_DEVICE="0", FALCON_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--scaling", scaling, "--no-configs", "--no-cpu-baseline"] + extra
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        log, _ = proc.communicate(timeout=900)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        log, _ = proc.communicate()
+        pytest.fail("two-rank bench timed out:\n" + log[-3000:])
+    assert proc.returncode == 0, log[-3000:]
+    lines = [l for l in log.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, log[-3000:]                                         # rank 0 prints ONE JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 3 and out["value"] > 0
+    assert out["unit"] == "spectra/s" and out["roofline"]["frac"] <= 1.0
+    assert abs(out["value"] - 300000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]

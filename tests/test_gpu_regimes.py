@@ -128,6 +128,45 @@ def test_config5_float16_vectors_low_dim_800_through_the_index(ctx):
     assert adjusted_rand_score(ref, lab_flat.cpu().numpy()) >= 0.99
 
 
+def test_many_partition_job_equals_single_gpu(ctx):
+    """bench.py --scaling weak on one device: a dataset of 2 blocks x 2 charges = 4 partitions, `PartitionRunner.run(shard=(r,
+    w))` for every r of w = 2 (whole partitions per rank where the deal balances) and w = 3 (window by window): the union of
+    the ranks' results is the single-GPU partition of every charge partition, every row exactly once"""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, PartitionRunner, SpectrumDataset
+    parts = []
+    for k in range(2):
+        data = synth.generate(7000, seed=31, first_block=k)
+        for ch in (2, 3):
+            c = synth.select_charge(data, ch)
+            parts.append(SpectrumDataset(*(ctx.to_dev(c[key], dt) for key, dt in (
+                ("precursor_mz", torch.float32), ("retention_time", torch.float32), ("mz", torch.float32),
+                ("intensity", torch.float32), ("indptr", torch.int64)))))
+    p = AnnParams(eps=0.3)
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, p)
+    runner = PartitionRunner(ctx.device, 2)
+    try:
+        single = [lab.cpu().numpy() for lab, _ in runner.run(parts, *args)]
+        for world in (2, 3):
+            merged = [np.full(len(ds), -1, np.int64) for ds in parts]
+            offs = [0] * len(parts)
+            for r in range(world):
+                outs = runner.run(parts, *args, shard=(r, world))
+                for j, ((lab, med), last) in enumerate(zip(outs, runner.lasts)):
+                    rows = last["rows"].cpu().numpy()
+                    lab, med = lab.cpu().numpy(), med.cpu().numpy()
+                    assert len(lab) == len(rows) and (merged[j][rows] == -1).all()
+                    merged[j][rows] = lab + offs[j]
+                    offs[j] += len(med)
+            for j in range(len(parts)):
+                assert (merged[j] >= 0).all()
+                pairs = np.unique(np.stack([single[j], merged[j]]), axis=1)
+                assert pairs.shape[1] == len(np.unique(single[j])) == len(np.unique(merged[j]))
+    finally:
+        runner.close()
+
+
 def test_bucket_sharded_run_many_equals_single_gpu(ctx):
     """bench.py's multi-GPU step on one device: `run_many(shard=(r, 3))` for r = 0, 1, 2 (the same buckets -> ranks
     assignment every rank derives) and `SparseGraphExchange.assemble_labels`-style merging give the single-GPU

@@ -1,7 +1,7 @@
 """Where a rank's time goes in the bucket-sharded job (strong scaling: ONE fixed dataset, default 10 M spectra, on `world`
-GPUs), measured on one GPU for rank 0: host-synchronised phases of `ClusterPipeline` (front = sort + bucket boundaries of the
-WHOLE dataset, replicated on every rank; restrict = the LPT deal + the rank's row subset; search; graph), next to the
-single-GPU pass of the same dataset.   python tools/shard_phases.py [world] [spectra]"""
+GPUs), measured on one GPU for rank 0: host-synchronised phases of `ClusterPipeline` (front = window histogram, deal, the rank's
+own sort and bucket boundaries; search; graph), next to the single-GPU pass of the same dataset.
+python tools/shard_phases.py [world] [spectra]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,17 +29,19 @@ def timed(fn):
 
 
 def one_pass(shard):
-    T = {"front": 0.0, "restrict": 0.0, "search": 0.0, "graph": 0.0}
-    for ds in parts:
-        st, t = timed(lambda: pipe._front(ctx, ds, *A, 2 ** 15, p)); T["front"] += t
+    T = {"plan": 0.0, "front": 0.0, "search": 0.0, "graph": 0.0}
+    if shard is not None:
+        owners, T["plan"] = timed(lambda: pipe.plan_shards(ctx, parts, 2 ** 15, p, shard[1]))
+    for j, ds in enumerate(parts):
         if shard is not None:
-            def restrict():
-                s2 = pipe._restrict(ctx, st, p, shard)
+            def front():
+                s2 = pipe._front_windows(ctx, ds, *A, 2 ** 15, p, shard, owner=owners[j])
                 s2["order_local"] = torch.arange(s2["rows"].numel(), dtype=torch.int64, device=ctx.tdev)
                 return s2
-            sub, t = timed(restrict); T["restrict"] += t
+            sub, t = timed(front); T["front"] += t
             run = dict(sub, order=sub["rows"])
         else:
+            st, t = timed(lambda: pipe._front(ctx, ds, *A, 2 ** 15, p)); T["front"] += t
             run = st
         _, t = timed(lambda: pipe._search(ds, run, *A, 0.05, p, False)); T["search"] += t
         if shard is not None:
