@@ -97,6 +97,20 @@ __device__ __forceinline__ int32_t uf_find(int32_t* parent, int32_t x) {
     return x;
 }
 
+// The find of the FINAL pass (every row -> its root, after all unions): no path halving.  With halving, a thread that has
+// loaded parent[i] and parent[parent[i]] may store that grandparent into parent[i] AFTER the row's own thread has stored
+// the root there -- parent[i] then names an ancestor that is not the root and the row gets the label slot of a non-root
+// (found by a 3,000-row chain in tests/test_gpu_linkage.py; shallow trees make it rare, not impossible).  Read-only finds
+// race with nothing: whatever a concurrent reader sees in parent[i] (the old link or the root) is an ancestor.
+__device__ __forceinline__ int32_t uf_find_final(const int32_t* parent, int32_t x) {
+    int32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+
 // hook the larger root under the smaller one (so every component's root is its lowest core row)
 __device__ __forceinline__ void uf_union(int32_t* parent, int32_t a, int32_t b) {
     while (true) {
@@ -130,8 +144,8 @@ __global__ void dbscan_roots_kernel(const int32_t* __restrict__ core, int32_t* _
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int32_t r = 0;
         if (core[i]) {
-            const int32_t root = uf_find(parent, (int32_t)i);
-            parent[i] = root;
+            const int32_t root = uf_find_final(parent, (int32_t)i);
+            __hip_atomic_store(&parent[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             r = root == (int32_t)i;
         }
         is_root[i] = r;

@@ -38,6 +38,16 @@ __device__ __forceinline__ int32_t lk_find(int32_t* parent, int32_t x) {
     return x;
 }
 
+// the final pass's find: read-only (graph.hip, uf_find_final: halving stores of other threads could overwrite a row's root)
+__device__ __forceinline__ int32_t lk_find_final(const int32_t* parent, int32_t x) {
+    int32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+
 __device__ __forceinline__ void lk_union(int32_t* parent, int32_t a, int32_t b) {
     while (true) {
         a = lk_find(parent, a);
@@ -68,8 +78,8 @@ __global__ void lk_edges_kernel(const int32_t* __restrict__ nb_idx, const float*
 
 __global__ void lk_roots_kernel(int32_t* __restrict__ parent, int32_t* __restrict__ count, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t root = lk_find(parent, (int32_t)i);
-        parent[i] = root;
+        const int32_t root = lk_find_final(parent, (int32_t)i);
+        __hip_atomic_store(&parent[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(&count[root], 1);
     }
 }

@@ -44,6 +44,11 @@ struct SelectArgs {
     int32_t* nb_count;           // [rows] stored neighbours per row, or nullptr
 };
 
+// the shared-stream form of the symmetric flat scan (scan.hip): XCD-list mode with xtile0 in 128-row groups
+bool dense4_supports(int d);
+int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, int64_t list_groups, float* sims,
+                  int64_t sims_base);
+int launch_dense_tiny4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base);
 // xcd_list_tiles > 0 selects XCD-list mode (simtile.h): `jobs` = the launch's jobs sorted by
 // decreasing size with xtile0 filled in, xcd_list_tiles = tiles of the longest of the 8 lists.
 int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,

@@ -128,6 +128,352 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// dense tile kernel, shared-stream form (flat buckets of more than 32 rows scanned against themselves)
+//
+// dense_kernel's four waves of a CU each stream their own candidates with one 16-byte load per lane and row: 64 cache
+// lines per load instruction, 3,200 line look-ups per wave and 32-candidate chunk -- the texture addresser, not the matrix
+// pipe, sets the pace (measured at 1 M spectra: 1.31 ms per launch; with the loads compiled out 0.83; with the same bytes
+// read 1 KB per instruction 0.98).  Here the four waves of a workgroup own four CONSECUTIVE 32-query tiles of one bucket and
+// share ONE candidate stream: a chunk's 32 rows arrive in LDS once, by row-contiguous LDS-DMA (`global_load_lds_dwordx4`:
+// 1 KB of one row per instruction, 8 lines), double-buffered; rows sit at a stride of 4 d + 16 bytes so that the MFMA
+// operand reads (lane = candidate row, 16 bytes of its k-half) are conflict-free.  The stream runs UPWARDS from the group's
+// own four diagonal chunks -- which are the query rows of its four tiles: a wave takes its queries into registers from LDS
+// when its chunk comes by and then meets every later chunk (blocks on and above the diagonal; every off-diagonal block is
+// stored twice, once transposed, as in dense_kernel).  Same k-ordered chain per block (simtile.h), same stores: the sims
+// are bit-identical.  A wave idles until the stream reaches its diagonal (the 4 x 4 corner of blocks costs 16 slots for 10
+// blocks).  Measured (s_memtime per workgroup): 16.6 k cycles per chunk against 12.8 k of MFMA issue.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool find_group_xcd(const DenseJob* __restrict__ jobs, int n_jobs, int x, int64_t i, int* job_index,
+                                               int* group) {
+    const int cnt = (n_jobs - x + 7) >> 3;
+    if (cnt <= 0) return false;
+    int lo = 0, hi = cnt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[x + 8 * mid].xtile0 <= i) lo = mid; else hi = mid - 1;
+    }
+    const DenseJob& j = jobs[x + 8 * lo];
+    const int64_t g = i - j.xtile0;                 // xtile0 counts 128-row groups here
+    if (g >= (j.nq + 127) / 128) return false;
+    *job_index = x + 8 * lo;
+    *group = (int)g;
+    return true;
+}
+
+template <int DH4>
+__global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict__ X, int d, const DenseJob* __restrict__ jobs,
+                                                        int n_jobs, float* __restrict__ sims, int64_t sims_base,
+                                                        int32_t* __restrict__ cursors) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stream_lds[];
+    __shared__ int32_t next_item;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    // Persistent workgroups, one per CU, that pull (bucket, group) items themselves: as one workgroup per item the launch
+    // left every CU idle for 19 us on average between two workgroups (median 7, 90th percentile 53: one 100 KB workgroup per
+    // CU, dispatched in order -- measured per CU with s_memtime).  Items of XCD list x (jobs x, x + 8, ...: simtile.h) are
+    // taken by the workgroups that RUN on XCD x (its L2 holds the bucket), in order, by a cursor per list; a workgroup
+    // whose own list is exhausted helps the next ones.
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    for (int turn = 0; turn < 8; ++turn) {
+    const int xl = (int)((xcc + turn) & 7);
+    for (;;) {
+    __syncthreads();                                         // (the previous item's last chunk has been read by every wave)
+    if (tid == 0) next_item = atomicAdd(&cursors[xl], 1);
+    __syncthreads();
+    const int item = next_item;
+    int ji, g;
+    if (!find_group_xcd(jobs, n_jobs, xl, item, &ji, &g)) break;
+    const DenseJob job = jobs[ji];
+    const int lt = 4 * g + w;                                // this wave's 32-query tile of the bucket
+    const int nc = job.nc, ncp = (nc + 31) & ~31;
+    const bool active = 32 * lt < job.nq;
+    const int dh = d >> 1, dh4 = dh >> 2;
+    const int row_bytes = d * 4, rs = row_bytes + 16;
+    unsigned char* const buf0 = stream_lds;
+    unsigned char* const buf1 = stream_lds + 32 * rs;
+    const unsigned char* const my0 = buf0 + r * rs + h * (dh * 4);      // this lane's operand row in either buffer
+    const unsigned char* const my1 = buf1 + r * rs + h * (dh * 4);
+
+    float* const out = sims + (job.obase - sims_base) + (int64_t)(32 * lt) * ncp + r;
+    float* const outT = sims + (job.obase - sims_base) + (int64_t)r * ncp + 32 * lt + 4 * h;
+    const int c_last = ((nc - 1) >> 5) << 5;
+    const int c_stop = 32 * lt;                              // this wave's diagonal chunk = its own query rows
+    const int c_first = 128 * g;                             // the group's first diagonal
+    const int n_chunks = (c_last - c_first) / 32 + 1;
+
+    // a chunk's 32 rows into LDS: wave w brings rows 8 w .. 8 w + 7, one KB of one row per instruction = one "piece".
+    // (inline asm, not the builtin: hipcc guards every later LDS read with `s_waitcnt vmcnt(0)` for a DMA it knows of,
+    //  which drains the stores and the next chunk's loads once per operand read; `chunk_barrier` below does the waiting)
+    constexpr int kParts = (DH4 * 32 + 1023) / 1024;
+    constexpr int kPieces = 8 * kParts;
+    auto issue_piece = [&](int k, int c0, unsigned char* buf) {
+        const int p = k / 8, row = 8 * w + (k & 7);
+        if (p * 1024 + lane * 16 < row_bytes) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(X + (job.c_row0 + min(c0 + row, nc - 1)) * d) +
+                                       p * 1024 + lane * 16;
+            const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)((uint32_t)(size_t)(__attribute__((address_space(3))) const void*)buf + (uint32_t)(row * rs + p * 1024)));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+        }
+    };
+    auto issue = [&](int c0, unsigned char* buf) {
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) issue_piece(k, c0, buf);
+    };
+
+    float q[DH4 * 4];
+    f32x16 prev;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) prev[i] = 0.f;
+    int prev_c0 = min(c_stop, c_last);
+    // the 20 stores of a finished block (first call: zeros into the diagonal chunk's slots, overwritten by the real
+    // epilogue later in program order): 16 rows of the block, then the transposed block in four 16-byte columns
+    constexpr int kStores = 20;
+    auto store_piece = [&](int k) {
+        if (k < 16) {
+            out[mfma32_row(k, h) * ncp + prev_c0] = prev[k];
+        } else {
+            const int gq = k - 16;
+            *reinterpret_cast<float4*>(outT + (int64_t)prev_c0 * ncp + 8 * gq) =
+                make_float4(prev[4 * gq], prev[4 * gq + 1], prev[4 * gq + 2], prev[4 * gq + 3]);
+        }
+    };
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int k = 0; k < kStores; ++k) store_piece(k);
+    };
+    // One chunk: DH4 steps of one 16-byte operand read + four MFMAs.  The wave's share of the NEXT chunk's DMA goes out one
+    // piece per step in the first half (issued as one burst the 16 KB stalled the wave's instruction stream -- and with it
+    // its MFMAs -- for 1,650 cycles per chunk), the previous block's stores one per step in the second half (900 cycles).
+    auto compute = [&](const unsigned char* lb, int c0, bool more, int next_c0, unsigned char* next_buf) {
+        constexpr int kRing = 4, kHalf = DH4 / 2;
+        constexpr int kDmaPer = (kPieces + kHalf - 1) / kHalf, kStPer = (kStores + (DH4 - kHalf) - 1) / (DH4 - kHalf);
+        auto ld = [&](int j) { return *reinterpret_cast<const float4*>(lb + 16 * (j < dh4 ? j : dh4 - 1)); };
+        float4 ring[kRing];
+#pragma unroll
+        for (int j = 0; j < kRing; ++j) ring[j] = ld(j);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DH4; ++j) {
+            const float4 s = ring[j % kRing];
+            if (j + kRing < DH4) ring[j % kRing] = ld(j + kRing);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 0], s.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 1], s.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 2], s.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[4 * j + 3], s.w, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (j < kHalf) {
+                if (more) {
+#pragma unroll
+                    for (int k = j * kDmaPer; k < (j + 1) * kDmaPer && k < kPieces; ++k) issue_piece(k, next_c0, next_buf);
+                }
+            } else {
+#pragma unroll
+                for (int k = (j - kHalf) * kStPer; k < (j - kHalf + 1) * kStPer && k < kStores; ++k) store_piece(k);
+                __builtin_amdgcn_sched_group_barrier(0x040, kStPer, 0);
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc));       // (simtile.h: the last MFMA's passes before the first read)
+        prev = acc;
+        prev_c0 = c0;
+    };
+    // The group's stream starts at its own four diagonal chunks -- which ARE the query rows of its four tiles: a wave takes
+    // its 32 rows into registers from LDS when its chunk comes by (no second pass over them; as one 16-byte load per lane and
+    // row straight from memory the 51 KB of a tile cost 15 us of every workgroup), then meets every later chunk.
+    auto take_queries = [&](const unsigned char* lb) {
+#pragma unroll
+        for (int j = 0; j < DH4; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < dh4) v = *reinterpret_cast<const float4*>(lb + 16 * j);
+            q[4 * j + 0] = v.x;
+            q[4 * j + 1] = v.y;
+            q[4 * j + 2] = v.z;
+            q[4 * j + 3] = v.w;
+        }
+    };
+    // Wait for this wave's share of the chunk issued one iteration ago, then meet the others.  VM operations retire in
+    // order: behind those loads the wave has issued at most one block's stores, which may stay in flight.
+    // (Three buffers with the loads two chunks ahead were measured: 17.6 k cycles per chunk against 16.6 k -- the chunk is
+    //  not waiting for its rows.  So was a rolled loop over a runtime buffer index: 17.9 k.)
+    bool stored = false;
+    auto chunk_barrier = [&]() {
+        if (stored) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kStores) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    issue(c_first, buf0);
+    for (int ci = 0, c0 = c_first; ci < n_chunks; ci += 2, c0 += 64) {
+        chunk_barrier();                                     // chunk ci has landed, buf1 is free again
+        stored = false;
+        if (active && c0 == c_stop) take_queries(my0);
+        if (active && c0 >= c_stop) {
+            compute(my0, c0, ci + 1 < n_chunks, c0 + 32, buf1);
+            stored = true;
+        } else if (ci + 1 < n_chunks) {
+            issue(c0 + 32, buf1);
+        }
+        if (ci + 1 >= n_chunks) break;
+        chunk_barrier();
+        stored = false;
+        if (active && c0 + 32 == c_stop) take_queries(my1);
+        if (active && c0 + 32 >= c_stop) {
+            compute(my1, c0 + 32, ci + 2 < n_chunks, c0 + 64, buf0);
+            stored = true;
+        } else if (ci + 2 < n_chunks) {
+            issue(c0 + 64, buf0);
+        }
+    }
+    if (active) epilogue();
+    }
+    }
+}
+
+// Buckets of up to 32 rows: one 32 x 32 block each, query rows = candidate rows = the SAME registers (lane (r, h) holds row r's
+// k-half h for either operand).  A persistent workgroup takes four such buckets at a time, one per wave; the rows arrive by
+// row-contiguous LDS-DMA (two buckets per round: the staging area is dense4_kernel's) and each wave runs its chain with
+// A = B = its registers.  (As one-wave workgroups of dense_kernel these buckets cost 66 us per tile: 15 us of
+// lane-strided row loads, the dispatch of 14,000 workgroups, one chunk of work.)
+template <int DH4>
+__global__ __launch_bounds__(256, 1) void dense_tiny4_kernel(const float* __restrict__ X, int d, const DenseJob* __restrict__ jobs,
+                                                             int n_jobs, float* __restrict__ sims, int64_t sims_base,
+                                                             int32_t* __restrict__ cursor) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stream_lds[];
+    __shared__ int32_t next_item;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int dh = d >> 1, dh4 = dh >> 2;
+    const int row_bytes = d * 4, rs = row_bytes + 16;
+    constexpr int kParts = (DH4 * 32 + 1023) / 1024;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)stream_lds;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) next_item = atomicAdd(cursor, 1);
+        __syncthreads();
+        const int j0 = 4 * next_item;
+        if (j0 >= n_jobs) break;
+        const bool active = j0 + w < n_jobs;
+        float q[DH4 * 4];
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if (round) __syncthreads();                      // (the first round's rows have been taken)
+            // 64 staging rows = two buckets of up to 32 rows; wave w brings staging rows 16 w .. 16 w + 15
+            const int jb = j0 + 2 * round + (w >> 1);        // the bucket of this wave's 16 staging rows
+            if (jb < n_jobs) {
+                const int64_t row0 = jobs[jb].c_row0;
+                const int nb = jobs[jb].nq;
+#pragma unroll
+                for (int p = 0; p < kParts; ++p) {
+                    if (p * 1024 + lane * 16 < row_bytes) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int sr = 16 * w + i;                                    // staging row
+                            const unsigned char* src = reinterpret_cast<const unsigned char*>(X + (row0 + min(sr & 31, nb - 1)) * d) +
+                                                       p * 1024 + lane * 16;
+                            const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + (uint32_t)(sr * rs + p * 1024)));
+                            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if ((w >> 1) == round && active) {
+                const unsigned char* lb = stream_lds + ((w & 1) * 32 + r) * rs + h * (dh * 4);
+#pragma unroll
+                for (int j = 0; j < DH4; ++j) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (j < dh4) v = *reinterpret_cast<const float4*>(lb + 16 * j);
+                    q[4 * j + 0] = v.x;
+                    q[4 * j + 1] = v.y;
+                    q[4 * j + 2] = v.z;
+                    q[4 * j + 3] = v.w;
+                }
+            }
+        }
+        if (!active) continue;
+        const DenseJob job = jobs[j0 + w];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < DH4 * 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[j], q[j], acc, 0, 0, 0);
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc));       // (simtile.h: the last MFMA's passes before the first read)
+        float* const out = sims + (job.obase - sims_base) + r;   // one [32, 32] block (nc <= 32)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out[mfma32_row(i, h) * 32] = acc[i];
+    }
+}
+
+
+bool dense4_supports(int d) { return d % 8 == 0 && d >= 32 && d <= 400; }   // (low_dim 512: the 64-step form needs scratch)
+
+// `list_groups` = the longest XCD list in 128-row groups (jobs[j].xtile0 counts groups)
+int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, int64_t list_groups, float* sims,
+                  int64_t sims_base) {
+    if (n_jobs <= 0 || list_groups <= 0) return FAL_OK;
+    const int dh4 = d / 8;
+    FAL_REQUIRE(list_groups * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
+    const size_t lds = (size_t)2 * 32 * (d * 4 + 16);
+    int32_t* cursors = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_CURSORS, sizeof(int32_t) * 16, (void**)&cursors));
+    dim3 grid((unsigned)std::min<int64_t>(list_groups * 8, ctx->num_cus)), block(256);
+    StageScope ts(ctx, ST_SCAN);
+    StageScope tk(ctx, ST_KERNEL);
+    FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t) * 8, ctx->stream));
+#define FAL_LAUNCH_DENSE4(DH4)                                                                                      \
+    do {                                                                                                            \
+        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)dense4_kernel<DH4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds));                                                               \
+        hipLaunchKernelGGL((dense4_kernel<DH4>), grid, block, lds, ctx->stream, X, d, jobs, n_jobs, sims, sims_base, \
+                           cursors);                                                                                \
+    } while (0)
+    if (dh4 <= 8) FAL_LAUNCH_DENSE4(8);
+    else if (dh4 <= 16) FAL_LAUNCH_DENSE4(16);
+    else if (dh4 <= 32) FAL_LAUNCH_DENSE4(32);
+    else if (dh4 <= 50) FAL_LAUNCH_DENSE4(50);
+    else {
+        set_error("dense4 supports low_dim <= 400 (got %d)", d);
+        return FAL_EUNSUPPORTED;
+    }
+#undef FAL_LAUNCH_DENSE4
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+// jobs of up to 32 rows each (any order)
+int launch_dense_tiny4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base) {
+    if (n_jobs <= 0) return FAL_OK;
+    const int dh4 = d / 8;
+    const size_t lds = (size_t)2 * 32 * (d * 4 + 16);
+    int32_t* cursors = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_CURSORS, sizeof(int32_t) * 16, (void**)&cursors));
+    cursors += 8;                                            // (the first eight are dense4_kernel's, possibly still in use)
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div(n_jobs, 4), ctx->num_cus)), block(256);
+    StageScope ts(ctx, ST_SCAN);
+    StageScope tk(ctx, ST_KERNEL);
+    FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t), ctx->stream));
+#define FAL_LAUNCH_TINY4(DH4)                                                                                       \
+    do {                                                                                                            \
+        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)dense_tiny4_kernel<DH4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds));                                                               \
+        hipLaunchKernelGGL((dense_tiny4_kernel<DH4>), grid, block, lds, ctx->stream, X, d, jobs, n_jobs, sims, sims_base, \
+                           cursors);                                                                                \
+    } while (0)
+    if (dh4 <= 8) FAL_LAUNCH_TINY4(8);
+    else if (dh4 <= 16) FAL_LAUNCH_TINY4(16);
+    else if (dh4 <= 32) FAL_LAUNCH_TINY4(32);
+    else if (dh4 <= 50) FAL_LAUNCH_TINY4(50);
+    else {
+        set_error("dense_tiny4 supports low_dim <= 400 (got %d)", d);
+        return FAL_EUNSUPPORTED;
+    }
+#undef FAL_LAUNCH_TINY4
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
 template <int EPI>
 static int launch_dense_t(fal_ctx* ctx, int stage, const float* Q, const float* Cm, int d, const DenseJob* jobs,
                           int n_jobs, int64_t tile_begin, int64_t n_tiles, float* sims, int64_t sims_base,

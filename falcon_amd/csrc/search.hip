@@ -271,40 +271,50 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         ctx->counters[3] = 0;
         border.clear();                       // nothing left for the staged flat path
     }
-    // a batch = jobs [j0, j1): [j0, jm) go to the f16-MFMA kernel (128-query tiles), [jm, j1) to the fp32 one
-    struct FlatBatch { size_t j0, jm, j1; int64_t tiles, list_tiles16, list_tiles32, floats; };
+    // a batch = jobs [j0, j1): [j0, jm) go to the f16-MFMA kernel (128-query tiles), [jm, jk) to the shared-stream fp32 kernel
+    // (groups of four 32-query tiles), [jk, j1) to the one-wave fp32 kernel
+    struct FlatBatch { size_t j0, jm, jk, j1; int64_t tiles, list_tiles16, list_groups4, list_tiles32, floats; };
     std::vector<FlatBatch> flat_batches;
     size_t need_flat = 0;
     const bool have16 = ivf->X16 != nullptr;
+    const bool have4 = ivf->X && dense4_supports(d);       // the shared-stream fp32 kernels (scan.hip)
     const int64_t thr16 = (ivf->X && d <= 512) ? 64 : 0;   // without float32 rows (or beyond the fp32 kernel's low_dim) everything takes the f16 kernel
     FAL_REQUIRE(have16 || ivf->X || border.empty(), FAL_EINVAL, "fal_ivf_search_topk: the index has no vectors to scan");
     {
-        FlatBatch cur{0, 0, 0, 0, 0, 0, 0};
-        int64_t xt16[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        FlatBatch cur{0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t xt16[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt4[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         auto close = [&]() {
             if (cur.j1 > cur.j0) {
                 cur.list_tiles16 = *std::max_element(xt16, xt16 + 8);
+                cur.list_groups4 = *std::max_element(xt4, xt4 + 8);
                 cur.list_tiles32 = *std::max_element(xt32, xt32 + 8);
                 flat_batches.push_back(cur);
                 need_flat = std::max(need_flat, (size_t)cur.floats);
             }
-            cur = FlatBatch{cur.j1, cur.j1, cur.j1, 0, 0, 0, 0};
+            cur = FlatBatch{cur.j1, cur.j1, cur.j1, cur.j1, 0, 0, 0, 0, 0};
             std::fill(xt16, xt16 + 8, 0);
+            std::fill(xt4, xt4 + 8, 0);
             std::fill(xt32, xt32 + 8, 0);
         };
         for (int64_t b : border) {
             const int64_t row0 = ivf->bucket_off[b], nb = ivf->bucket_off[b + 1] - row0;
             const int64_t tiles = ceil_div(nb, 32), floats = tiles * 32 * ((nb + 31) & ~31ll);
             if (cur.floats + floats > (int64_t)cap && cur.j1 > cur.j0) close();
-            const bool use16 = have16 && nb >= thr16;      // sizes are non-increasing: the f16 part is a prefix
+            const bool use16 = have16 && nb >= thr16;      // sizes are non-increasing: the f16 part is a prefix ...
+            const bool use4 = !use16 && have4 && nb > 32;  // ... and the shared-stream part follows it; then the one-block buckets
             int64_t xtile0;
             if (use16) {
                 const int x = (int)((cur.j1 - cur.j0) & 7);
                 xtile0 = xt16[x];
                 xt16[x] += ceil_div(nb, 128);
-                cur.jm = cur.j1 + 1;
-            } else {
+                cur.jm = cur.jk = cur.j1 + 1;
+            } else if (use4) {
                 const int x = (int)((cur.j1 - cur.jm) & 7);
+                xtile0 = xt4[x];
+                xt4[x] += ceil_div(nb, 128);
+                cur.jk = cur.j1 + 1;
+            } else {
+                const int x = (int)((cur.j1 - cur.jk) & 7);
                 xtile0 = xt32[x];
                 xt32[x] += tiles;
             }
@@ -385,9 +395,13 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         if (fb.jm > fb.j0)
             FAL_TRY(launch_scan16(ctx, ivf->x16_planes, ivf->X16, d, jb, (int)(fb.jm - fb.j0), fb.list_tiles16, buf, 0,
                                   buf + sims_floats));
-        if (fb.j1 > fb.jm)
-            // (flat buckets keep their rows' positions in list order: the sorted rows serve)
-            FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->X, ivf->X, d, flat_dev + fb.jm, (int)(fb.j1 - fb.jm), 0,
+        // (flat buckets keep their rows' positions in list order: the sorted rows serve)
+        if (fb.jk > fb.jm)
+            FAL_TRY(launch_dense4(ctx, ivf->X, d, flat_dev + fb.jm, (int)(fb.jk - fb.jm), fb.list_groups4, buf, 0));
+        if (fb.j1 > fb.jk && have4)
+            FAL_TRY(launch_dense_tiny4(ctx, ivf->X, d, flat_dev + fb.jk, (int)(fb.j1 - fb.jk), buf, 0));
+        else if (fb.j1 > fb.jk)
+            FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->X, ivf->X, d, flat_dev + fb.jk, (int)(fb.j1 - fb.jk), 0,
                                  fb.tiles, buf, 0, nullptr, fb.list_tiles32));
         SelectArgs sa{};
         sa.sims = buf; sa.sims_base = 0; sa.k = k_ann; sa.out_sim = sim; sa.out_idx = idx;

@@ -297,6 +297,27 @@ def test_refine_small_and_large_clusters_match_oracle(ctx, rt_tol):
     assert np.array_equal(out.cpu().numpy(), exp)
 
 
+def test_dbscan_long_chains_get_one_label_each(ctx):
+    """components that are long CHAINS (row i's only neighbour is row i + 1): the union-find trees are deep when the final pass
+    maps every row to its root.  That pass once compressed paths while it stored the roots -- another thread's halving store
+    could land on top of a row's root and the row got the label slot of a non-root (seen on a 3,000-row chain; rare on
+    shallow trees, not impossible).  Repeated: the race was timing dependent."""
+    import torch
+    n, k, seg = 60000, 4, 3000
+    idx = np.full((n, k), -1, np.int32)
+    dist = np.full((n, k), np.inf, np.float32)
+    i = np.arange(n)
+    link = (i % seg) != seg - 1                                # chains of 3,000 rows
+    idx[link, 0] = i[link] + 1
+    dist[link, 0] = 0.05
+    ti, td = torch.from_numpy(idx).to(ctx.tdev), torch.from_numpy(dist).to(ctx.tdev)
+    exp = (i // seg).astype(np.int32)
+    for rep in range(20):
+        lab, n_cl = ctx.dbscan(ti, td, 0.1)
+        assert n_cl == n // seg
+        assert np.array_equal(lab.cpu().numpy(), exp), rep
+
+
 def test_star_graphs_more_clusters_than_half_the_rows(ctx):
     """DBSCAN clusters may hold ONE member: cores 0..3 of a star each keep only the non-core border 4 as their
     eps-neighbour, so 5 rows form 4 clusters (the refine arrays were sized for n/2 + 1 clusters).

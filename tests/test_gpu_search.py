@@ -26,11 +26,13 @@ def unit_vectors(n, d, seed, n_centers=None, noise=0.25):
     return (X / np.where(nrm > 0, nrm, 1)).astype(np.float32)
 
 
-@pytest.mark.parametrize("d,k", [(400, 128), (400, 64), (64, 16), (512, 200), (200, 7)])
+@pytest.mark.parametrize("d,k", [(400, 128), (400, 64), (64, 16), (512, 200), (200, 7), (128, 32), (256, 100)])
 def test_flat_exhaustive_topk(ctx, d, k):
-    """flat buckets == brute-force cosine top-k inside each bucket (SURVEY 8c ground truth)."""
+    """flat buckets == brute-force cosine top-k inside each bucket (SURVEY 8c ground truth).  Sizes cover the three forms of
+    the fp32 scan: one block per bucket (<= 32 rows: dense_tiny4_kernel), groups of four tiles sharing a candidate stream
+    (dense4_kernel: partial groups, partial last tiles, many groups), and dense_kernel (low_dim 512)."""
     import torch
-    sizes = [1, 2, 31, 32, 33, 100, 257, 700, 1500]
+    sizes = [1, 2, 31, 32, 33, 100, 128, 129, 257, 700, 1500, 7, 19, 30]
     off = np.concatenate([[0], np.cumsum(sizes)])
     X = unit_vectors(off[-1], d, 3)
     X[off[4]:off[4] + 5] = X[off[4]]                 # exact duplicates -> exact ties

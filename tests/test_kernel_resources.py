@@ -33,6 +33,8 @@ def _kernel_scratch(src, tmp_path):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src,pattern,expected", [
     ("scan.hip", "dense_kernel", 10),          # DH4 in {8,16,32,50,64} x {store, arg-max}
+    ("scan.hip", "dense4_kernel", 4),          # the shared-stream flat scan: DH4 in {8,16,32,50}
+    ("scan.hip", "dense_tiny4_kernel", 4),
     ("scan16.hip", "scan16_kernel", 10),
     ("ivf_fine.hip", "ivf_list4_kernel", 5),
     ("assign.hip", "assign_kernel", 5),
