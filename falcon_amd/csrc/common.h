@@ -73,7 +73,7 @@ struct fal_ctx {
     int32_t* fb_host = nullptr;           // pinned, 16 words, zeroed at creation: [0] / [2] fallback queries of the last prefiltered
                                           // search (flat / IVF buckets), [1] ambiguous rows of the last k-means pass
     int32_t* zero_dev = nullptr;          // 16 zero words on the device (stream-ordered resets of fb_host)
-    int64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t counters[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // caching device allocator for per-call objects (index arrays): blocks are recycled, never
     // returned to the driver before the context dies (hipMalloc / hipFree cost ~100 us each and

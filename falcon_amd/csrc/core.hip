@@ -202,7 +202,7 @@ int fal_ctx_enable_timing(fal_ctx* c, int on) {
 }
 
 int fal_ctx_counter(fal_ctx* c, int which, int64_t* value) {
-    FAL_REQUIRE(c && value && which >= 0 && which < 8, FAL_EINVAL, "fal_ctx_counter: bad argument");
+    FAL_REQUIRE(c && value && which >= 0 && which < 10, FAL_EINVAL, "fal_ctx_counter: bad argument");
     *value = c->counters[which];
     if (which == 5) *value = c->fb_host ? (int64_t)c->fb_host[0] + (int64_t)c->fb_host[2] : 0;   // fallback queries of the last prefiltered search: flat + IVF buckets (after a sync)
     return FAL_OK;

@@ -451,8 +451,7 @@ int launch_dense_tiny4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs
     FAL_TRY(ctx->reserve(SLOT_CURSORS, sizeof(int32_t) * 16, (void**)&cursors));
     cursors += 8;                                            // (the first eight are dense4_kernel's, possibly still in use)
     dim3 grid((unsigned)std::min<int64_t>(ceil_div(n_jobs, 4), ctx->num_cus)), block(256);
-    StageScope ts(ctx, ST_SCAN);
-    StageScope tk(ctx, ST_KERNEL);
+    StageScope ts(ctx, ST_SCAN);                             // (not ST_KERNEL: that stage times the dominant kernel alone)
     FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t), ctx->stream));
 #define FAL_LAUNCH_TINY4(DH4)                                                                                       \
     do {                                                                                                            \
@@ -516,6 +515,8 @@ int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* 
                                       xcd_list_tiles);
 }
 
+// (Four queries per workgroup, taken in turn -- a test of whether the dispatch of 700,000 one-wave workgroups bounds the flat
+//  select of 1 M spectra: 0.54 -> 0.80 ms per launch.  It does not; the waves in flight do.)
 template <int MODE, bool FUSE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_DENSE ? 8 : 3, 8))) void select_kernel(SelectArgs a) {
     __shared__ uint32_t sel_u[kSelBuf];       // the selected set (+ room for one streamed chunk of a long row)
@@ -524,13 +525,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE
     __shared__ int64_t seg_src[FAL_MAX_N_PROBE];       // MODE_IVF: perm position of each probed list
     const int lane = threadIdx.x;
     const int k = a.k;
+    const unsigned qblock = blockIdx.x;
 
     // ---- locate this query ---------------------------------------------------------------
     SelQuery qy{nullptr, 0, 0};
     int64_t out_row = 0;
-    const int64_t t = a.tile_begin + (blockIdx.x >> 5);
-    const int ql = blockIdx.x & 31;
-    const DenseJob job = a.jobs[a.tile_job[blockIdx.x >> 5]];
+    const int64_t t = a.tile_begin + (qblock >> 5);
+    const int ql = qblock & 31;
+    const DenseJob job = a.jobs[a.tile_job[qblock >> 5]];
     const int lt = (int)(t - job.tile0);
     if (32 * lt + ql >= job.nq) return;
     if (MODE == MODE_DENSE) {

@@ -420,6 +420,13 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             ctx->counters[4] += 1024 * (ch * (ch + 1) / 2);   // both kernels: blocks on/above the diagonal (f16: + up to 3 per 128-row tile)
         }
     for (const DenseJob& j : flat) ctx->counters[0] += (int64_t)j.nq * j.nc;
+    ctx->counters[7] = ctx->counters[8] = 0;               // the one-block buckets (dense_tiny4_kernel: outside stage 8)
+    if (have4)
+        for (const FlatBatch& fb : flat_batches)
+            for (size_t j = fb.jk; j < fb.j1; ++j) {
+                ctx->counters[7] += (int64_t)flat[j].nq * flat[j].nc;
+                ctx->counters[8] += 1024;
+            }
     ctx->counters[1] = 0;
     if (!fused) {
         ctx->counters[2] = (int64_t)flat_batches.size();

@@ -61,8 +61,9 @@ int fal_ctx_sync(fal_ctx* ctx);
 /* Elapsed milliseconds (HIP events on the context's stream) of the kernels the LAST
  * call of the named stage enqueued; used by bench.py for the roofline figure.
  * stage: 0 vectorize, 1 kmeans/ivf build, 2 coarse probe, 3 fine scan (cosine kernel),
- * 4 top-k select, 5 filter, 6 dbscan, 7 tail, 8 the launches of the cosine kernel alone (dense_kernel /
- * scan16_kernel / list16_kernel / ivf_list4_kernel; a subset of stage 3: the exact pair chains are not in it). */
+ * 4 top-k select, 5 filter, 6 dbscan, 7 tail, 8 the launches of the cosine kernel alone (dense4_kernel / dense_kernel /
+ * scan16_kernel / list16_kernel / ivf_list4_kernel; a subset of stage 3: the exact pair chains and the one-block
+ * buckets' dense_tiny4_kernel are not in it). */
 int fal_ctx_stage_ms(fal_ctx* ctx, int stage, float* ms, int64_t* launches);
 int fal_ctx_enable_timing(fal_ctx* ctx, int on);
 /* Work counters of the LAST fal_ivf_search_topk on this context (for roofline accounting):
@@ -75,7 +76,9 @@ int fal_ctx_enable_timing(fal_ctx* ctx, int on);
  * which = 5: queries of the last prefiltered search that took the exact fallback (after a sync);
  * which = 6: precondition check of the float16 prefilters for the LAST index built on this context: bit 0 = rows of
  *            an indexed bucket, bit 1 = rows handed to the flat prefilter hold negative / non-finite components, so
- *            that index is built / searched with the exact kernels (see fal_ivf_build_x16). */
+ *            that index is built / searched with the exact kernels (see fal_ivf_build_x16);
+ * which = 7, 8: the part of counters 0 and 4 that belongs to flat buckets of up to 32 rows, whose kernel is not
+ *            timed under stage 8 (subtract them to price stage 8's launches). */
 int fal_ctx_counter(fal_ctx* ctx, int which, int64_t* value);
 
 /* ---- a1  bin geometry: reference spectrum.py:172-199 `get_dim` (float32) --- [host] */

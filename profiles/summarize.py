@@ -14,7 +14,7 @@ import statistics
 import sys
 
 GROUPS = {  # kernel-name substring -> stage key
-    "vectorize_kernel": "vectorize", "dense_kernel": "scan", "scan16_kernel": "scan", "ivf_list_kernel": "scan",
+    "vectorize_kernel": "vectorize", "dense_kernel": "scan", "dense4_kernel": "scan", "dense_tiny4_kernel": "scan", "scan16_kernel": "scan", "ivf_list_kernel": "scan",
     "ivf_list4_kernel": "scan", "approx_kernel": "prefilter_approx", "band_kernel": "prefilter_band",
     "resolve_kernel": "prefilter_resolve", "fused_fallback_kernel": "prefilter_fallback",
     "assign16_kernel": "kmeans_assign16", "assign_exact_rows": "kmeans_exact_rows", "assign_kernel": "kmeans_assign",

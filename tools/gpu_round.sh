@@ -25,5 +25,5 @@ for c in j.get('configs', []):
 print(j.get('cpu_baseline'))
 j = json.load(open('gpurun_out/r3_bench_1M_pipelined_under_rocprof.json')); print('pipelined under rocprof', j['value'], j['roofline']['avg_launch_ms'])
 PY
-grep "dense_kernel<50, 0>" $O/r3_bench_1M_pipelined_kernel_stats.csv | cut -c1-60,170-260
-grep "dense_kernel<50, 0>" $O/r3_bench_1M_kernel_stats.csv | cut -c1-60,170-260
+grep "dense4_kernel<50>" $O/r3_bench_1M_pipelined_kernel_stats.csv | cut -c1-60,170-260
+grep "dense4_kernel<50>" $O/r3_bench_1M_kernel_stats.csv | cut -c1-60,170-260

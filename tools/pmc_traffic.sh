@@ -20,7 +20,7 @@ run 10M_f16 $R/tools/scale_run.py 10000000 f32 16 f16 800
 python3 - <<'PY'
 import sqlite3, collections, json, os
 R = os.environ["GRAFT_REPO_ROOT"]
-KERNEL = {"headline": "dense_kernel<50, 0>", "10M_f32": "list16_kernel", "10M_f32_dense": "list16_kernel", "10M_f16": "list16_kernel"}
+KERNEL = {"headline": "dense4_kernel<50>", "10M_f32": "list16_kernel", "10M_f32_dense": "list16_kernel", "10M_f16": "list16_kernel"}
 def agg(db, counter):
     d = collections.defaultdict(lambda: [0, 0.0])
     for name, v in sqlite3.connect(db).execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
