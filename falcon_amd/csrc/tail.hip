@@ -356,6 +356,7 @@ __global__ void cluster_size_kernel(const int32_t* __restrict__ labels, int64_t 
 __global__ __launch_bounds__(256) void medoid_score_kernel(const int32_t* __restrict__ labels, int64_t n,
                                                            const int32_t* __restrict__ nb_idx,
                                                            const float* __restrict__ nb_dist, int k,
+                                                           const int32_t* __restrict__ extent,
                                                            const int32_t* __restrict__ size,
                                                            unsigned long long* __restrict__ best) {
     // one wave per row: coalesced row read, same-cluster slots found by ballot, then their
@@ -366,11 +367,12 @@ __global__ __launch_bounds__(256) void medoid_score_kernel(const int32_t* __rest
         if (l < 0) continue;
         float s = 0.f;
         int same = 0;
-        for (int c0 = 0; c0 < k; c0 += 64) {
+        const int ext = extent ? extent[i] : k;           // (a9's row extents: nothing is stored beyond)
+        for (int c0 = 0; c0 < ext; c0 += 64) {
             const int c = c0 + lane;
             int32_t j = -1;
             float dv = 0.f;
-            if (c < k) {
+            if (c < ext) {
                 j = nb_idx[i * k + c];
                 dv = nb_dist[i * k + c];
             }
@@ -461,7 +463,7 @@ int fal::refine_dev(fal_ctx* ctx, int32_t* labels, int64_t n, const float* mz, c
 // a11 + a12 on a device-resident cluster count; the number of noise rows is left at *d_noise_out
 int fal::finalize_dev(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, const int64_t* d_count,
                       const int64_t* row_order, const int32_t* nb_idx, const float* nb_dist, int k,
-                      int32_t* labels_out, int32_t* medoids_out, int64_t** d_noise_out) {
+                      int32_t* labels_out, int32_t* medoids_out, int64_t** d_noise_out, const int32_t* extent) {
     hipStream_t st = ctx->stream;
     const int64_t cmax = n + 1;               // fal_finalize accepts any n_clusters <= n (single-member clusters included)
     int32_t *size = nullptr, *noise = nullptr;
@@ -477,7 +479,7 @@ int fal::finalize_dev(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, con
     {
         StageScope ts(ctx, ST_TAIL);
         hipLaunchKernelGGL(cluster_size_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, size, row_order, noise);
-        hipLaunchKernelGGL(medoid_score_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64)), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, size, best);
+        hipLaunchKernelGGL(medoid_score_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64)), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, extent, size, best);
         FAL_TRY(device_scan_i32(ctx, noise, n, rank, SLOT_TAIL3));
         hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, d_count, row_order, rank,
                            best, labels_out, medoids_out);
@@ -543,12 +545,13 @@ static int cluster_graph_impl(fal_ctx* ctx, const int32_t* nb_idx, const float* 
     FAL_REQUIRE(nb_idx && nb_dist && precursor_mz_sorted && row_order && labels_sorted_scratch && labels_out && medoids_out,
                 FAL_EINVAL, "fal_cluster_graph: NULL array");
     int64_t *d_db = nullptr, *d_cl = nullptr, *d_noise = nullptr;
+    const int32_t* extent = nullptr;                      // a9's row extents (SLOT_DB: not touched by a10 / a11)
     ctx->stage_reset(ST_TAIL);
-    if (method < 0) FAL_TRY(dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels_sorted_scratch, &d_db));
+    if (method < 0) FAL_TRY(dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels_sorted_scratch, &d_db, &extent));
     else FAL_TRY(linkage_dev(ctx, nb_idx, nb_dist, n, k, eps, method, labels_sorted_scratch, &d_db));
     FAL_TRY(refine_dev(ctx, labels_sorted_scratch, n, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol, d_db, &d_cl));
     FAL_TRY(finalize_dev(ctx, labels_sorted_scratch, n, d_cl, row_order, nb_idx, nb_dist, k, labels_out, medoids_out,
-                         &d_noise));
+                         &d_noise, extent));
     int64_t h[2] = {0, 0};
     FAL_CHECK_HIP(hipMemcpyAsync(&h[0], d_cl, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     FAL_CHECK_HIP(hipMemcpyAsync(&h[1], d_noise, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
