@@ -13,7 +13,7 @@ constexpr uint16_t kColDense = 0xFFFE;       // in entry 0: the row has more tha
 enum { SLOT_JOBS = 0, SLOT_SIMS = 1, SLOT_PROBES = 2, SLOT_PROBE_SIM = 3, SLOT_QOFF = 4, SLOT_JOBS2 = 5,
        SLOT_MISC = 6, SLOT_MISC2 = 7, SLOT_SORT = 8, SLOT_SORT2 = 9, SLOT_TAIL = 10, SLOT_TAIL2 = 11,
        SLOT_TAIL3 = 12, SLOT_TAIL4 = 13, SLOT_DB = 14, SLOT_DB2 = 15, SLOT_DB3 = 16, SLOT_FIN = 17, SLOT_FIN2 = 18,
-       SLOT_FIN3 = 19, SLOT_INV = 20, SLOT_INVCNT = 21, SLOT_SIMS2 = 22, SLOT_TILEJOB = 23, SLOT_FUSED = 24, SLOT_FUSED2 = 25, SLOT_FUSED3 = 26, SLOT_JOBS3 = 27, SLOT_WIN = 28, SLOT_CURSORS = 29 };
+       SLOT_FIN3 = 19, SLOT_INV = 20, SLOT_INVCNT = 21, SLOT_SIMS2 = 22, SLOT_TILEJOB = 23, SLOT_FUSED = 24, SLOT_FUSED2 = 25, SLOT_FUSED3 = 26, SLOT_JOBS3 = 27, SLOT_WIN = 28, SLOT_CURSORS = 29, SLOT_ITEMS = 30 };
 // out[0..n] = exclusive prefix sums of in[0..n) (out has n + 1 entries)
 int launch_exclusive_scan(fal_ctx* ctx, const int64_t* in, int64_t n, int64_t* out);
 }

@@ -44,9 +44,9 @@ struct SelectArgs {
     int32_t* nb_count;           // [rows] stored neighbours per row, or nullptr
 };
 
-// the shared-stream form of the symmetric flat scan (scan.hip): XCD-list mode with xtile0 in 128-row groups
+// the shared-stream form of the symmetric flat scan (scan.hip): jobs sorted by decreasing size, job j on XCD list j % 8
 bool dense4_supports(int d);
-int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, int64_t list_groups, float* sims,
+int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, const DenseJob* jobs_host, int n_jobs, float* sims,
                   int64_t sims_base);
 int launch_dense_tiny4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base);
 // xcd_list_tiles > 0 selects XCD-list mode (simtile.h): `jobs` = the launch's jobs sorted by

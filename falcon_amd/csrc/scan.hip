@@ -144,56 +144,94 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
 // are bit-identical.  A wave idles until the stream reaches its diagonal (the 4 x 4 corner of blocks costs 16 slots for 10
 // blocks).  Measured (s_memtime per workgroup): 16.6 k cycles per chunk against 12.8 k of MFMA issue.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool find_group_xcd(const DenseJob* __restrict__ jobs, int n_jobs, int x, int64_t i, int* job_index,
-                                               int* group) {
-    const int cnt = (n_jobs - x + 7) >> 3;
-    if (cnt <= 0) return false;
-    int lo = 0, hi = cnt - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[x + 8 * mid].xtile0 <= i) lo = mid; else hi = mid - 1;
-    }
-    const DenseJob& j = jobs[x + 8 * lo];
-    const int64_t g = i - j.xtile0;                 // xtile0 counts 128-row groups here
-    if (g >= (j.nq + 127) / 128) return false;
-    *job_index = x + 8 * lo;
-    *group = (int)g;
-    return true;
-}
-
 template <int DH4>
 __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict__ X, int d, const DenseJob* __restrict__ jobs,
-                                                        int n_jobs, float* __restrict__ sims, int64_t sims_base,
-                                                        int32_t* __restrict__ cursors) {
+                                                        float* __restrict__ sims, int64_t sims_base,
+                                                        int32_t* __restrict__ cursors, const int32_t* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char stream_lds[];
     __shared__ int32_t next_item;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    // Persistent workgroups, one per CU, that pull (bucket, group) items themselves: as one workgroup per item the launch
-    // left every CU idle for 19 us on average between two workgroups (median 7, 90th percentile 53: one 100 KB workgroup per
-    // CU, dispatched in order -- measured per CU with s_memtime).  Items of XCD list x (jobs x, x + 8, ...: simtile.h) are
-    // taken by the workgroups that RUN on XCD x (its L2 holds the bucket), in order, by a cursor per list; a workgroup
-    // whose own list is exhausted helps the next ones.
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    for (int turn = 0; turn < 8; ++turn) {
-    const int xl = (int)((xcc + turn) & 7);
-    for (;;) {
-    __syncthreads();                                         // (the previous item's last chunk has been read by every wave)
-    if (tid == 0) next_item = atomicAdd(&cursors[xl], 1);
-    __syncthreads();
-    const int item = next_item;
-    int ji, g;
-    if (!find_group_xcd(jobs, n_jobs, xl, item, &ji, &g)) break;
-    const DenseJob job = jobs[ji];
-    const int lt = 4 * g + w;                                // this wave's 32-query tile of the bucket
-    const int nc = job.nc, ncp = (nc + 31) & ~31;
-    const bool active = 32 * lt < job.nq;
     const int dh = d >> 1, dh4 = dh >> 2;
     const int row_bytes = d * 4, rs = row_bytes + 16;
     unsigned char* const buf0 = stream_lds;
     unsigned char* const buf1 = stream_lds + 32 * rs;
     const unsigned char* const my0 = buf0 + r * rs + h * (dh * 4);      // this lane's operand row in either buffer
     const unsigned char* const my1 = buf1 + r * rs + h * (dh * 4);
+    constexpr int kParts = (DH4 * 32 + 1023) / 1024;
+    constexpr int kPieces = 8 * kParts;
+    constexpr int kStores = 20;                              // VM operations of one block's stores
+
+    // a chunk's 32 rows into LDS: wave w brings rows 8 w .. 8 w + 7, one KB of one row per instruction = one "piece".
+    // (inline asm, not the builtin: hipcc guards every later LDS read with `s_waitcnt vmcnt(0)` for a DMA it knows of,
+    //  which drains the stores and the next chunk's loads once per operand read; `chunk_barrier` below does the waiting)
+    struct Target {
+        const float* rows;       // the bucket's first row
+        int nc, c0;              // its rows, the chunk's first row
+        unsigned char* buf;
+        bool valid;
+    };
+    auto issue_piece = [&](int k, const Target& t) {
+        const int p = k / 8, row = 8 * w + (k & 7);
+        if (p * 1024 + lane * 16 < row_bytes) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(t.rows + (int64_t)min(t.c0 + row, t.nc - 1) * d) +
+                                       p * 1024 + lane * 16;
+            const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)((uint32_t)(size_t)(__attribute__((address_space(3))) const void*)t.buf + (uint32_t)(row * rs + p * 1024)));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
+        }
+    };
+    auto issue = [&](const Target& t) {
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) issue_piece(k, t);
+    };
+    // Wait for this wave's share of the chunk about to be read, then meet the others.  VM operations retire in order:
+    // `after` = what the wave has issued SINCE that chunk's loads (one or two blocks' stores) may stay in flight.
+    // (Three buffers with the loads two chunks ahead were measured: 17.6 k cycles per chunk against 16.6 k -- the chunk is
+    //  not waiting for its rows.  So was a rolled loop over a runtime buffer index: 17.9 k.)
+    auto chunk_barrier = [&](int after) {
+        if (after >= 2 * kStores) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * kStores) : "memory");
+        else if (after >= kStores) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kStores) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    // Persistent workgroups, one per CU, that pull (bucket, group) items themselves: as one workgroup per item the launch
+    // left every CU idle for 19 us on average between two workgroups (median 7, 90th percentile 53: one 100 KB workgroup per
+    // CU, dispatched in order -- measured per CU with s_memtime).  Items of XCD list x (jobs x, x + 8, ...: simtile.h; the
+    // host lists them in `table`: 9 offsets, then (job, group) pairs from word 16) are taken by the workgroups that RUN on
+    // XCD x (its L2 holds the bucket), in order, by a cursor per list; a workgroup whose own list is exhausted helps the
+    // next ones.  The cursor runs two items ahead: while item `cur` is computed the next one is known -- its first chunk is
+    // loaded under cur's last chunk -- and the fetch of the one after that is in flight.
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    for (int turn = 0; turn < 8; ++turn) {
+    const int xl = (int)((xcc + turn) & 7);
+    const int n_items = table[xl + 1] - table[xl];
+    const int32_t* const items = table + 16 + 2 * table[xl];
+    __syncthreads();
+    if (tid == 0) next_item = atomicAdd(&cursors[xl], 1);
+    __syncthreads();
+    int cur = next_item;
+    __syncthreads();
+    if (tid == 0) next_item = atomicAdd(&cursors[xl], 1);
+    __syncthreads();
+    int nxt = next_item;
+    bool preloaded = false, prev_stored = false;
+    int par = 0;                                             // the buffer of the item's first chunk
+    while (cur < n_items) {
+    int fetched = 0;
+    if (tid == 0) fetched = atomicAdd(&cursors[xl], 1);      // (consumed at the end of the item)
+    const int g = items[2 * cur + 1];
+    const DenseJob job = jobs[items[2 * cur]];
+    const bool have_next = nxt < n_items;
+    Target first_of_next{X, 1, 0, nullptr, false};
+    if (have_next) {
+        const int nj = items[2 * nxt], ng = items[2 * nxt + 1];
+        first_of_next = Target{X + jobs[nj].c_row0 * d, jobs[nj].nc, 128 * ng, nullptr, true};
+    }
+    const float* const rows = X + job.c_row0 * d;
+    const int lt = 4 * g + w;                                // this wave's 32-query tile of the bucket
+    const int nc = job.nc, ncp = (nc + 31) & ~31;
+    const bool active = 32 * lt < job.nq;
 
     float* const out = sims + (job.obase - sims_base) + (int64_t)(32 * lt) * ncp + r;
     float* const outT = sims + (job.obase - sims_base) + (int64_t)r * ncp + 32 * lt + 4 * h;
@@ -202,26 +240,6 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
     const int c_first = 128 * g;                             // the group's first diagonal
     const int n_chunks = (c_last - c_first) / 32 + 1;
 
-    // a chunk's 32 rows into LDS: wave w brings rows 8 w .. 8 w + 7, one KB of one row per instruction = one "piece".
-    // (inline asm, not the builtin: hipcc guards every later LDS read with `s_waitcnt vmcnt(0)` for a DMA it knows of,
-    //  which drains the stores and the next chunk's loads once per operand read; `chunk_barrier` below does the waiting)
-    constexpr int kParts = (DH4 * 32 + 1023) / 1024;
-    constexpr int kPieces = 8 * kParts;
-    auto issue_piece = [&](int k, int c0, unsigned char* buf) {
-        const int p = k / 8, row = 8 * w + (k & 7);
-        if (p * 1024 + lane * 16 < row_bytes) {
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(X + (job.c_row0 + min(c0 + row, nc - 1)) * d) +
-                                       p * 1024 + lane * 16;
-            const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane(
-                (int)((uint32_t)(size_t)(__attribute__((address_space(3))) const void*)buf + (uint32_t)(row * rs + p * 1024)));
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
-        }
-    };
-    auto issue = [&](int c0, unsigned char* buf) {
-#pragma unroll
-        for (int k = 0; k < kPieces; ++k) issue_piece(k, c0, buf);
-    };
-
     float q[DH4 * 4];
     f32x16 prev;
 #pragma unroll
@@ -229,7 +247,6 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
     int prev_c0 = min(c_stop, c_last);
     // the 20 stores of a finished block (first call: zeros into the diagonal chunk's slots, overwritten by the real
     // epilogue later in program order): 16 rows of the block, then the transposed block in four 16-byte columns
-    constexpr int kStores = 20;
     auto store_piece = [&](int k) {
         if (k < 16) {
             out[mfma32_row(k, h) * ncp + prev_c0] = prev[k];
@@ -244,9 +261,8 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
         for (int k = 0; k < kStores; ++k) store_piece(k);
     };
     // One chunk: DH4 steps of one 16-byte operand read + four MFMAs.  The wave's share of the NEXT chunk's DMA goes out one
-    // piece per step in the first half (issued as one burst the 16 KB stalled the wave's instruction stream -- and with it
-    // its MFMAs -- for 1,650 cycles per chunk), the previous block's stores one per step in the second half (900 cycles).
-    auto compute = [&](const unsigned char* lb, int c0, bool more, int next_c0, unsigned char* next_buf) {
+    // piece per step in the first half, the previous block's stores one per step in the second half.
+    auto compute = [&](const unsigned char* lb, int c0, const Target& next) {
         constexpr int kRing = 4, kHalf = DH4 / 2;
         constexpr int kDmaPer = (kPieces + kHalf - 1) / kHalf, kStPer = (kStores + (DH4 - kHalf) - 1) / (DH4 - kHalf);
         auto ld = [&](int j) { return *reinterpret_cast<const float4*>(lb + 16 * (j < dh4 ? j : dh4 - 1)); };
@@ -267,9 +283,9 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             if (j < kHalf) {
-                if (more) {
+                if (next.valid) {
 #pragma unroll
-                    for (int k = j * kDmaPer; k < (j + 1) * kDmaPer && k < kPieces; ++k) issue_piece(k, next_c0, next_buf);
+                    for (int k = j * kDmaPer; k < (j + 1) * kDmaPer && k < kPieces; ++k) issue_piece(k, next);
                 }
             } else {
 #pragma unroll
@@ -295,39 +311,57 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
             q[4 * j + 3] = v.w;
         }
     };
-    // Wait for this wave's share of the chunk issued one iteration ago, then meet the others.  VM operations retire in
-    // order: behind those loads the wave has issued at most one block's stores, which may stay in flight.
-    // (Three buffers with the loads two chunks ahead were measured: 17.6 k cycles per chunk against 16.6 k -- the chunk is
-    //  not waiting for its rows.  So was a rolled loop over a runtime buffer index: 17.9 k.)
-    bool stored = false;
-    auto chunk_barrier = [&]() {
-        if (stored) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kStores) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    };
 
-    issue(c_first, buf0);
-    for (int ci = 0, c0 = c_first; ci < n_chunks; ci += 2, c0 += 64) {
-        chunk_barrier();                                     // chunk ci has landed, buf1 is free again
-        stored = false;
-        if (active && c0 == c_stop) take_queries(my0);
+    // chunk ci sits in buffer (par + ci) & 1; behind the first chunk's loads (issued under the previous item's last chunk)
+    // the wave has stored that item's last two blocks
+    int after = 0;
+    if (preloaded) after = prev_stored ? 2 * kStores : 0;
+    else issue(Target{rows, nc, c_first, par ? buf1 : buf0, true});
+    bool odd = par != 0;
+    int ci = 0, c0 = c_first;
+    for (;;) {
+        if (!odd) {
+            chunk_barrier(after);                            // chunk ci has landed in buf0, buf1 is free again
+            Target next = ci + 1 < n_chunks ? Target{rows, nc, c0 + 32, buf1, true} : first_of_next;
+            next.buf = buf1;
+            if (active && c0 == c_stop) take_queries(my0);
+            if (active && c0 >= c_stop) {
+                compute(my0, c0, next);
+                after = kStores;
+            } else {
+                if (next.valid) issue(next);
+                after = 0;
+            }
+            ++ci;
+            c0 += 32;
+            if (ci >= n_chunks) break;
+        }
+        odd = false;
+        chunk_barrier(after);                                // chunk ci has landed in buf1, buf0 is free again
+        Target next = ci + 1 < n_chunks ? Target{rows, nc, c0 + 32, buf0, true} : first_of_next;
+        next.buf = buf0;
+        if (active && c0 == c_stop) take_queries(my1);
         if (active && c0 >= c_stop) {
-            compute(my0, c0, ci + 1 < n_chunks, c0 + 32, buf1);
-            stored = true;
-        } else if (ci + 1 < n_chunks) {
-            issue(c0 + 32, buf1);
+            compute(my1, c0, next);
+            after = kStores;
+        } else {
+            if (next.valid) issue(next);
+            after = 0;
         }
-        if (ci + 1 >= n_chunks) break;
-        chunk_barrier();
-        stored = false;
-        if (active && c0 + 32 == c_stop) take_queries(my1);
-        if (active && c0 + 32 >= c_stop) {
-            compute(my1, c0 + 32, ci + 2 < n_chunks, c0 + 64, buf0);
-            stored = true;
-        } else if (ci + 2 < n_chunks) {
-            issue(c0 + 64, buf0);
-        }
+        ++ci;
+        c0 += 32;
+        if (ci >= n_chunks) break;
     }
     if (active) epilogue();
+    // the cursor value fetched at the top becomes the item after next
+    if (tid == 0) next_item = fetched;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int nxt2 = next_item;
+    par = (par + n_chunks) & 1;
+    preloaded = have_next;
+    prev_stored = active;
+    cur = nxt;
+    nxt = nxt2;
     }
     }
 }
@@ -409,16 +443,29 @@ __global__ __launch_bounds__(256, 1) void dense_tiny4_kernel(const float* __rest
 
 bool dense4_supports(int d) { return d % 8 == 0 && d >= 32 && d <= 400; }   // (low_dim 512: the 64-step form needs scratch)
 
-// `list_groups` = the longest XCD list in 128-row groups (jobs[j].xtile0 counts groups)
-int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, int64_t list_groups, float* sims,
+// jobs_host = the host copy of `jobs` (sorted by decreasing size: job j belongs to XCD list j % 8)
+int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, const DenseJob* jobs_host, int n_jobs, float* sims,
                   int64_t sims_base) {
-    if (n_jobs <= 0 || list_groups <= 0) return FAL_OK;
+    if (n_jobs <= 0) return FAL_OK;
     const int dh4 = d / 8;
-    FAL_REQUIRE(list_groups * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
+    // the item table: 9 offsets (in items), then the (job, 128-row group) pairs of XCD list 0, 1, ... from word 16
+    std::vector<int32_t> table(16, 0);
+    for (int x = 0; x < 8; ++x) {
+        for (int j = x; j < n_jobs; j += 8)
+            for (int g = 0; g < (jobs_host[j].nq + 127) / 128; ++g) {
+                table.push_back(j);
+                table.push_back(g);
+            }
+        table[x + 1] = (int32_t)((table.size() - 16) / 2);
+    }
+    const int64_t n_items = table[8];
+    int32_t* table_dev = nullptr;
+    FAL_TRY(ctx->reserve(SLOT_ITEMS, sizeof(int32_t) * table.size(), (void**)&table_dev));
+    FAL_TRY(ctx->upload(table_dev, table.data(), sizeof(int32_t) * table.size()));
     const size_t lds = (size_t)2 * 32 * (d * 4 + 16);
     int32_t* cursors = nullptr;
     FAL_TRY(ctx->reserve(SLOT_CURSORS, sizeof(int32_t) * 16, (void**)&cursors));
-    dim3 grid((unsigned)std::min<int64_t>(list_groups * 8, ctx->num_cus)), block(256);
+    dim3 grid((unsigned)std::min<int64_t>(n_items, ctx->num_cus)), block(256);
     StageScope ts(ctx, ST_SCAN);
     StageScope tk(ctx, ST_KERNEL);
     FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t) * 8, ctx->stream));
@@ -426,8 +473,8 @@ int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int
     do {                                                                                                            \
         FAL_CHECK_HIP(hipFuncSetAttribute((const void*)dense4_kernel<DH4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                           (int)lds));                                                               \
-        hipLaunchKernelGGL((dense4_kernel<DH4>), grid, block, lds, ctx->stream, X, d, jobs, n_jobs, sims, sims_base, \
-                           cursors);                                                                                \
+        hipLaunchKernelGGL((dense4_kernel<DH4>), grid, block, lds, ctx->stream, X, d, jobs, sims, sims_base, cursors, \
+                           table_dev);                                                                              \
     } while (0)
     if (dh4 <= 8) FAL_LAUNCH_DENSE4(8);
     else if (dh4 <= 16) FAL_LAUNCH_DENSE4(16);

@@ -273,7 +273,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     }
     // a batch = jobs [j0, j1): [j0, jm) go to the f16-MFMA kernel (128-query tiles), [jm, jk) to the shared-stream fp32 kernel
     // (groups of four 32-query tiles), [jk, j1) to the one-wave fp32 kernel
-    struct FlatBatch { size_t j0, jm, jk, j1; int64_t tiles, list_tiles16, list_groups4, list_tiles32, floats; };
+    struct FlatBatch { size_t j0, jm, jk, j1; int64_t tiles, list_tiles16, list_tiles32, floats; };
     std::vector<FlatBatch> flat_batches;
     size_t need_flat = 0;
     const bool have16 = ivf->X16 != nullptr;
@@ -281,19 +281,17 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     const int64_t thr16 = (ivf->X && d <= 512) ? 64 : 0;   // without float32 rows (or beyond the fp32 kernel's low_dim) everything takes the f16 kernel
     FAL_REQUIRE(have16 || ivf->X || border.empty(), FAL_EINVAL, "fal_ivf_search_topk: the index has no vectors to scan");
     {
-        FlatBatch cur{0, 0, 0, 0, 0, 0, 0, 0, 0};
-        int64_t xt16[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt4[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        FlatBatch cur{0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t xt16[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         auto close = [&]() {
             if (cur.j1 > cur.j0) {
                 cur.list_tiles16 = *std::max_element(xt16, xt16 + 8);
-                cur.list_groups4 = *std::max_element(xt4, xt4 + 8);
                 cur.list_tiles32 = *std::max_element(xt32, xt32 + 8);
                 flat_batches.push_back(cur);
                 need_flat = std::max(need_flat, (size_t)cur.floats);
             }
-            cur = FlatBatch{cur.j1, cur.j1, cur.j1, cur.j1, 0, 0, 0, 0, 0};
+            cur = FlatBatch{cur.j1, cur.j1, cur.j1, cur.j1, 0, 0, 0, 0};
             std::fill(xt16, xt16 + 8, 0);
-            std::fill(xt4, xt4 + 8, 0);
             std::fill(xt32, xt32 + 8, 0);
         };
         for (int64_t b : border) {
@@ -309,9 +307,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                 xt16[x] += ceil_div(nb, 128);
                 cur.jm = cur.jk = cur.j1 + 1;
             } else if (use4) {
-                const int x = (int)((cur.j1 - cur.jm) & 7);
-                xtile0 = xt4[x];
-                xt4[x] += ceil_div(nb, 128);
+                xtile0 = 0;                                  // (launch_dense4 lists the groups of these jobs itself)
                 cur.jk = cur.j1 + 1;
             } else {
                 const int x = (int)((cur.j1 - cur.jk) & 7);
@@ -397,7 +393,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
                                   buf + sims_floats));
         // (flat buckets keep their rows' positions in list order: the sorted rows serve)
         if (fb.jk > fb.jm)
-            FAL_TRY(launch_dense4(ctx, ivf->X, d, flat_dev + fb.jm, (int)(fb.jk - fb.jm), fb.list_groups4, buf, 0));
+            FAL_TRY(launch_dense4(ctx, ivf->X, d, flat_dev + fb.jm, flat.data() + fb.jm, (int)(fb.jk - fb.jm), buf, 0));
         if (fb.j1 > fb.jk && have4)
             FAL_TRY(launch_dense_tiny4(ctx, ivf->X, d, flat_dev + fb.jk, (int)(fb.j1 - fb.jk), buf, 0));
         else if (fb.j1 > fb.jk)
