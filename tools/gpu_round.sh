@@ -27,3 +27,8 @@ j = json.load(open('gpurun_out/r3_bench_1M_pipelined_under_rocprof.json')); prin
 PY
 grep "dense4_kernel<50>" $O/r3_bench_1M_pipelined_kernel_stats.csv | cut -c1-60,170-260
 grep "dense4_kernel<50>" $O/r3_bench_1M_kernel_stats.csv | cut -c1-60,170-260
+rm -rf $O/p_trace
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 tools/scale_run.py 10000000 > $O/r3_10M_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r3_10M_f32_kernel_stats.csv
+tail -2 $O/r3_10M_under_rocprof.txt
+rm -rf $O/p_trace
