@@ -58,7 +58,7 @@ def cpu_baseline(host, params, seconds_hint=20.0):
     so the work per spectrum) of the full run."""
     from oracle import falcon_oracle as fo
     pm = host["precursor_mz"]
-    lo, width = 600.0, 400.0          # ~350 k spectra at the default density: ~10 s on the GPU box's host cores
+    lo, width = 600.0, 240.0          # ~210 k spectra at the default density: 6 s on an idle GPU box's host cores (30 s seen on a busy one)
     sel = np.flatnonzero((pm >= lo) & (pm < lo + width))
     if len(sel) < 256:
         sel = np.arange(min(len(pm), 20000))
