@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // a9
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool edge_ok(int32_t j, float dist, int64_t i, float eps) {
-    return j >= 0 && (int64_t)j != i && dist <= eps;
+// (ids outside [0, n) are treated as "no neighbour": an uninitialised neighbour array must not send the union-find walking
+//  through foreign memory -- it hung a GPU box for its whole time limit once)
+__device__ __forceinline__ bool edge_ok(int32_t j, float dist, int64_t i, float eps, int64_t n) {
+    return j >= 0 && (int64_t)j < n && (int64_t)j != i && dist <= eps;
 }
 
 // core(i) <=> row i stores a neighbour within eps (the point itself is the other sample).
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void dbscan_core_kernel(const int32_t* __restr
         for (int s0 = 0; s0 < k; s0 += 64) {
             const int s = s0 + lane;
             const int32_t j = s < k ? nb_idx[i * k + s] : -1;
-            const bool ok = s < k && edge_ok(j, nb_dist[i * k + s], i, eps);
+            const bool ok = s < k && edge_ok(j, nb_dist[i * k + s], i, eps, n);
             c = c || __ballot(ok) != 0;
             const uint64_t stored = __ballot(j >= 0);
             if (stored) ext = s0 + 64 - __clzll((unsigned long long)stored);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void dbscan_edges_kernel(const int32_t* __rest
         const int ext = core[i] ? extent[i] : 0;
         for (int s = (int)(e % kEdgeThreads); s < ext; s += kEdgeThreads) {
             const int32_t j = nb_idx[i * k + s];
-            if (!edge_ok(j, nb_dist[i * k + s], i, eps)) continue;
+            if (!edge_ok(j, nb_dist[i * k + s], i, eps, n)) continue;
             if (core[j]) uf_union(parent, (int32_t)i, j);
             else atomicMin(&border_src[j], (int32_t)i);
         }

@@ -72,7 +72,7 @@ __global__ void lk_edges_kernel(const int32_t* __restrict__ nb_idx, const float*
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / k;
         const int32_t j = nb_idx[e];
-        if (j >= 0 && (int64_t)j != i && nb_dist[e] <= t) lk_union(parent, (int32_t)i, j);
+        if (j >= 0 && (int64_t)j < n && (int64_t)j != i && nb_dist[e] <= t) lk_union(parent, (int32_t)i, j);
     }
 }
 
@@ -118,7 +118,7 @@ __global__ void lk_single_kernel(const int32_t* __restrict__ parent, const int32
 
 // one wave per component: method 1 = complete, 2 = average
 __global__ __launch_bounds__(64) void lk_agglomerate_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
-                                                            int k, double t, int method, const int32_t* __restrict__ parent,
+                                                            int64_t n, int k, double t, int method, const int32_t* __restrict__ parent,
                                                             const int32_t* __restrict__ count, const int32_t* __restrict__ comp_root,
                                                             const int64_t* __restrict__ moff, const int64_t* __restrict__ qoff,
                                                             const int32_t* __restrict__ mem, int32_t* __restrict__ mem_sorted,
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void lk_agglomerate_kernel(const int32_t* __res
         const int64_t row = ms[a];
         for (int s = lane; s < k; s += 64) {
             const int32_t j = nb_idx[row * k + s];
-            if (j >= 0 && (int64_t)j != row && parent[j] == root) D[(int64_t)a * m + lidx[j]] = (double)nb_dist[row * k + s];
+            if (j >= 0 && (int64_t)j < n && (int64_t)j != row && parent[j] == root) D[(int64_t)a * m + lidx[j]] = (double)nb_dist[row * k + s];
         }
     }
     __threadfence_block();
@@ -285,7 +285,7 @@ int linkage_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64
             int32_t *lidx = cl + n_mem, *cursor = lidx + n, *comp_root = cursor + n;
             FAL_CHECK_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n, st));
             hipLaunchKernelGGL(lk_scatter_kernel, dim3(grid), dim3(256), 0, st, parent, count, n, moff, cursor, mem, crank, comp_root);
-            hipLaunchKernelGGL(lk_agglomerate_kernel, dim3((unsigned)n_comp), dim3(64), 0, st, nb_idx, nb_dist, k, (double)t, method,
+            hipLaunchKernelGGL(lk_agglomerate_kernel, dim3((unsigned)n_comp), dim3(64), 0, st, nb_idx, nb_dist, n, k, (double)t, method,
                                parent, count, comp_root, moff, qoff, mem, mem_sorted, lidx, act, sz, cl, D, rep);
         }
     }

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void medoid_score_kernel(const int32_t* __rest
                 j = nb_idx[i * k + c];
                 dv = nb_dist[i * k + c];
             }
-            const bool in = j >= 0 && (int64_t)j != i && labels[j] == l;
+            const bool in = j >= 0 && (int64_t)j < n && (int64_t)j != i && labels[j] == l;
             uint64_t mask = __ballot(in);
             same += __popcll(mask);
             while (mask) {

@@ -114,3 +114,27 @@ def test_bad_arguments_are_reported_not_fatal(ctx):
         idxr.search(16, 1000)                                                # k_ann beyond FAL_MAX_K_ANN
     with pytest.raises(FalconHipError):
         ctx.vectorize(np.zeros(4, np.float32), np.zeros(4, np.float32), np.array([0, 4]), None, 100.0, 0.05, 100, 402)
+
+
+def test_dbscan_ignores_neighbour_ids_outside_the_dataset(ctx):
+    """neighbour ids >= n (an uninitialised or corrupted neighbour array) are treated as "no neighbour" by the graph stage:
+    they once sent the union-find through foreign memory (a GPU box hung for its whole time limit)"""
+    import torch
+    n, k = 5000, 8
+    rng = np.random.default_rng(3)
+    idx = np.full((n, k), -1, np.int32)
+    dist = np.full((n, k), np.inf, np.float32)
+    idx[:-1, 0] = np.arange(1, n)
+    dist[:-1, 0] = 0.05
+    idx[::7, 1] = rng.integers(n, 2 ** 31 - 1, size=len(idx[::7]))      # garbage ids with small distances
+    dist[::7, 1] = 0.01
+    ref_idx = idx.copy()
+    ref_idx[::7, 1] = -1
+    ti, td = torch.from_numpy(idx).to(ctx.tdev), torch.from_numpy(dist).to(ctx.tdev)
+    tr = torch.from_numpy(ref_idx).to(ctx.tdev)
+    lab, n_cl = ctx.dbscan(ti, td, 0.1)
+    lab_ref, n_ref = ctx.dbscan(tr, td, 0.1)
+    assert n_cl == n_ref and torch.equal(lab, lab_ref)
+    lab, n_cl = ctx.linkage_cluster(ti, td, 0.1, "single")
+    lab_ref, n_ref = ctx.linkage_cluster(tr, td, 0.1, "single")
+    assert n_cl == n_ref and torch.equal(lab, lab_ref)
