@@ -78,6 +78,8 @@ _SIGNATURES = {
                       c_void_p, P(c_int64)], c_int),
     "fal_cluster_graph": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_double, c_int,
                            c_double, c_void_p, c_void_p, c_void_p, c_void_p, P(c_int64), P(c_int64)], c_int),
+    "fal_cluster_graph_counted": ([c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_void_p, c_double,
+                                   c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, P(c_int64), P(c_int64)], c_int),
     "fal_cluster_graph_linkage": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, c_void_p, c_double, c_int,
                                    c_double, c_void_p, c_void_p, c_void_p, c_void_p, P(c_int64), P(c_int64)], c_int),
     "fal_linkage_cluster": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p, P(c_int64)], c_int),

@@ -271,8 +271,9 @@ class ClusterPipeline:
             labels, medoids = c.finalize(lab, n_cl, order, nb_idx, nb_dist)
         else:
             # production: a9..a12 fused, counts stay on the device, one synchronisation
+            # (after the exact re-scoring a stored neighbour may have moved beyond eps, but it is still stored: counts hold)
             labels, medoids, _, _ = c.cluster_graph(nb_idx, nb_dist, p.eps, mzs, rts, precursor_tol_mass,
-                                                    precursor_tol_mode, rt_tol, order, linkage=hier)
+                                                    precursor_tol_mode, rt_tol, order, linkage=hier, nb_count=st["nb_count"])
             last = dict(nb_idx=nb_idx, nb_dist=nb_dist, nb_count=st["nb_count"], order=order, n_list=st["n_list"],
                         splits=st["splits"])                          # the sparse graph (exchange) + the bucket table
             index.close()

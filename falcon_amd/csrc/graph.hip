@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ s
 // ------------------------------------------------------------------------------------------
 // (ids outside [0, n) are treated as "no neighbour": an uninitialised neighbour array must not send the union-find walking
 //  through foreign memory -- it hung a GPU box for its whole time limit once)
+constexpr int kEdgeThreads = 8;      // threads per row of the counted core pass and the edges pass
 __device__ __forceinline__ bool edge_ok(int32_t j, float dist, int64_t i, float eps, int64_t n) {
     return j >= 0 && (int64_t)j < n && (int64_t)j != i && dist <= eps;
 }
@@ -134,10 +135,33 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int32_t a, int32_t b) 
     }
 }
 
+// dbscan_core_kernel for front-packed rows of known length (`count` = a8's nb_count): eight threads per row look at the
+// stored neighbours only, the row's verdict is the OR over their lanes
+__global__ __launch_bounds__(256) void dbscan_core_counted_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
+                                                                  const int32_t* __restrict__ count, int64_t n, int k, float eps,
+                                                                  int32_t* __restrict__ core, int32_t* __restrict__ parent,
+                                                                  int32_t* __restrict__ border_src) {
+    const int lane = threadIdx.x & 63, sub = lane & 7;
+    const int64_t total = (n + 7) / 8 * 64;                  // whole waves: every lane takes part in the ballot
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e >> 3;
+        bool c = false;
+        if (i < n) {
+            const int ext = min(count[i], k);
+            for (int s = sub; s < ext && !c; s += 8) c = edge_ok(nb_idx[i * k + s], nb_dist[i * k + s], i, eps, n);
+        }
+        const uint64_t any = __ballot(c);
+        if (sub == 0 && i < n) {
+            core[i] = ((any >> (lane & ~7)) & 0xffull) != 0;
+            parent[i] = (int32_t)i;
+            border_src[i] = 0x7fffffff;
+        }
+    }
+}
+
 // eight threads per row, one per stored edge (slots s, s + 8, ... below the row's extent): core->core edges are united,
 // core->border edges vote for the border point's lowest-index core in-neighbour.  (One thread per SLOT read 8 n_neighbors
 // bytes of every core row: 0.39 ms per 1 M spectra; one wave per row left most lanes idle behind four dependent loads.)
-constexpr int kEdgeThreads = 8;
 __global__ __launch_bounds__(256) void dbscan_edges_kernel(const int32_t* __restrict__ nb_idx, const float* __restrict__ nb_dist,
                                                            int64_t n, int k, float eps, const int32_t* __restrict__ core,
                                                            const int32_t* __restrict__ extent, int32_t* __restrict__ parent,
@@ -306,7 +330,7 @@ int fal_neighbors_to_csr_mapped(fal_ctx* ctx, const int32_t* nb_idx, const float
 
 // a9 with the cluster count left on the device at *d_count_out (no host synchronisation)
 int fal::dbscan_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps,
-                    int32_t* labels, int64_t** d_count_out, const int32_t** extent_out) {
+                    int32_t* labels, int64_t** d_count_out, const int32_t** extent_out, const int32_t* nb_count) {
     int32_t* buf = nullptr;
     int64_t* rank = nullptr;
     FAL_TRY(ctx->reserve(SLOT_DB, sizeof(int32_t) * (size_t)n * 5, (void**)&buf));
@@ -317,8 +341,16 @@ int fal::dbscan_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, i
     ctx->stage_reset(ST_DBSCAN);
     {
         StageScope ts(ctx, ST_DBSCAN);
-        hipLaunchKernelGGL(dbscan_core_kernel, dim3(wgrid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent,
-                           border, extent);
+        if (nb_count) {
+            // front-packed rows of known length: nothing beyond nb_count[i] is read, here or by the later passes
+            const unsigned cgrid = (unsigned)std::min<int64_t>(ceil_div(n * kEdgeThreads, 256), (int64_t)ctx->num_cus * 32);
+            hipLaunchKernelGGL(dbscan_core_counted_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, nb_count, n, k,
+                               eps, core, parent, border);
+            extent = const_cast<int32_t*>(nb_count);
+        } else {
+            hipLaunchKernelGGL(dbscan_core_kernel, dim3(wgrid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, parent,
+                               border, extent);
+        }
         const unsigned egrid = (unsigned)std::min<int64_t>(ceil_div(n * kEdgeThreads, 256), (int64_t)ctx->num_cus * 32);
         hipLaunchKernelGGL(dbscan_edges_kernel, dim3(egrid), dim3(256), 0, ctx->stream, nb_idx, nb_dist, n, k, eps, core, extent,
                            parent, border);

@@ -537,7 +537,7 @@ int fal_finalize(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, int64_t 
 static int cluster_graph_impl(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps, int method,
                               const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
                               double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
-                              int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+                              int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels, const int32_t* nb_count = nullptr) {
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX && n_clusters && n_labels, FAL_EINVAL,
                 "fal_cluster_graph: bad argument");
     *n_clusters = *n_labels = 0;
@@ -547,7 +547,7 @@ static int cluster_graph_impl(fal_ctx* ctx, const int32_t* nb_idx, const float* 
     int64_t *d_db = nullptr, *d_cl = nullptr, *d_noise = nullptr;
     const int32_t* extent = nullptr;                      // a9's row extents (SLOT_DB: not touched by a10 / a11)
     ctx->stage_reset(ST_TAIL);
-    if (method < 0) FAL_TRY(dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels_sorted_scratch, &d_db, &extent));
+    if (method < 0) FAL_TRY(dbscan_dev(ctx, nb_idx, nb_dist, n, k, eps, labels_sorted_scratch, &d_db, &extent, nb_count));
     else FAL_TRY(linkage_dev(ctx, nb_idx, nb_dist, n, k, eps, method, labels_sorted_scratch, &d_db));
     FAL_TRY(refine_dev(ctx, labels_sorted_scratch, n, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol, d_db, &d_cl));
     FAL_TRY(finalize_dev(ctx, labels_sorted_scratch, n, d_cl, row_order, nb_idx, nb_dist, k, labels_out, medoids_out,
@@ -567,6 +567,15 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
                       int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
     return cluster_graph_impl(ctx, nb_idx, nb_dist, n, k, eps, -1, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol,
                               row_order, labels_sorted_scratch, labels_out, medoids_out, n_clusters, n_labels);
+}
+
+int fal_cluster_graph_counted(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, const int32_t* nb_count, int64_t n, int k,
+                              float eps, const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
+                              double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
+                              int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+    FAL_REQUIRE(nb_count || n == 0, FAL_EINVAL, "fal_cluster_graph_counted: NULL nb_count");
+    return cluster_graph_impl(ctx, nb_idx, nb_dist, n, k, eps, -1, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol,
+                              row_order, labels_sorted_scratch, labels_out, medoids_out, n_clusters, n_labels, nb_count);
 }
 
 int fal_cluster_graph_linkage(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float threshold,

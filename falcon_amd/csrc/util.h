@@ -12,7 +12,7 @@ int sort_pairs_u32_i32(fal_ctx* ctx, const uint32_t* kin, uint32_t* kout, const 
 // a9 / a10 / a11+a12 with every count left on the device (graph.hip, tail.hip)
 // (*extent_out: per row, one past its last stored neighbour -- valid until SLOT_DB is reserved again)
 int dbscan_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps, int32_t* labels,
-               int64_t** d_count_out, const int32_t** extent_out = nullptr);
+               int64_t** d_count_out, const int32_t** extent_out = nullptr, const int32_t* nb_count = nullptr);
 // f4: hierarchical clustering of the neighbour graph cut at t (linkage.hip): method 0 single, 1 complete, 2 average
 int linkage_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float t, int method, int32_t* labels,
                 int64_t** d_count_out);

@@ -342,9 +342,10 @@ class Context:
     LINKAGE = {"single": 0, "complete": 1, "average": 2}
 
     def cluster_graph(self, nb_idx, nb_dist, eps: float, mz_sorted, rt_sorted, tol: float, mode: str, rt_tol, order,
-                      linkage: Optional[str] = None):
+                      linkage: Optional[str] = None, nb_count=None):
         """a9..a12 fused: -> labels i32[n] (dataset rows), medoids i32[n_labels], labels_sorted, n_clusters.
-        `linkage` = None: DBSCAN(eps); "single" / "complete" / "average": hierarchical clustering cut at `eps` (f4)."""
+        `linkage` = None: DBSCAN(eps); "single" / "complete" / "average": hierarchical clustering cut at `eps` (f4).
+        `nb_count` (the search's per-row neighbour counts, rows front-packed): the graph passes read the stored slots only."""
         torch = _torch()
         n, k = nb_idx.shape
         lab_sorted = self.empty((n,), torch.int32)
@@ -354,7 +355,10 @@ class Context:
         tail = (self._p(mz_sorted), self._p(rt_sorted), float(tol), int(mode == "Da"),
                 -1.0 if rt_tol is None else float(rt_tol), self._p(order), self._p(lab_sorted), self._p(labels),
                 self._p(medoids), C.byref(nc), C.byref(nl))
-        if linkage is None:
+        if linkage is None and nb_count is not None:
+            check(self.lib.fal_cluster_graph_counted(self._h, self._p(nb_idx), self._p(nb_dist), self._p(nb_count), n, k,
+                                                     float(eps), *tail), "fal_cluster_graph_counted")
+        elif linkage is None:
             check(self.lib.fal_cluster_graph(self._h, self._p(nb_idx), self._p(nb_dist), n, k, float(eps), *tail),
                   "fal_cluster_graph")
         else:

@@ -291,6 +291,14 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
                       int32_t* labels_sorted_scratch, int32_t* labels_out, int32_t* medoids_out,
                       int64_t* n_clusters /*[host]*/, int64_t* n_labels /*[host]*/);
 
+/* The same for FRONT-PACKED neighbour rows of known length (what fal_ivf_search_neighbors leaves: nb_count[i] stored
+ * neighbours in slots 0 .. nb_count[i] - 1, padding behind): the graph passes read the stored slots only. --- [dev] */
+int fal_cluster_graph_counted(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, const int32_t* nb_count,
+                              int64_t n, int k, float eps, const float* precursor_mz_sorted, const float* rt_sorted,
+                              double tol, int tol_is_da, double rt_tol, const int64_t* row_order,
+                              int32_t* labels_sorted_scratch, int32_t* labels_out, int32_t* medoids_out,
+                              int64_t* n_clusters /*[host]*/, int64_t* n_labels /*[host]*/);
+
 /* ---- f4  hierarchical clustering of the neighbour graph: the clustering the reference snapshot ships,
  *          fcluster(fastcluster.linkage(pdist, linkage), distance_threshold, "distance") (cluster.py:283-290), on the
  *          sparse graph with "missing pair = distance 1" (cluster.py:621-626), normally after fal_rescore_neighbors
