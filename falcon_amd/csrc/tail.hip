@@ -393,6 +393,33 @@ __global__ __launch_bounds__(256) void medoid_score_kernel(const int32_t* __rest
     }
 }
 
+// the same for rows of known extent (a9 hands them over): one THREAD per row walks the few stored slots in order -- a wave
+// per row leaves most of its lanes idle on rows of a handful of neighbours
+__global__ __launch_bounds__(256) void medoid_score_rows_kernel(const int32_t* __restrict__ labels, int64_t n,
+                                                                const int32_t* __restrict__ nb_idx,
+                                                                const float* __restrict__ nb_dist, int k,
+                                                                const int32_t* __restrict__ extent,
+                                                                const int32_t* __restrict__ size,
+                                                                unsigned long long* __restrict__ best) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t l = labels[i];
+        if (l < 0) continue;
+        float s = 0.f;
+        int same = 0;
+        const int ext = min(extent[i], k);
+        for (int c = 0; c < ext; ++c) {
+            const int32_t j = nb_idx[i * k + c];
+            if (j >= 0 && (int64_t)j < n && (int64_t)j != i && labels[j] == l) {
+                s += nb_dist[i * k + c];                        // (slot order, float32: the oracle's sum)
+                ++same;
+            }
+        }
+        s += (float)(size[l] - 1 - same);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(uint32_t)i;
+        atomicMin(&best[l], key);
+    }
+}
+
 __global__ void finalize_kernel(const int32_t* __restrict__ labels, int64_t n, const int64_t* __restrict__ d_count,
                                 const int64_t* __restrict__ row_order, const int64_t* __restrict__ noise_rank,
                                 const unsigned long long* __restrict__ best, int32_t* __restrict__ labels_out,
@@ -479,7 +506,11 @@ int fal::finalize_dev(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, con
     {
         StageScope ts(ctx, ST_TAIL);
         hipLaunchKernelGGL(cluster_size_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, size, row_order, noise);
-        hipLaunchKernelGGL(medoid_score_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64)), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, extent, size, best);
+        if (extent)
+            hipLaunchKernelGGL(medoid_score_rows_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->num_cus * 32)),
+                               dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, extent, size, best);
+        else
+            hipLaunchKernelGGL(medoid_score_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 4), (int64_t)ctx->num_cus * 64)), dim3(256), 0, st, labels_sorted, n, nb_idx, nb_dist, k, extent, size, best);
         FAL_TRY(device_scan_i32(ctx, noise, n, rank, SLOT_TAIL3));
         hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(256), 0, st, labels_sorted, n, d_count, row_order, rank,
                            best, labels_out, medoids_out);
