@@ -270,3 +270,25 @@ def test_ivf_build_with_f16_prefilter_is_identical(ctx, sizes, nlists, d):
     assert np.array_equal(asg[off[-2]:off[-1]], ra)
     lb = np.concatenate([[0], np.cumsum(nlists)])
     assert np.array_equal(cent[lb[-2]:lb[-1]], C)
+
+
+def test_flat_scan_random_bucket_mixes(ctx):
+    """the three forms of the fp32 flat scan on random mixes of bucket sizes (1 .. 1,400 rows: one-block buckets, partial and
+    many 4-tile groups side by side in one launch, persistent workgroups pulling them in size order) and low_dims: top-k
+    similarities and ids bit-identical to the brute-force oracle in every bucket"""
+    import torch
+    rng = np.random.default_rng(2026)
+    for case in range(8):
+        d = int(rng.choice([64, 128, 200, 256, 400, 400]))
+        k = int(rng.choice([16, 64, 128]))
+        nb = int(rng.integers(3, 30))
+        sizes = [int(x) for x in np.concatenate([rng.integers(1, 40, nb // 2), rng.integers(33, 1400, nb - nb // 2)])]
+        rng.shuffle(sizes)
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        X = unit_vectors(off[-1], d, 100 + case)
+        idxr = ctx.ivf_build(torch.from_numpy(X).to(ctx.tdev), off, np.ones(len(sizes), np.int32))
+        sim, idx = idxr.search(16, k)
+        sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
+        for a, b in zip(off[:-1], off[1:]):
+            rs, ri = fo.exhaustive_topk(X[a:b], k, base=a)
+            assert_topk_exact(sim[a:b], idx[a:b], rs, ri, what=f"case {case} d {d} bucket {a}:{b}")
