@@ -24,9 +24,6 @@
 
 namespace fal {
 
-#define FAL_GLDS16(gptr, lptr)                                                                        \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 template <int DH4>
 __global__ __launch_bounds__(256, 1) void assign_kernel(const float* __restrict__ X, const float* __restrict__ Cn, int d,
@@ -60,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void assign_kernel(const float* __restrict_
 #pragma unroll
         for (int jj = 0; jj < (DH4 + 3) / 4; ++jj) {
             const int j = 4 * jj + w;
-            if (j < DH4) FAL_GLDS16(rowp + min(j, dh4 - 1), buf + j * 64);      // padded steps re-read the last real one
+            if (j < DH4) lds_dma16(rowp + min(j, dh4 - 1), buf + j * 64);      // padded steps re-read the last real one
         }
     };
 
@@ -118,13 +115,17 @@ __global__ __launch_bounds__(256, 1) void assign_kernel(const float* __restrict_
         prev_c0 = c0;
     };
 
+    // A barrier does NOT wait for LDS-DMA: every wave drains its own queue (vmcnt(0): the chunk issued one phase ago, and the
+    // epilogue's atomics) BEFORE it arrives, so past the barrier all four waves' parts of the chunk have landed.  Written
+    // out in asm because hipcc's own tracking of `global_load_lds` dropped the wait on the loop's back-edge (round 3: a bare
+    // s_barrier at the loop header, the build's rows raced their DMA; tests/test_kernel_resources.py now lints the ISA).
     issue(0, sbuf0);
     for (int c0 = 0; c0 < nr; c0 += 64) {
-        __syncthreads();          // chunk c0 has landed (the barrier drains the LDS-DMA queue); sbuf1 is free again
+        FAL_DMA_BARRIER();        // chunk c0 has landed; sbuf1 is free again
         if (c0 + 32 < nr) issue(c0 + 32, sbuf1);
         if (active) compute(sbuf0, c0);
         if (c0 + 32 >= nr) break;
-        __syncthreads();
+        FAL_DMA_BARRIER();
         if (c0 + 64 < nr) issue(c0 + 64, sbuf0);
         if (active) compute(sbuf1, c0 + 32);
     }

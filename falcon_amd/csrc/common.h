@@ -120,4 +120,18 @@ __device__ __forceinline__ void wave_lds_sync() {
     asm volatile("" ::: "memory");
 }
 
+// Workgroup barrier behind LDS-DMA (`global_load_lds`): s_barrier does not wait for a wave's outstanding DMA, and hipcc's own
+// s_waitcnt insertion for the builtin lost the wait on a loop back-edge (round 3, assign.hip).  Every wave drains its vector
+// memory queue, then arrives: past the barrier every wave's DMA issued before it has landed in LDS.
+#define FAL_DMA_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// One LDS-DMA instruction: lane l's 16 bytes at `g` (per lane) land at `lds` (wave-uniform) + 16 l.  Inline asm, not
+// `__builtin_amdgcn_global_load_lds`: for a DMA it knows of hipcc either guards later LDS reads with `s_waitcnt vmcnt(0)` (the
+// overlap with the next chunk's loads is gone) or, across a loop back-edge, forgets the wait altogether (see above).  With the
+// asm form the compiler knows nothing; FAL_DMA_BARRIER / hand-counted vmcnt do ALL the waiting.
+__device__ __forceinline__ void lds_dma16(const void* g, const void* lds) {
+    const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(__attribute__((address_space(3))) const void*)lds);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory", "m0");
+}
+
 }  // namespace fal

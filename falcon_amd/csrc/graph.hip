@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void dbscan_edges_kernel(const int32_t* __rest
     const int64_t total = n * kEdgeThreads;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = e / kEdgeThreads;
-        const int ext = core[i] ? extent[i] : 0;
+        const int ext = core[i] ? min(extent[i], k) : 0;        // (a caller's nb_count may exceed k: clamp like the core / medoid passes)
         for (int s = (int)(e % kEdgeThreads); s < ext; s += kEdgeThreads) {
             const int32_t j = nb_idx[i * k + s];
             if (!edge_ok(j, nb_dist[i * k + s], i, eps, n)) continue;

@@ -41,9 +41,6 @@ namespace fal {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-#define FAL_GLDS16(gptr, lptr)                                                                        \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 
 // ------------------------------------------------------------------------------------------------------------
@@ -220,15 +217,14 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
     constexpr int kAllow = (16 + 1) + (kRowOps + 16 + 1), kAllowIdle = 1 + (kRowOps + 1);
 #define FAL_STEP(CUR, FILL, C, STRICT)                                                                     \
     {                                                                                                      \
+        /* wait and barrier in ONE asm per arm: no path reaches a barrier without its wait (tests/isa_lint.py) */ \
         if (STRICT) {                                                                                      \
-            if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps + 16 + 1) : "memory");            \
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRowOps + 1) : "memory");                        \
+            if (active) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kRowOps + 16 + 1) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kRowOps + 1) : "memory");            \
         } else {                                                                                           \
-            if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAllow) : "memory");                      \
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAllowIdle) : "memory");                         \
+            if (active) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kAllow) : "memory");          \
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kAllowIdle) : "memory");             \
         }                                                                                                  \
-        __builtin_amdgcn_s_barrier();                                                                      \
-        asm volatile("" ::: "memory");                                                                     \
         issue_rows((C) + 2, FILL);                                                                         \
         if (active) compute(CUR, C);                                                                       \
         issue_meta((C) + 5);                                                                               \

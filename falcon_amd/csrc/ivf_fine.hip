@@ -20,9 +20,6 @@ namespace fal {
 // three times from L2/HBM, one wave per slice; here once.  Same fmaf chain, same stores: bit-identical sims.
 // Tiles of this kernel = groups of 4 slices (ListScanArgs::group_shift = 7).
 // ------------------------------------------------------------------------------------------------
-#define FAL_GLDS16(gptr, lptr)                                                                        \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 template <int DH4>
 __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
@@ -67,7 +64,7 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
 #pragma unroll
         for (int jj = 0; jj < (DH4 + 3) / 4; ++jj) {
             const int j = 4 * jj + w;
-            if (j < DH4) FAL_GLDS16(rowp + min(j, dh4 - 1), buf + j * 64);
+            if (j < DH4) lds_dma16(rowp + min(j, dh4 - 1), buf + j * 64);
         }
     };
 
@@ -120,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
     int64_t dest_raw = q_dest(0);            // of the chunk whose epilogue runs next
     for (int c0 = 0; c0 < nq; c0 += 64) {
         {
-            __syncthreads();      // chunk c0 has landed; sbuf1 is free again
+            FAL_DMA_BARRIER();    // chunk c0 has landed (every wave drained its own DMA queue first); sbuf1 is free again
             pin(row_next, dest_raw);
             if (c0 + 32 < nq) issue(row_next, sbuf1);
             dest_prev = (uint32_t)(dest_raw - a.sims_base);
@@ -130,7 +127,7 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
         }
         if (c0 + 32 >= nq) break;
         {
-            __syncthreads();
+            FAL_DMA_BARRIER();
             pin(row_next, dest_raw);
             if (c0 + 64 < nq) issue(row_next, sbuf0);
             dest_prev = (uint32_t)(dest_raw - a.sims_base);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
     const int xl = (int)((xcc + turn) & 7);
     const int n_items = table[xl + 1] - table[xl];
     const int32_t* const items = table + 16 + 2 * table[xl];
-    __syncthreads();
+    FAL_DMA_BARRIER();                                       // (nothing of the previous list is in flight past here)
     if (tid == 0) next_item = atomicAdd(&cursors[xl], 1);
     __syncthreads();
     int cur = next_item;
@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
     if (active) epilogue();
     // the cursor value fetched at the top becomes the item after next
     if (tid == 0) next_item = fetched;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (the next item's first chunk stays in flight across this barrier -- it only hands `next_item` over; the chunk is
+    //  waited for by the next item's first chunk_barrier.  The tag exempts it from tests/isa_lint.py's DMA-barrier rule.)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier ; dma-ok: cursor hand-off only" ::: "memory");
     const int nxt2 = next_item;
     par = (par + n_chunks) & 1;
     preloaded = have_next;

@@ -1,60 +1,79 @@
-"""repeat the build of an index (exact k-means and float16-prefiltered k-means) and its search many times on the same data and
-report anything that differs between repetitions: a determinism / race hunt."""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from falcon_amd.device import Context
-from tests.test_gpu_search import unit_vectors, sparse_unit_vectors
+"""Race hunt for the index build (VERDICT r3 next #1d): repeat the exact (all-fp32, `assign_kernel`) and the float16-prefiltered
+k-means build of a 512 / 64 / 200-list index many times on fixed data and compare EVERY repetition with the oracle's index
+(computed once on the CPU).  Options make a late LDS-DMA likely: low_dim 64 / 128 (a chunk's compute phase is only 32 / 64 MFMAs
+long) and `--hammer` (a second stream copies a few GB back and forth all the time: the row DMAs queue behind it in HBM).
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-sparse = len(sys.argv) > 2 and sys.argv[2] == "sparse"
+    python tools/stress_build.py REPS [--d 128] [--sparse] [--hammer] [--lib PATH]
+
+`--lib` loads another build of the same library (A/B against a kept round-3 .so: it must FAIL there and pass here)."""
+import argparse
+import os
+import sys
+import threading
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument("reps", type=int, nargs="?", default=50)
+ap.add_argument("--d", type=int, default=128)
+ap.add_argument("--sparse", action="store_true")
+ap.add_argument("--hammer", action="store_true")
+ap.add_argument("--lib", default=None)
+ap.add_argument("--keyed", action="store_true", help="also repeat the float16-prefiltered build")
+args = ap.parse_args()
+
+from falcon_amd import _lib
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+    _lib._SIGNATURES = {k: v for k, v in _lib._SIGNATURES.items()}      # (an older build may lack newer exports)
+import numpy as np
+import torch
+from falcon_amd.device import Context
+from tests.test_gpu_stress import NLIST, ITERS, compare_index, describe_first_difference, oracle_index, stress_data
+
+if args.lib:
+    import ctypes
+    probe = ctypes.CDLL(_lib.LIB_PATH)
+    _lib._SIGNATURES = {k: v for k, v in _lib._SIGNATURES.items() if hasattr(probe, k)}
 ctx = Context(0)
-sizes = [21000, 3000, 11000]
-nl = np.array([512, 64, 200], np.int32)
-off = np.concatenate([[0], np.cumsum(sizes)])
-n = int(off[-1])
-X = sparse_unit_vectors(n, 128, 67) if sparse else unit_vectors(n, 128, 67, noise=0.35)
-X[off[0]:off[0] + 21000:41] = X[off[0]]
+X, off = stress_data(args.sparse, args.d)
+ref = oracle_index(X, off)
+nl = np.array(NLIST, np.int32)
 Xd = torch.from_numpy(X).to(ctx.tdev)
 X16 = Xd.to(torch.float16).contiguous()
-ref = None
-bad = 0
-for it in range(reps):
-    plain = ctx.ivf_build(Xd, off, nl, kmeans_iters=3)
-    keyed = ctx.ivf_build(Xd, off, nl, kmeans_iters=3, Xkm=X16)
-    ep = [t.cpu().numpy() for t in plain.export()]
-    ek = [t.cpu().numpy() for t in keyed.export()]
-    res = []
-    for n_probe in (32, 5):
-        s0, i0 = plain.search(n_probe, 64)
-        s1, i1 = keyed.search(n_probe, 64)
-        res.append((s0.cpu().numpy().view(np.uint32), i0.cpu().numpy(), s1.cpu().numpy().view(np.uint32), i1.cpu().numpy()))
-    names = ["cent", "asg", "perm", "loff"]
-    msgs = []
-    for nm, a, b in zip(names, ep, ek):
-        if not np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b):
-            msgs.append(f"plain/keyed {nm} differ at {np.flatnonzero((a != b).reshape(len(a), -1).any(1))[:5]}")
-    for j, (s0, i0, s1, i1) in enumerate(res):
-        if not (np.array_equal(i0, i1) and np.array_equal(s0, s1)):
-            rows = np.flatnonzero((i0 != i1).any(1) | (s0 != s1).any(1))
-            msgs.append(f"search {j}: plain/keyed differ in {len(rows)} rows, first {rows[:5]}")
-    cur = (ep, ek, res)
-    if ref is None:
-        ref = cur
-    else:
-        for nm, a, b in zip(names, ref[0], ep):
-            if not np.array_equal(a, b, equal_nan=True):
-                msgs.append(f"plain {nm} differs from repetition 0")
-        for nm, a, b in zip(names, ref[1], ek):
-            if not np.array_equal(a, b, equal_nan=True):
-                msgs.append(f"keyed {nm} differs from repetition 0")
-        for j in range(2):
-            for t, nm in enumerate(["plain sims", "plain idx", "keyed sims", "keyed idx"]):
-                if not np.array_equal(ref[2][j][t], res[j][t]):
-                    rows = np.flatnonzero((ref[2][j][t] != res[j][t]).any(1))
-                    msgs.append(f"search {j} {nm} differs from repetition 0 in {len(rows)} rows, first {rows[:5]}")
-    if msgs:
-        bad += 1
-        print(f"rep {it}:", "; ".join(msgs), flush=True)
-    plain.close(); keyed.close()
-print(f"{reps} repetitions, {bad} with differences")
+
+stop = False
+
+
+def hammer():
+    s2 = torch.cuda.Stream(device=ctx.tdev)
+    a = torch.empty(1 << 30, dtype=torch.uint8, device=ctx.tdev)
+    b = torch.empty(1 << 30, dtype=torch.uint8, device=ctx.tdev)
+    with torch.cuda.stream(s2):
+        while not stop:
+            for _ in range(8):
+                b.copy_(a)
+                a.copy_(b)
+            s2.synchronize()
+
+
+th = None
+if args.hammer:
+    th = threading.Thread(target=hammer, daemon=True)
+    th.start()
+
+bad = {"plain": 0, "keyed": 0}
+for it in range(args.reps):
+    for which in (("plain", "keyed") if args.keyed else ("plain",)):
+        index = ctx.ivf_build(Xd, off, nl, kmeans_iters=ITERS, Xkm=X16 if which == "keyed" else None)
+        diff, got = compare_index(ref, index.export())
+        if diff:
+            bad[which] += 1
+            if bad[which] <= 10:
+                print(f"rep {it}: {which} build left the oracle in {diff}: {describe_first_difference(X, off, ref, got)}", flush=True)
+        index.close()
+stop = True
+if th:
+    th.join()
+print(f"lib={os.path.basename(_lib.LIB_PATH)} d={args.d} sparse={args.sparse} hammer={args.hammer}: {args.reps} repetitions, "
+      f"{bad['plain']} plain and {bad['keyed']} keyed builds differ from the oracle")
+sys.exit(1 if (bad["plain"] or bad["keyed"]) else 0)
