@@ -83,6 +83,19 @@ struct fal_ctx {
     int pool_alloc(size_t bytes, void** out);
     void pool_free(void* ptr);
 
+    // Scratch slots (`reserve`): a pointer handed out stays valid until the public call that obtained it returns -- a slot
+    // that has to grow retires its old block instead of freeing it; retired blocks are freed when the next public call
+    // begins (fal::CallScope).  FALCON_DEBUG_POISON=1: every grown slot and every pool block is filled with 0xFF before use
+    // (reads of scratch nobody wrote show up as NaN / -1 instead of a previous test's plausible data), and a slot that
+    // grows after it was already reserved inside the same public call fails with FAL_EINTERNAL (the earlier pointer would
+    // silently address the old block).
+    bool debug_poison = false;
+    int call_depth = 0;
+    uint64_t call_epoch = 1;
+    uint64_t slot_epoch[32] = {};
+    uint32_t slot_gen[32] = {};
+    std::vector<void*> retired;
+    void release_retired();
     int reserve(int slot, size_t bytes, void** out);
     void stage_reset(int stage);
     int stage_begin(int stage, hipEvent_t* stop_out, hipStream_t on = nullptr);
@@ -103,6 +116,21 @@ struct StageScope {
     }
     ~StageScope() {
         if (on && stop) c->stage_end(stop, s);
+    }
+};
+
+// First statement of every public entry point that uses a context: scratch pointers obtained below it stay valid until it
+// ends (see fal_ctx::reserve).  Entry points call each other; only the outermost scope counts.
+struct CallScope {
+    fal_ctx* c;
+    explicit CallScope(fal_ctx* ctx) : c(ctx) {
+        if (c && c->call_depth++ == 0) {
+            ++c->call_epoch;
+            if (!c->retired.empty()) c->release_retired();
+        }
+    }
+    ~CallScope() {
+        if (c) --c->call_depth;
     }
 };
 

@@ -1,6 +1,7 @@
 // Context, error reporting and the two host-side helpers (a1 get_dim, a3 hash table).
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 #include "hash.h"
@@ -15,19 +16,44 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace fal
 
+void fal_ctx::release_retired() {
+    if (retired.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (void* p : retired) (void)hipFree(p);
+    retired.clear();
+}
+
 int fal_ctx::reserve(int slot, size_t bytes, void** out) {
     fal::Scratch& s = scratch[slot];
     if (bytes > s.cap) {
         if (s.ptr) {
-            FAL_CHECK_HIP(hipStreamSynchronize(stream));
-            FAL_CHECK_HIP(hipFree(s.ptr));
+            if (debug_poison && call_depth > 0 && slot_epoch[slot] == call_epoch) {
+                fal::set_error("scratch slot %d grows (%zu -> %zu bytes) after it was reserved earlier in the same call: "
+                               "a pointer into its old block would be stale", slot, s.cap, bytes);
+                return FAL_EINTERNAL;
+            }
+            if (call_depth > 0) {
+                retired.push_back(s.ptr);        // kernels of this call may still use it; freed when the next call begins
+            } else {
+                FAL_CHECK_HIP(hipStreamSynchronize(stream));
+                FAL_CHECK_HIP(hipFree(s.ptr));
+            }
             s.ptr = nullptr;
             s.cap = 0;
         }
-        size_t want = bytes + bytes / 8 + 256;
-        FAL_CHECK_HIP(hipMalloc(&s.ptr, want));
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&s.ptr, want);
+        if (e == hipErrorOutOfMemory && !retired.empty()) {     // (the retired blocks are what does not fit: let them go)
+            (void)hipGetLastError();
+            release_retired();
+            e = hipMalloc(&s.ptr, want);
+        }
+        FAL_CHECK_HIP(e);
         s.cap = want;
+        ++slot_gen[slot];
+        if (debug_poison) FAL_CHECK_HIP(hipMemsetAsync(s.ptr, 0xFF, want, stream));
     }
+    slot_epoch[slot] = call_epoch;
     *out = s.ptr;
     return FAL_OK;
 }
@@ -40,12 +66,14 @@ int fal_ctx::pool_alloc(size_t bytes, void** out) {
     if (best >= 0 && pool[best].cap <= 2 * bytes + (1 << 20)) {
         pool[best].used = true;
         *out = pool[best].ptr;
+        if (debug_poison) FAL_CHECK_HIP(hipMemsetAsync(pool[best].ptr, 0xFF, pool[best].cap, stream));
         return FAL_OK;
     }
     void* p = nullptr;
     const size_t cap = bytes + bytes / 16 + 256;
     FAL_CHECK_HIP(hipMalloc(&p, cap));
     pool.push_back({p, cap, true});
+    if (debug_poison) FAL_CHECK_HIP(hipMemsetAsync(p, 0xFF, cap, stream));
     *out = p;
     return FAL_OK;
 }
@@ -164,6 +192,8 @@ int fal_ctx_create(int device, void* stream, int own_stream, fal_ctx** out) {
         return FAL_ENOMEM;
     }
     memset(c->fb_host, 0, 64);
+    const char* dbg = getenv("FALCON_DEBUG_POISON");
+    c->debug_poison = dbg && dbg[0] && dbg[0] != '0';
     *out = c;
     return FAL_OK;
 }
@@ -174,6 +204,7 @@ int fal_ctx_destroy(fal_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& s : c->scratch)
         if (s.ptr) (void)hipFree(s.ptr);
+    for (void* p : c->retired) (void)hipFree(p);
     for (auto& b : c->pool) (void)hipFree(b.ptr);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->fb_host) (void)hipHostFree(c->fb_host);
@@ -190,6 +221,7 @@ int fal_ctx_destroy(fal_ctx* c) {
 }
 
 int fal_ctx_sync(fal_ctx* c) {
+    fal::CallScope _call(c);
     FAL_REQUIRE(c, FAL_EINVAL, "fal_ctx_sync: NULL ctx");
     FAL_CHECK_HIP(hipStreamSynchronize(c->stream));
     return FAL_OK;
@@ -209,6 +241,7 @@ int fal_ctx_counter(fal_ctx* c, int which, int64_t* value) {
 }
 
 int fal_ctx_stage_ms(fal_ctx* c, int stage, float* ms, int64_t* launches) {
+    fal::CallScope _call(c);
     FAL_REQUIRE(c && ms && stage >= 0 && stage < fal::kNumStages, FAL_EINVAL, "fal_ctx_stage_ms: bad argument");
     FAL_CHECK_HIP(hipStreamSynchronize(c->stream));
     float total = 0.f;

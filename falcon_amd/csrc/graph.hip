@@ -276,6 +276,7 @@ extern "C" {
 int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int64_t n, int k_ann,
                          const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
                          double rt_tol, int n_neighbors, int32_t* nb_idx, float* nb_dist) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && k_ann >= 1 && n_neighbors >= 1, FAL_EINVAL, "fal_filter_neighbors: bad argument");
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(sim && idx && precursor_mz_sorted && nb_idx && nb_dist, FAL_EINVAL, "fal_filter_neighbors: NULL array");
@@ -290,6 +291,7 @@ int fal_filter_neighbors(fal_ctx* ctx, const float* sim, const int32_t* idx, int
 
 int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, const int32_t* nb_count, int64_t n, int k,
                          int64_t id_offset, int64_t row0, int64_t* indptr_out, int32_t* idx_out, float* dist_out) {
+    fal::CallScope _call(ctx);
     return fal_neighbors_to_csr_mapped(ctx, nb_idx, nb_dist, nb_count, n, k, nullptr, id_offset, row0, indptr_out, idx_out,
                                        dist_out);
 }
@@ -297,6 +299,7 @@ int fal_neighbors_to_csr(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_di
 int fal_neighbors_to_csr_mapped(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, const int32_t* nb_count, int64_t n,
                                 int k, const int64_t* id_map, int64_t id_offset, int64_t row0, int64_t* indptr_out,
                                 int32_t* idx_out, float* dist_out) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && row0 >= 0, FAL_EINVAL, "fal_neighbors_to_csr: bad argument");
     FAL_REQUIRE(indptr_out, FAL_EINVAL, "fal_neighbors_to_csr: NULL indptr");
     if (row0 == 0) FAL_CHECK_HIP(hipMemsetAsync(indptr_out, 0, sizeof(int64_t), ctx->stream));
@@ -366,6 +369,7 @@ int fal::dbscan_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, i
 
 extern "C" int fal_dbscan(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float eps,
                           int32_t* labels, int64_t* n_clusters) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_dbscan: bad argument");
     if (n_clusters) *n_clusters = 0;
     if (n == 0) return FAL_OK;

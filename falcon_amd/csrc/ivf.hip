@@ -309,6 +309,7 @@ __global__ void rows_sign16_kernel(const uint4* __restrict__ x, int64_t n8, int3
 extern "C" {
 
 int fal_ivf_destroy(fal_ivf* ivf) {
+    fal::CallScope _call(ivf ? ivf->ctx : nullptr);
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
                     ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals, ivf->neg_dev};
@@ -319,6 +320,7 @@ int fal_ivf_destroy(fal_ivf* ivf) {
 }
 
 int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes) {
+    fal::CallScope _call(ivf ? ivf->ctx : nullptr);
     FAL_REQUIRE(ivf && X16 && (planes == 1 || planes == 2), FAL_EINVAL, "fal_ivf_attach_f16: bad argument");
     {
         const int d = ivf->d;
@@ -335,6 +337,7 @@ int fal_ivf_attach_f16(fal_ivf* ivf, const void* X16, int planes) {
 int fal_ivf_attach_prefilter(fal_ivf* ivf, const void* X16) { return fal_ivf_attach_prefilter_ex(ivf, X16, 1); }
 
 int fal_ivf_attach_prefilter_ex(fal_ivf* ivf, const void* X16, int which) {
+    fal::CallScope _call(ivf ? ivf->ctx : nullptr);
     FAL_REQUIRE(ivf && X16, FAL_EINVAL, "fal_ivf_attach_prefilter: NULL argument");
     FAL_REQUIRE(ivf->X, FAL_EINVAL, "fal_ivf_attach_prefilter: the index has no float32 rows to refine with");
     FAL_REQUIRE(which >= 1 && which <= 3, FAL_EINVAL, "fal_ivf_attach_prefilter_ex: which must be 1 (flat buckets), 2 (IVF buckets) or 3");
@@ -380,11 +383,13 @@ int fal_ivf_total_lists(const fal_ivf* ivf, int64_t* total_lists) {
 
 int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const int64_t* bucket_off,
                   int64_t n_buckets, const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
+    fal::CallScope _call(ctx);
     return fal_ivf_build_x16(ctx, X, nullptr, n, low_dim, bucket_off, n_buckets, n_list, kmeans_iters, out);
 }
 
 int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, int low_dim, const int64_t* bucket_off,
                       int64_t n_buckets, const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && out, FAL_EINVAL, "fal_ivf_build: NULL ctx/out");
     *out = nullptr;
     FAL_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "fal_ivf_build: n must be < 2^31 per partition");
@@ -661,6 +666,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
 
 int fal_ivf_export(fal_ctx* ctx, const fal_ivf* ivf, float* centroids, int32_t* assign, int32_t* perm,
                    int64_t* list_off) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && ivf, FAL_EINVAL, "fal_ivf_export: NULL");
     hipStream_t st = ctx->stream;
     if (centroids)

@@ -303,6 +303,7 @@ using namespace fal;
 
 extern "C" int fal_linkage_cluster(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64_t n, int k, float threshold,
                                    int method, int32_t* labels, int64_t* n_clusters) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_linkage_cluster: bad argument");
     FAL_REQUIRE(method >= 0 && method <= 2, FAL_EINVAL, "fal_linkage_cluster: method must be 0 (single), 1 (complete) or 2 (average)");
     FAL_REQUIRE(threshold < 1.0f, FAL_EUNSUPPORTED, "fal_linkage_cluster: the threshold must be below 1 (the distance of a missing pair)");

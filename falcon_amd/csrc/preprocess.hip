@@ -239,6 +239,7 @@ extern "C" int fal_process_spectra(fal_ctx* ctx, const double* mz, const float* 
                                    double min_mz_range, double mz_min, double mz_max, double remove_precursor_tol,
                                    double min_intensity, int max_peaks_used, int scaling, int32_t* valid_out,
                                    int64_t* out_indptr, float* out_mz, float* out_intensity) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && nnz >= 0, FAL_EINVAL, "fal_process_spectra: bad argument");
     FAL_REQUIRE(scaling >= 0 && scaling <= 3 && max_peaks_used >= 0 && min_peaks >= 0, FAL_EINVAL,
                 "fal_process_spectra: bad option");

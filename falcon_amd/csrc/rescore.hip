@@ -180,6 +180,7 @@ using namespace fal;
 extern "C" int fal_rescore_neighbors(fal_ctx* ctx, const int32_t* nb_idx, float* nb_dist, int64_t n, int k, const float* mz,
                                      const float* intensity, const int64_t* indptr, const int64_t* row_order,
                                      double fragment_tol, int min_matches) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && k >= 1 && fragment_tol >= 0.0, FAL_EINVAL, "fal_rescore_neighbors: bad argument");
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(nb_idx && nb_dist && indptr && row_order, FAL_EINVAL, "fal_rescore_neighbors: NULL array");

@@ -631,6 +631,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
 }
 
 extern "C" int fal_ivf_search_topk(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann, float* sim, int32_t* idx) {
+    fal::CallScope _call(ctx);
     return search_impl(ctx, ivf, n_probe, k_ann, sim, idx, nullptr);
 }
 
@@ -638,6 +639,7 @@ extern "C" int fal_ivf_search_neighbors(fal_ctx* ctx, const fal_ivf* ivf, int n_
                                         const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
                                         double rt_tol, int n_neighbors, int32_t* nb_idx, float* nb_dist,
                                         int32_t* nb_count) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && ivf, FAL_EINVAL, "fal_ivf_search_neighbors: NULL ctx/ivf");
     FAL_REQUIRE(n_neighbors >= 1 && n_neighbors <= FAL_MAX_K_ANN, FAL_EUNSUPPORTED,
                 "fal_ivf_search_neighbors: n_neighbors must be in [1, %d]", FAL_MAX_K_ANN);

@@ -275,6 +275,7 @@ using namespace fal;
 extern "C" {
 
 int fal_sort_by_precursor(fal_ctx* ctx, const float* precursor_mz, int64_t n, int64_t* order_out, float* mz_sorted_out) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0, FAL_EINVAL, "fal_sort_by_precursor: bad argument");
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(precursor_mz && order_out && mz_sorted_out, FAL_EINVAL, "fal_sort_by_precursor: NULL array");
@@ -297,6 +298,7 @@ int fal_sort_by_precursor(fal_ctx* ctx, const float* precursor_mz, int64_t n, in
 }
 
 int fal_gather_f32(fal_ctx* ctx, const float* src, const int64_t* order, int64_t n, float* out) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0, FAL_EINVAL, "fal_gather_f32: bad argument");
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(src && order && out, FAL_EINVAL, "fal_gather_f32: NULL array");
@@ -308,6 +310,7 @@ int fal_gather_f32(fal_ctx* ctx, const float* src, const int64_t* order, int64_t
 
 int fal_window_counts(fal_ctx* ctx, const float* const* precursor_mz, const int64_t* n, int n_parts, double mz_interval,
                       int64_t n_windows, int32_t* counts, int32_t* counts_host) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n_parts >= 0 && mz_interval > 0.0 && n_windows >= 1 && (n_parts == 0 || (precursor_mz && n && counts)),
                 FAL_EINVAL, "fal_window_counts: bad argument");
     if (n_parts == 0) return FAL_OK;
@@ -349,6 +352,7 @@ int fal_window_counts(fal_ctx* ctx, const float* const* precursor_mz, const int6
 
 int fal_window_select(fal_ctx* ctx, const float* precursor_mz, int64_t n, double mz_interval, int64_t n_windows,
                       const int32_t* owner, int rank, int64_t* rows_out, float* mz_out, int64_t* count) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && mz_interval > 0.0 && n_windows >= 1 && owner && count, FAL_EINVAL, "fal_window_select: bad argument");
     *count = 0;
     if (n == 0) return FAL_OK;
@@ -373,6 +377,7 @@ int fal_window_select(fal_ctx* ctx, const float* precursor_mz, int64_t n, double
 int fal_precursor_splits(fal_ctx* ctx, const float* mz, int64_t n, double tol, int tol_is_da, int64_t batch_size,
                          double mz_interval, int chunk_last, int64_t* splits_out, int64_t max_splits,
                          int64_t* n_splits) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && splits_out && n_splits && n >= 0 && batch_size >= 1 && max_splits >= 2, FAL_EINVAL,
                 "fal_precursor_splits: bad argument");
     *n_splits = 0;

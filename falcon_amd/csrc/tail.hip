@@ -524,6 +524,7 @@ extern "C" {
 
 int fal_refine_clusters(fal_ctx* ctx, int32_t* labels, int64_t n, const float* precursor_mz_sorted,
                         const float* rt_sorted, double tol, int tol_is_da, double rt_tol, int64_t* n_clusters) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n_clusters && n >= 0 && n < (int64_t)INT32_MAX, FAL_EINVAL, "fal_refine_clusters: bad argument");
     const int64_t C = *n_clusters;
     FAL_REQUIRE(C >= 0 && C <= n, FAL_EINVAL, "fal_refine_clusters: *n_clusters must hold the DBSCAN cluster count");
@@ -545,6 +546,7 @@ int fal_refine_clusters(fal_ctx* ctx, int32_t* labels, int64_t n, const float* p
 int fal_finalize(fal_ctx* ctx, const int32_t* labels_sorted, int64_t n, int64_t n_clusters, const int64_t* row_order,
                  const int32_t* nb_idx, const float* nb_dist, int k, int32_t* labels_out, int32_t* medoids_out,
                  int64_t* n_labels) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && n >= 0 && n_clusters >= 0 && n_clusters <= n && k >= 1, FAL_EINVAL, "fal_finalize: bad argument");
     if (n_labels) *n_labels = 0;
     if (n == 0) return FAL_OK;
@@ -596,6 +598,7 @@ int fal_cluster_graph(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist,
                       const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
                       double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
                       int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+    fal::CallScope _call(ctx);
     return cluster_graph_impl(ctx, nb_idx, nb_dist, n, k, eps, -1, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol,
                               row_order, labels_sorted_scratch, labels_out, medoids_out, n_clusters, n_labels);
 }
@@ -604,6 +607,7 @@ int fal_cluster_graph_counted(fal_ctx* ctx, const int32_t* nb_idx, const float* 
                               float eps, const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
                               double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
                               int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(nb_count || n == 0, FAL_EINVAL, "fal_cluster_graph_counted: NULL nb_count");
     return cluster_graph_impl(ctx, nb_idx, nb_dist, n, k, eps, -1, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol,
                               row_order, labels_sorted_scratch, labels_out, medoids_out, n_clusters, n_labels, nb_count);
@@ -613,6 +617,7 @@ int fal_cluster_graph_linkage(fal_ctx* ctx, const int32_t* nb_idx, const float* 
                               int method, const float* precursor_mz_sorted, const float* rt_sorted, double tol, int tol_is_da,
                               double rt_tol, const int64_t* row_order, int32_t* labels_sorted_scratch, int32_t* labels_out,
                               int32_t* medoids_out, int64_t* n_clusters, int64_t* n_labels) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(method >= 0 && method <= 2, FAL_EINVAL, "fal_cluster_graph_linkage: method must be 0 (single), 1 (complete) or 2 (average)");
     FAL_REQUIRE(threshold < 1.0f, FAL_EUNSUPPORTED, "fal_cluster_graph_linkage: the threshold must be below 1 (the distance of a missing pair)");
     return cluster_graph_impl(ctx, nb_idx, nb_dist, n, k, threshold, method, precursor_mz_sorted, rt_sorted, tol, tol_is_da, rt_tol,

@@ -154,6 +154,7 @@ extern "C" {
 
 int fal_to_vector_indices(fal_ctx* ctx, const float* mz, int64_t nnz, double min_mz, double bin_size,
                           int32_t* out_indices) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(ctx && (nnz == 0 || (mz && out_indices)) && nnz >= 0 && bin_size > 0, FAL_EINVAL,
                 "fal_to_vector_indices: bad argument");
     if (nnz == 0) return FAL_OK;
@@ -171,6 +172,7 @@ static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity,
 int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                   const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                   uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(out_dtype == FAL_DTYPE_F32 || out_dtype == FAL_DTYPE_F16 || out_dtype == FAL_DTYPE_SPLIT16, FAL_EINVAL,
                 "fal_vectorize: bad out_dtype");
     return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out_dtype, out,
@@ -180,6 +182,7 @@ int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const i
 int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                        const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                        uint32_t low_dim, uint32_t seed, int normalize, float* out_f32, void* out_f16) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(n == 0 || out_f16, FAL_EINVAL, "fal_vectorize_pair: NULL array");
     return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, -3, out_f32,
                           out_f16);
@@ -188,6 +191,7 @@ int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, co
 int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                             const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                             uint32_t low_dim, uint32_t seed, int normalize, float* out_f32_image, void* out_f16) {
+    fal::CallScope _call(ctx);
     FAL_REQUIRE(n == 0 || (out_f16 && out_f32_image), FAL_EINVAL, "fal_vectorize_f16_image: NULL array");
     return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, -4,
                           out_f32_image, out_f16);

@@ -114,7 +114,7 @@ def select_charge(data: dict, charge: int) -> dict:
 # numpy generator needs ~20 s of host time per million spectra.  Same distributions, parameters and
 # layout as `_block` / `generate` / `select_charge`; a different random stream (torch's Philox), so the
 # spectra are statistically -- not bitwise -- the numpy ones.  Parity tests keep the numpy generator
-# (the oracle runs on its output); tests/test_gpu_synth.py compares the statistics of the two.
+# (the oracle runs on its output); tests/test_host_logic.py::test_device_generator_matches_the_numpy_recipe_statistically compares the statistics of the two.
 # ---------------------------------------------------------------------------------------------
 def _block_device(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, dev):
     import torch

@@ -35,6 +35,7 @@ extern "C" {
 #define FAL_ENOMEM       -3   /* device allocation failed */
 #define FAL_ENODEV       -4   /* no usable gfx950 device */
 #define FAL_EUNSUPPORTED -5   /* parameter outside the compiled limits */
+#define FAL_EINTERNAL    -6   /* a library invariant failed (only raised under FALCON_DEBUG_POISON=1) */
 
 #define FAL_DTYPE_F32 0
 #define FAL_DTYPE_F16 1

@@ -30,7 +30,8 @@ def _free_port():
 def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, regime):
     import torch
     if torch.cuda.is_initialized():
-        pytest.skip("this pytest process already owns a GPU context: run tests/test_gpu_0_world2.py first / on its own")
+        pytest.fail("this pytest process already owns a GPU context (a GPU test file sorted in front of this one?): "
+                    "tests/test_gpu_00_world2.py must run first / on its own")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "world2_worker.py"), str(tmp_path), str(n_spectra),
@@ -73,7 +74,8 @@ def test_bench_runs_as_a_two_rank_job(scaling, extra):
     import json
     import torch
     if torch.cuda.is_initialized():
-        pytest.skip("this pytest process already owns a GPU context: run tests/test_gpu_0_world2.py first / on its own")
+        pytest.fail("this pytest process already owns a GPU context (a GPU test file sorted in front of this one?): "
+                    "tests/test_gpu_00_world2.py must run first / on its own")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", FALCON_BENCH_DEVICE="0", FALCON_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_0_world2.py: one rank of a world-size-N job on ONE GPU (gloo carries the collectives; RCCL refuses
+"""Worker of tests/test_gpu_00_world2.py: one rank of a world-size-N job on ONE GPU (gloo carries the collectives; RCCL refuses
 two ranks on one device).  Launched by `python -m torch.distributed.run`; never imported by pytest.
 
 Every rank builds the same dataset (numpy generator, same seed), runs the HIP pipeline on its own precursor buckets
