@@ -136,6 +136,10 @@ def main():
                          "numpy generator the parity tests use (~20 s of host time per million spectra)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange step's device work (CSR packing, payload) at 1 GPU too (no collective)")
+    ap.add_argument("--exchange-only", action="store_true",
+                    help="collective self-check: run ONLY the exchange step (SparseGraphExchange: sizes all-gather + one padded "
+                         "payload all-gather over RCCL) with synthetic ragged payloads on the N ranks, verify every rank's received "
+                         "bytes, print one JSON line and exit (0 = ok)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the 10 M / 50 M configurations of the `configs` array")
     ap.add_argument("--configs-spectra", type=int, default=10_000_000)
@@ -177,6 +181,27 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def rccl_info():
+        try:
+            v = torch.cuda.nccl.version()
+            v = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:                                    # pragma: no cover
+            v = f"unavailable ({e!r})"
+        return {"backend": backend if world > 1 else "none (1 rank)", "version": v, "ranks": world,
+                "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+
+    if args.exchange_only:
+        res = fdist.exchange_self_check(dev, n_neighbors=args.n_neighbors)
+        res.update({"mode": "exchange-only", "n_gpus": world, "rccl": rccl_info()})
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(res), flush=True)
+        sys.exit(0 if res["ok"] else 1)
 
     ctx = Context(local_rank)
     pipe = ClusterPipeline(ctx)
@@ -575,6 +600,7 @@ def main():
                                 if world > 1 else None)},
             "roofline": roof,
             "stage_ms": s["stage_ms"],
+            "rccl": rccl_info(),
         }
         if h2h is not None:
             out["value_host_to_host"] = n_total / h2h

@@ -310,6 +310,7 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
     if (a_in.n_tiles <= 0) return FAL_OK;
     Coarse16Args a = a_in;
     int32_t* tj = nullptr;
+    ctx->release(SLOT_TILEJOB);        // a launcher-local table: the previous launcher's pointer is dead
     FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(a.n_tiles, 1 << 16) + 32 * a.n_tiles + 64), (void**)&tj));
     StageScope ts(ctx, ST_COARSE);
     hipLaunchKernelGGL(tile_job_c16_kernel, dim3((unsigned)ceil_div(a.n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,

@@ -97,6 +97,9 @@ struct fal_ctx {
     std::vector<void*> retired;
     void release_retired();
     int reserve(int slot, size_t bytes, void** out);
+    // the caller holds no pointer into the slot any more (kernels already enqueued keep their block: it is retired, not freed,
+    // if the slot grows): the next reserve of this call may grow it without tripping the debug check
+    void release(int slot) { slot_epoch[slot] = 0; }
     void stage_reset(int stage);
     int stage_begin(int stage, hipEvent_t* stop_out, hipStream_t on = nullptr);
     int stage_end(hipEvent_t stop, hipStream_t on = nullptr);

@@ -503,6 +503,7 @@ int launch_select16(fal_ctx* ctx, const Select16Args& a_in, int64_t n_tiles) {
     a.n_tiles = n_tiles;
     // tile -> job table, then the list of queries with more than 2,048 keys (count in front)
     int32_t* tj = nullptr;
+    ctx->release(SLOT_TILEJOB);        // a launcher-local table: the previous launcher's pointer is dead
     FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(n_tiles, 1 << 16) + 32 * n_tiles + 64), (void**)&tj));
     a.big_count = tj + std::max<int64_t>(n_tiles, 1 << 16);
     a.big_list = a.big_count + 16;

@@ -423,6 +423,7 @@ int launch_kept16(fal_ctx* ctx, const Kept16Args& a_in, int64_t n_tiles) {
     if (n_tiles <= 0) return FAL_OK;
     Kept16Args a = a_in;
     int32_t* tj = nullptr;           // (the tile -> job table launch_select16 left in the slot for the same tiles)
+    ctx->release(SLOT_TILEJOB);        // a launcher-local table: the previous launcher's pointer is dead
     FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * 16, (void**)&tj));
     a.tile_job = tj;
     a.n_tiles = n_tiles;

@@ -648,6 +648,7 @@ int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a_in, int
         // tile -> job once per tile instead of a binary search in every query's workgroup
         const int64_t n_tiles = n_blocks / 32;
         int32_t* tj = nullptr;
+        ctx->release(SLOT_TILEJOB);        // a launcher-local table: the previous launcher's pointer is dead
         FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)std::max<int64_t>(n_tiles, 1 << 16), (void**)&tj));
         hipLaunchKernelGGL(tile_job_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, on ? on : ctx->stream, a.jobs,
                            a.n_jobs, a.tile_begin, n_tiles, tj);

@@ -571,6 +571,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         uint16_t* keys = nullptr;
         // (list16_kernel addresses a batch's keys by 32-bit byte offsets from the buffer's base)
         FAL_REQUIRE(need_fine + 2 * kSimsSlack < ((size_t)1 << 31), FAL_EUNSUPPORTED, "key batch too large (lower FALCON_SIMS_MB)");
+        ctx->release(SLOT_SIMS);        // the flat / coarse stage's sims are dead (its launches are enqueued)
         FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(uint16_t) * (need_fine + 2 * kSimsSlack), (void**)&keys));
         int64_t max_cand = 0;
         for (int64_t t = 0; t < ivf_tiles; ++t) max_cand = std::max(max_cand, qoff[(size_t)t + 1] - qoff[(size_t)t]);
@@ -606,6 +607,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         FAL_CHECK_HIP(hipStreamSynchronize(st));
         return FAL_OK;
     }
+    ctx->release(SLOT_SIMS);        // the flat / coarse stage's sims are dead (its launches are enqueued)
     FAL_TRY(ctx->reserve(SLOT_SIMS, sizeof(float) * (need_fine + kSimsSlack), (void**)&sims));
     FAL_TRY(ivf_ensure_xl(ctx, ivf));
     for (const IvfBatch& bt : ivf_batches) {

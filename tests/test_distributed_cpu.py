@@ -295,3 +295,49 @@ def test_run_sharded_world2_gloo_equals_one_rank():
     assert np.array_equal(np.sort(m0), np.sort(rmed))
     assert np.array_equal(l0[m0], np.arange(len(m0)))
     assert len(np.unique(ref)) > 50 and (np.bincount(ref) > 1).sum() > 20    # a non-trivial clustering
+
+
+def _self_check_worker(rank, world, port, q, corrupt):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from falcon_amd import distributed as fd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if corrupt and rank == 1:
+            # a rank whose received bytes differ from what the sender built: flip one id of rank 0's piece on arrival
+            orig = fd.SparseGraphExchange.finish
+
+            def bad_finish(self, h):
+                g = orig(self, h)
+                g["idx"][0][0] += 1
+                return g
+            fd.SparseGraphExchange.finish = bad_finish
+        q.put((rank, fd.exchange_self_check(torch.device("cpu"), n_neighbors=8, scale=300, rounds=2)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_exchange_self_check_world3_gloo(corrupt):
+    """`bench.py --exchange-only`'s collective self-test (ragged payloads, every rank verifies every rank's bytes) on three
+    gloo ranks; a single flipped id on one rank turns the verdict red on ALL ranks"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + (7 if corrupt else 0)
+    procs = [ctx.Process(target=_self_check_worker, args=(r, 3, port, q, corrupt)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(3):
+        assert res[r]["world_size"] == 3 and res[r]["ranks_seen"] == [0, 1, 2]
+        assert res[r]["ok"] == (not corrupt)
+    assert len({res[r]["payload_bytes_this_rank"] for r in range(3)}) == 3          # ragged: every rank sends a different size
+    if corrupt:
+        assert res[1]["local_errors"] and not res[0]["local_errors"]

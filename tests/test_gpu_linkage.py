@@ -32,12 +32,13 @@ def test_linkage_matches_reference_golden(ctx, method):
         assert n_cl == exp.max() + 1
 
 
-def test_linkage_refuses_a_connected_group_beyond_its_cap(ctx):
-    """the complete / average agglomeration is one wave per connected group and cubic in its size; a chain of 3,000
-    rows within the threshold (what single-linkage chaining produces on dense precursor regions) must be refused with a
-    clear error instead of running for minutes.  Single linkage takes the same graph."""
+def test_linkage_has_no_group_size_cap(ctx):
+    """round 3 refused connected groups of more than 2,048 rows (`FAL_EUNSUPPORTED`) where the reference runs
+    fastcluster on whole blocks (cluster.py:277-290).  Groups beyond the one-wave form now take `lk_agglomerate_big_kernel`
+    (a 16-wave workgroup, cached nearest partners: the same merges in the same order).  A chain of 3,000 rows with EQUAL
+    distances inside the threshold: the tie order (lowest (a, b) first) pairs the rows up -- (0, 1), (2, 3), ... -- and a pair
+    cannot take a third row (complete: one missing pair = height 1; average: (1 + 0.05) / 2)."""
     import torch
-    from falcon_amd._lib import FalconHipError
     n, k = 3000, 4
     idx = np.full((n, k), -1, np.int32)
     dist = np.full((n, k), np.inf, np.float32)
@@ -45,14 +46,44 @@ def test_linkage_refuses_a_connected_group_beyond_its_cap(ctx):
     dist[:-1, 0] = 0.05
     ti, td = torch.from_numpy(idx).to(ctx.tdev), torch.from_numpy(dist).to(ctx.tdev)
     for method in ("complete", "average"):
-        with pytest.raises(FalconHipError, match="connected group of 3000 spectra"):
-            ctx.linkage_cluster(ti, td, 0.1, method)
+        lab, n_cl = ctx.linkage_cluster(ti, td, 0.1, method)
+        assert n_cl == n // 2
+        assert np.array_equal(lab.cpu().numpy(), np.arange(n) // 2), method
     lab, n_cl = ctx.linkage_cluster(ti, td, 0.1, "single")
     assert n_cl == 1 and bool((lab == 0).all())
-    # a group below the cap still runs
-    m = 1500
-    lab, n_cl = ctx.linkage_cluster(ti[:m].clone().clamp(max=m - 1), td[:m].clone(), 0.1, "complete")
-    assert n_cl >= 1
+
+
+@pytest.mark.parametrize("m,k", [(2500, 24), (6000, 16)])
+def test_linkage_of_a_group_of_thousands_of_rows_equals_scipy(ctx, m, k):
+    """one connected group of m rows next to small ones (both agglomeration kernels in one call), distinct heights (random
+    geometry), so scipy's dendrogram cut at t is THE answer: labels must be identical, not just ARI-close"""
+    import torch
+    rng = np.random.default_rng(m)
+    # a long noisy curve: neighbours along the curve are within the threshold, the group is one component of m rows
+    s = np.arange(m) * 0.006
+    pos = np.stack([s, 0.008 * rng.normal(size=m)], 1)
+    small = np.concatenate([rng.normal(size=(30, 2)) * 0.01 + np.array([0.0, 50.0 + 5 * g]) for g in range(20)])
+    pos = np.concatenate([pos, small])
+    n = len(pos)
+    nb_idx = np.full((n, k), -1, np.int32)
+    nb_dist = np.full((n, k), np.inf, np.float32)
+    for i0 in range(0, n, 1000):
+        blk = np.sqrt(((pos[i0:i0 + 1000, None] - pos[None]) ** 2).sum(-1)).astype(np.float32)
+        for r in range(len(blk)):
+            i = i0 + r
+            o = np.argpartition(blk[r], k + 1)[:k + 1]
+            o = o[np.argsort(blk[r][o], kind="stable")]
+            o = o[o != i][:k]
+            nb_idx[i, :len(o)] = o
+            nb_dist[i, :len(o)] = np.clip(blk[r][o], 0, 0.99)
+    ti, td = torch.from_numpy(nb_idx).to(ctx.tdev), torch.from_numpy(nb_dist).to(ctx.tdev)
+    for method, t in (("complete", 0.05), ("average", 0.04)):
+        ref = fo.linkage_clusters(nb_idx, nb_dist, t, method)
+        lab, n_cl = ctx.linkage_cluster(ti, td, t, method)
+        lab = lab.cpu().numpy()
+        assert np.array_equal(lab, ref), (method, int((lab != ref).sum()))
+        assert n_cl == ref.max() + 1
+        assert np.bincount(ref[:m][ref[:m] >= 0]).max() < 200          # (the big group is cut into many small clusters)
 
 
 def test_linkage_large_component_and_ties(ctx):
