@@ -481,6 +481,8 @@ int linkage_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64
     hipLaunchKernelGGL(lk_label_kernel, dim3(grid), dim3(256), 0, st, rep, rank, n, labels);
     FAL_CHECK_HIP(hipGetLastError());
     *d_count_out = rank + n;
+    // the agglomeration's work arrays are dead on the host side (their kernels are enqueued): the tail stage reuses the slots
+    for (int slot : {SLOT_TAIL, SLOT_TAIL2, SLOT_TAIL3, SLOT_TAIL4, SLOT_DB3}) ctx->release(slot);
     return FAL_OK;
 }
 

@@ -187,8 +187,14 @@ __global__ void compact_flags_kernel(const int32_t* __restrict__ flag, const int
 
 // ---- multi-GPU front: whole precursor windows are the unit dealt to ranks -------------------------------------
 __device__ __forceinline__ int64_t window_of(float mz, double interval, int64_t n_windows) {
-    const double w = floor((double)mz / interval);                      // (the arithmetic of split_flags_kernel)
-    return w >= 0.0 ? (w < (double)(n_windows - 1) ? (int64_t)w : n_windows - 1) : 0;      // (NaN -> 0)
+    // slot of the window floor(mz / interval) (the arithmetic of split_flags_kernel) in the table of n_windows deal units:
+    // windows beyond the table WRAP AROUND (w mod n_windows) instead of collapsing into the last slot -- with a small
+    // mz_interval (0.05 -> the table ends at 819 m/z) a clamp sent most of the dataset to one unit = one rank;
+    // wrapped, a slot holds whole windows w, w + n_windows, ... : still a valid deal unit (buckets never cross a window),
+    // and the load stays spread.  (NaN / negative -> slot 0)
+    const double w = floor((double)mz / interval);
+    if (!(w >= 0.0)) return 0;
+    return w < (double)n_windows ? (int64_t)w : (int64_t)fmod(w, (double)n_windows);
 }
 
 // the partitions of one job (precursor charges) are counted by ONE pair of launches: blockIdx.y = partition

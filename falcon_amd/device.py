@@ -177,7 +177,7 @@ class Context:
               "fal_gather_f32")
         return out
 
-    N_WINDOWS = 1 << 14           # windows the multi-GPU front end counts (m/z < 16,383 x mz_interval; beyond: one shared window)
+    N_WINDOWS = 1 << 14           # deal units the multi-GPU front end counts: window w = floor(mz / mz_interval) -> slot w mod 16,384
 
     def window_counts(self, precursor_mzs, mz_interval: float):
         """spectra per precursor window floor(mz / mz_interval) of every partition of a job (`fal_window_counts`: one pair of
@@ -211,7 +211,7 @@ class Context:
         own = np.full(self.N_WINDOWS, -1, np.int32)
         own[:len(owner)] = owner
         if len(owner):
-            own[len(owner):] = owner[-1]                  # (windows behind the counted ones hold no spectrum)
+            own[len(owner):] = owner[-1]                  # (slots behind the counted ones hold no spectrum)
         own_d = self.to_dev(own, torch.int32)
         rows = self.empty((max(n, 1),), torch.int64)
         mzs = self.empty((max(n, 1),), torch.float32)

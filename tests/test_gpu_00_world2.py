@@ -65,8 +65,9 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, 
 
 
 @pytest.mark.parametrize("scaling,extra", [
-    ("weak", ["--spectra", "150000"]),                   # 2 blocks -> 4 charge partitions, whole partitions per rank
-    ("strong", ["--spectra-total", "300000"]),           # one dataset, window by window
+    # 2 blocks -> 4 charge partitions, whole partitions per rank; then the line's `strong_scaling` leg: one shared dataset
+    ("weak", ["--spectra", "150000", "--spectra-total", "200000"]),
+    ("strong", ["--spectra-total", "300000", "--no-configs"]),           # one dataset, window by window
 ])
 def test_bench_runs_as_a_two_rank_job(scaling, extra):
     """bench.py's own N > 1 control flow (dataset of the scaling mode, the deal, the overlapped exchange, label assembly, max
@@ -79,7 +80,7 @@ def test_bench_runs_as_a_two_rank_job(scaling, extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", FALCON_BENCH_DEVICE="0", FALCON_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--scaling", scaling, "--no-configs", "--no-cpu-baseline"] + extra
+           "--scaling", scaling, "--no-cpu-baseline"] + extra
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
         log, _ = proc.communicate(timeout=900)
@@ -94,3 +95,6 @@ def test_bench_runs_as_a_two_rank_job(scaling, extra):
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["steps"] == 3 and out["value"] > 0
     assert out["unit"] == "spectra/s" and out["roofline"]["frac"] <= 1.0
     assert abs(out["value"] - 300000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert out["rccl"]["ranks"] == 2
+    if scaling == "weak":
+        assert out["strong_scaling"]["value"] > 0 and out["strong_scaling"]["scaling"] == "strong", out["strong_scaling"]

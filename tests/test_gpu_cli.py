@@ -58,6 +58,41 @@ def test_main_mgf_to_csv(tmp_path):
     assert main(args + ["--overwrite"]) == 0
 
 
+def test_config1_10k_mgf_at_eps_010_labels_equal_the_oracle(tmp_path):
+    """BASELINE configs[0] as written -- 10k synthetic MGF spectra, low_dim 400, eps = 0.10 -- through `main()` with the
+    default preprocessing: the CSV's cluster column must EQUAL the oracle's labels (not ARI-close) on the arrays main()
+    clustered (work_dir's per-charge files, whose own parity is test_main_preprocesses_raw_spectra_on_the_device's subject),
+    with the per-charge label offsets of falcon.py:189-193."""
+    from falcon_amd import synth
+    from falcon_amd.falcon import main
+    from falcon_amd.ms_io import ms_io
+    d = synth.generate(10000, seed=5)
+    specs = []
+    for i in range(10000):
+        a, b = d["indptr"][i], d["indptr"][i + 1]
+        specs.append({"identifier": f"scan={i}", "precursor_mz": float(d["precursor_mz"][i]),
+                      "precursor_charge": int(d["precursor_charge"][i]), "retention_time": float(d["retention_time"][i]),
+                      "mz": d["mz"][a:b].astype(np.float64), "intensity": d["intensity"][a:b]})
+    mgf = str(tmp_path / "in.mgf")
+    ms_io.write_spectra(mgf, specs)
+    out, work = str(tmp_path / "res"), tmp_path / "work"
+    assert main([mgf, out, "--eps", "0.1", "--low_dim", "400", "--work_dir", str(work)]) == 0
+    lines = [l for l in open(out + ".csv").read().splitlines() if not l.startswith("#")]
+    table = {r[1]: (int(r[2]), int(r[5])) for r in (l.split(",") for l in lines[1:])}
+    offset, n_seen = 0, 0
+    for charge in (2, 3):
+        z = np.load(work / "spectra" / f"spectra_charge_{charge}.npz")
+        ref, rmed = fo.generate_clusters(z["mz"], z["intensity"], z["indptr"], z["precursor_mz"], z["retention_time"], eps=0.1,
+                                         low_dim=400)
+        got = np.array([table[str(i)][1] for i in z["identifier"]])
+        assert all(table[str(i)][0] == charge for i in z["identifier"][:50])
+        assert np.array_equal(got - offset, ref), (charge, int((got - offset != ref).sum()))
+        offset += len(rmed)
+        n_seen += len(ref)
+        assert (np.bincount(ref) > 1).sum() > 100                      # a real clustering at the config's eps
+    assert n_seen == len(table)
+
+
 def test_main_preprocesses_raw_spectra_on_the_device(tmp_path):
     """raw MGF peaks (outside the m/z window, on the precursor ions, below 1 % of the base peak, > 50 peaks) go
     through `fal_process_spectra` inside main(); what lands in work_dir equals the host `process_spectrum`."""

@@ -212,3 +212,30 @@ def test_bucket_sharded_run_many_equals_single_gpu(ctx):
         nb_idx, nb_dist, order = single_nb[j]
         full = {(int(order[i]), int(order[c]), float(dd)) for i in range(len(order)) for c, dd in zip(nb_idx[i], nb_dist[i]) if c >= 0}
         assert len(seen_edges[j]) > 100 and seen_edges[j] <= full                           # ids are dataset rows
+
+
+def test_small_mz_interval_wraps_windows_instead_of_collapsing_them(ctx):
+    """with mz_interval = 0.05 the 16,384-entry window table ends at 819 m/z; round 3 clamped every precursor
+    beyond it into ONE deal unit (one rank got most of the dataset).  Windows now wrap around the table: the sharded run still
+    equals the single-GPU partition and every one of 3 ranks gets a real share."""
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, SpectrumDataset
+    data = synth.generate(12000, seed=31)                       # precursors 400 .. 1200 m/z: windows up to 24,000
+    c = synth.select_charge(data, 2)
+    ds = SpectrumDataset(c["precursor_mz"], c["retention_time"], c["mz"], c["intensity"], c["indptr"])
+    assert (c["precursor_mz"] / 0.05 > ctx.N_WINDOWS).mean() > 0.3
+    pipe = ClusterPipeline(ctx)
+    p = AnnParams(eps=0.3, mz_interval=0.05)
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, p)
+    ref = pipe.run_many([ds], *args)[0][0].cpu().numpy()
+    merged, off, share = np.full(len(ds), -1, np.int64), 0, []
+    for r in range(3):
+        (lab, med), = pipe.run_many([ds], *args, shard=(r, 3))
+        rows = pipe.lasts[0]["rows"].cpu().numpy()
+        assert (merged[rows] == -1).all()
+        merged[rows] = lab.cpu().numpy() + off
+        off += int(med.numel())
+        share.append(len(rows) / len(ds))
+    assert (merged >= 0).all() and min(share) > 0.2, share
+    pairs = np.unique(np.stack([ref, merged]), axis=1)
+    assert pairs.shape[1] == len(np.unique(ref)) == len(np.unique(merged))
