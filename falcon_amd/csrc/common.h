@@ -63,6 +63,8 @@ struct fal_ctx {
     size_t arena_off = 0;
     int upload(void* dst, const void* src, size_t bytes);
     int num_cus = 256;
+    int persistent_wgs = 256;             // workgroups of the persistent one-per-CU kernels (dense4 / dense_tiny4): num_cus, or a
+                                          // share of them when another context's stream is meant to run beside this one
     bool timing = false;
     // per-stage accumulated event pairs for the LAST call of that stage
     struct StageTimer {

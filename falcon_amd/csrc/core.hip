@@ -173,6 +173,11 @@ int fal_ctx_create(int device, void* stream, int own_stream, fal_ctx** out) {
     fal_ctx* c = new fal_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
+    c->persistent_wgs = c->num_cus;
+    if (const char* e = getenv("FALCON_PERSISTENT_WGS")) {        // experiment switch (NOTES.md round 4: CU shares of two streams)
+        const int v = atoi(e);
+        if (v >= 8 && v <= c->num_cus) c->persistent_wgs = v;
+    }
     if (!own_stream) {
         c->stream = (hipStream_t)stream;
         c->own_stream = false;

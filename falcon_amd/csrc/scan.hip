@@ -467,7 +467,7 @@ int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, con
     const size_t lds = (size_t)2 * 32 * (d * 4 + 16);
     int32_t* cursors = nullptr;
     FAL_TRY(ctx->reserve(SLOT_CURSORS, sizeof(int32_t) * 16, (void**)&cursors));
-    dim3 grid((unsigned)std::min<int64_t>(n_items, ctx->num_cus)), block(256);
+    dim3 grid((unsigned)std::min<int64_t>(n_items, ctx->persistent_wgs)), block(256);
     StageScope ts(ctx, ST_SCAN);
     StageScope tk(ctx, ST_KERNEL);
     FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t) * 8, ctx->stream));
@@ -499,7 +499,7 @@ int launch_dense_tiny4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs
     int32_t* cursors = nullptr;
     FAL_TRY(ctx->reserve(SLOT_CURSORS, sizeof(int32_t) * 16, (void**)&cursors));
     cursors += 8;                                            // (the first eight are dense4_kernel's, possibly still in use)
-    dim3 grid((unsigned)std::min<int64_t>(ceil_div(n_jobs, 4), ctx->num_cus)), block(256);
+    dim3 grid((unsigned)std::min<int64_t>(ceil_div(n_jobs, 4), ctx->persistent_wgs)), block(256);
     StageScope ts(ctx, ST_SCAN);                             // (not ST_KERNEL: that stage times the dominant kernel alone)
     FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t), ctx->stream));
 #define FAL_LAUNCH_TINY4(DH4)                                                                                       \
