@@ -30,6 +30,7 @@ def asm_dir(tmp_path_factory):
     ("scan.hip", "dense_tiny4_kernel", 4),
     ("scan16.hip", "scan16_kernel", 10),
     ("ivf_fine.hip", "ivf_list4_kernel", 5),
+    ("ivf16.hip", "list16_kernel", 5),
     ("assign.hip", "assign_kernel", 5),
     ("assign.hip", "assign_wave_kernel", 5),
 ])
@@ -118,9 +119,11 @@ def test_dense4_vm_operation_counts_match_the_hand_counted_waits(asm_dir, dh4, p
 
 @pytest.mark.parametrize("steps,row_ops", [(4, 8), (8, 8), (16, 8), (25, 8), (50, 16)])
 def test_list16_vm_operation_counts_match_the_hand_counted_waits(asm_dir, steps, row_ops):
-    """ivf16.hip: per step and wave kRowOps row DMAs + 1 metadata DMA and 16 key stores; FAL_STEP's allowance is built
-    from exactly these."""
-    body = next(b for k, b in L.kernels(L.compile_to_asm("ivf16.hip", asm_dir)).items() if f"list16_kernelILi{steps}E" in k)
+    """ivf16.hip: per step and wave kRowOps row DMAs + 1 metadata DMA and 16 key stores; the steps' vmcnt allowances are built
+    from exactly these (and a spill would add scratch loads behind them: none allowed)."""
+    asm = L.compile_to_asm("ivf16.hip", asm_dir)
+    name, body = next((k, b) for k, b in L.kernels(asm).items() if f"list16_kernelILi{steps}E" in k)
+    assert L.kernel_meta(asm, "private_segment_fixed_size")[name] == 0, "list16_kernel spills: scratch loads are VM operations too"
     runs = [r for r in L.vm_ops_between_barriers(body) if r[2] > 0]
     assert runs, "no MFMA stretch found"
     for dma, stores, mfma in runs:
