@@ -45,16 +45,12 @@ _SIGNATURES = {
                             c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p], c_int),
     "fal_vectorize_f16_image": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                  c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p], c_int),
-    "fal_vectorize_indexed": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
-                               c_uint32, c_uint32, c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p], c_int),
     "fal_window_counts": ([c_void_p, c_void_p, c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p], c_int),
     "fal_window_select": ([c_void_p, c_void_p, c_int64, c_double, c_int64, c_void_p, c_int, c_void_p, c_void_p, P(c_int64)], c_int),
     "fal_precursor_splits": ([c_void_p, c_void_p, c_int64, c_double, c_int, c_int64, c_double, c_int,
                               c_void_p, c_int64, P(c_int64)], c_int),
     "fal_ivf_build": ([c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, P(c_void_p)], c_int),
     "fal_ivf_build_x16": ([c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, P(c_void_p)], c_int),
-    "fal_ivf_build_sparse": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64,
-                              c_void_p, c_int, P(c_void_p)], c_int),
     "fal_ivf_attach_f16": ([c_void_p, c_void_p, c_int], c_int),
     "fal_ivf_attach_prefilter": ([c_void_p, c_void_p], c_int),
     "fal_ivf_attach_prefilter_ex": ([c_void_p, c_void_p, c_int], c_int),

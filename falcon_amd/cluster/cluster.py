@@ -211,16 +211,12 @@ class ClusterPipeline:
         all_flat = bool((n_list == 1).all())
         vec = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
                                      p.hash_seed, True, dt)
-        X = X16 = Xpre = Xkm = sparse = None
+        X = X16 = Xpre = Xkm = None
         which = 0
-        # with an index the vectoriser also leaves the rows' sparse form (k-means update, exact pair chains): one pass over the
-        # peaks instead of the build's second pass over 4 low_dim bytes per row (fal_vectorize_indexed / fal_ivf_build_sparse)
-        vec_sp = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
-                                        p.hash_seed, True, dt, sparse=True)
         if p.dtype == "f16" and not all_flat:
             # float16 vectors with an index: the exact kernels (k-means close calls, coarse quantiser, pair chains) work on the
             # float32 image of the rounded rows, the float16 rows themselves are every prefilter copy AND the flat buckets' scan
-            X, X16, sparse = vec_sp("f16+image")
+            X, X16 = vec("f16+image")
             Xkm = X16 if p.kmeans_prefilter else None
             if p.ivf_prefilter and not keep_intermediates:
                 which, Xpre = 2, X16
@@ -237,18 +233,13 @@ class ClusterPipeline:
             if p.ivf_prefilter and not keep_intermediates and ok16 and bool((n_list > 1).any()):
                 which |= 2
             want_km = p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 512)).any())
-            if (want_km or which) and not all_flat:
-                X, x16, sparse = vec_sp("f32+f16")     # ... and the float16 rounding of the same rows + their sparse form
-                Xkm = x16 if want_km else None
-                Xpre = x16 if which else None
-            elif want_km or which:
+            if want_km or which:
                 X, x16 = vec("f32+f16")            # the float16 rounding of the same rows, from the same pass over the peaks
                 Xkm = x16 if want_km else None
                 Xpre = x16 if which else None
             else:
                 X = vec("f32")
-        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre, Xkm=Xkm, prefilter_which=max(which, 1),
-                            sparse=sparse)
+        index = c.ivf_build(X, splits, n_list, p.kmeans_iters, X16=X16, Xpre=Xpre, Xkm=Xkm, prefilter_which=max(which, 1))
         if keep_intermediates:
             sim, idx = index.search(p.n_probe, p.n_neighbors_ann)
             nb_idx, nb_dist = c.filter_neighbors(sim, idx, mzs, rts, precursor_tol_mass, precursor_tol_mode, rt_tol,

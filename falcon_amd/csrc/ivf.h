@@ -57,7 +57,6 @@ struct fal_ivf {
     // column 0xFFFF = unused entry, 0xFFFE in entry 0 = more than 64 non-zeros, use the dense row); owned
     uint16_t* sp_cols = nullptr;
     float* sp_vals = nullptr;
-    bool sp_borrowed = false;        // the caller's arrays (fal_ivf_build_sparse: made by fal_vectorize_indexed), not the pool's
     int64_t* list_off = nullptr;     // [total_lists + 1] list-order positions
     int64_t* counts = nullptr;       // [total_lists + 1] list sizes (flat buckets)
     void* bk_dev = nullptr;          // BucketDev[n_ivf_buckets]

@@ -312,8 +312,7 @@ int fal_ivf_destroy(fal_ivf* ivf) {
     fal::CallScope _call(ivf ? ivf->ctx : nullptr);
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
-                    ivf->pos_of_row, ivf->ckeys, ivf->sp_borrowed ? nullptr : ivf->sp_cols, ivf->sp_borrowed ? nullptr : ivf->sp_vals,
-                    ivf->neg_dev};
+                    ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals, ivf->neg_dev};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -388,27 +387,9 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim, const in
     return fal_ivf_build_x16(ctx, X, nullptr, n, low_dim, bucket_off, n_buckets, n_list, kmeans_iters, out);
 }
 
-static int ivf_build_impl(fal_ctx* ctx, const float* X, const void* X16, const uint16_t* sp_cols_in, const float* sp_vals_in,
-                          const int32_t* sp_flags_in, int64_t n, int low_dim, const int64_t* bucket_off, int64_t n_buckets,
-                          const int32_t* n_list, int kmeans_iters, fal_ivf** out);
-
 int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, int low_dim, const int64_t* bucket_off,
                       int64_t n_buckets, const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
     fal::CallScope _call(ctx);
-    return ivf_build_impl(ctx, X, X16, nullptr, nullptr, nullptr, n, low_dim, bucket_off, n_buckets, n_list, kmeans_iters, out);
-}
-
-int fal_ivf_build_sparse(fal_ctx* ctx, const float* X, const void* X16, const uint16_t* sp_cols, const float* sp_vals,
-                         const int32_t* sp_flags, int64_t n, int low_dim, const int64_t* bucket_off, int64_t n_buckets,
-                         const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
-    fal::CallScope _call(ctx);
-    FAL_REQUIRE(n == 0 || (sp_cols && sp_vals && sp_flags), FAL_EINVAL, "fal_ivf_build_sparse: NULL sparse arrays");
-    return ivf_build_impl(ctx, X, X16, sp_cols, sp_vals, sp_flags, n, low_dim, bucket_off, n_buckets, n_list, kmeans_iters, out);
-}
-
-static int ivf_build_impl(fal_ctx* ctx, const float* X, const void* X16, const uint16_t* sp_cols_in, const float* sp_vals_in,
-                          const int32_t* sp_flags_in, int64_t n, int low_dim, const int64_t* bucket_off, int64_t n_buckets,
-                          const int32_t* n_list, int kmeans_iters, fal_ivf** out) {
     FAL_REQUIRE(ctx && out, FAL_EINVAL, "fal_ivf_build: NULL ctx/out");
     *out = nullptr;
     FAL_REQUIRE(n >= 0 && n < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "fal_ivf_build: n must be < 2^31 per partition");
@@ -526,14 +507,8 @@ static int ivf_build_impl(fal_ctx* ctx, const float* X, const void* X16, const u
             B_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * tab.size(), (void**)&boff_dev));
             B_TRY(ctx->upload(boff_dev, tab.data(), sizeof(int64_t) * tab.size()));
             lbase_dev = boff_dev + n_buckets + 1;
-            if (sp_cols_in) {                    // made by the vectoriser (fal_vectorize_indexed): borrowed, like X
-                ivf->sp_cols = const_cast<uint16_t*>(sp_cols_in);
-                ivf->sp_vals = const_cast<float*>(sp_vals_in);
-                ivf->sp_borrowed = true;
-            } else {
-                B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, (void**)&ivf->sp_cols));
-                B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&ivf->sp_vals));
-            }
+            B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * kSparseW, (void**)&ivf->sp_cols));
+            B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&ivf->sp_vals));
             sp_cols = ivf->sp_cols;
             sp_vals = ivf->sp_vals;
             B_TRY(ctx->reserve(SLOT_SORT2, 3 * sizeof(uint32_t) * (size_t)n, &sortbuf));
@@ -542,13 +517,9 @@ static int ivf_build_impl(fal_ctx* ctx, const float* X, const void* X16, const u
             iota = (int32_t*)(key_out + n);
             {
                 StageScope ts(ctx, ST_BUILD);
-                if (sp_cols_in) {
-                    B_HIP(hipMemcpyAsync(neg_dev, sp_flags_in, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-                } else {
-                    hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
-                                       nbk, sp_cols, sp_vals, neg_dev);
-                    B_HIP(hipGetLastError());
-                }
+                hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
+                                   nbk, sp_cols, sp_vals, neg_dev);
+                B_HIP(hipGetLastError());
                 hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, st, iota, n);
                 B_HIP(hipGetLastError());
             }

@@ -18,7 +18,6 @@
 #include <hip/hip_fp16.h>
 #include "common.h"
 #include "hash.h"
-#include "ivf.h"
 
 namespace {
 
@@ -44,16 +43,12 @@ template <int OUT_F16>
 __global__ __launch_bounds__(64) void vectorize_kernel(
     const float* __restrict__ mz, const float* __restrict__ inten, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out, void* __restrict__ out2,
-    uint16_t* __restrict__ sp_cols, float* __restrict__ sp_vals, int32_t* __restrict__ sp_flags) {
+    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out, void* __restrict__ out2) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t passes = (d + 255) / 256;
     float* acc = reinterpret_cast<float*>(smem);                 // passes*256 floats
     uint32_t* tag = reinterpret_cast<uint32_t*>(acc + passes * 256);  // d entries
-    __shared__ uint16_t sc[fal::kSparseW];                       // the row's sparse form (OUT_F16 >= 3 with sp_cols)
-    __shared__ float sv[fal::kSparseW];
     const uint32_t lane = threadIdx.x;
-    bool neg = false;
 
     for (uint32_t i = lane; i < passes * 256; i += 64) acc[i] = 0.f;
     for (uint32_t i = lane; i < d; i += 64) tag[i] = 0xFFFFFFFFu;
@@ -138,66 +133,13 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
                     *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(OUT_F16 >= 3 ? out2 : out) + r * (int64_t)d + e) = pk;
                     if (OUT_F16 == 4) o = make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
                     if (OUT_F16 >= 3) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
-                    if (OUT_F16 >= 3 && sp_cols) *reinterpret_cast<float4*>(&acc[e]) = o;     // (the float32 row, for the sparse form)
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + r * (int64_t)d + e) = o;
                 }
             }
         }
-        if (OUT_F16 >= 3 && sp_cols) {
-            // The row's sparse form, what the index build's sparsify_rows_kernel would make of the float32 row just written
-            // (ivf.hip: <= 64 (column, value) entries in the order of the exact similarity chains -- column 0, d/2, 1, d/2 + 1,
-            // ... --, 0xFFFF = unused entry, 0xFFFE in entry 0 = more than 64 non-zeros: read the dense row), made here from the
-            // row in LDS instead of by a second pass over 4 d bytes per row of HBM.
-            __syncthreads();
-            sc[lane] = fal::kColPad;
-            sv[lane] = 0.f;
-            const float4* row = reinterpret_cast<const float4*>(acc);
-            const int dh4 = (int)(d >> 3);
-            int base = 0;
-            for (int e0 = 0; e0 < dh4; e0 += 64) {
-                const int e = e0 + (int)lane;
-                const float4 lo = e < dh4 ? row[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 hi = e < dh4 ? row[dh4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float xs[8] = {lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lo.w, hi.w};
-                int c = 0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    c += (int)(xs[j] != 0.f);
-                    neg |= !(xs[j] >= 0.f) || xs[j] > 65504.f;
-                }
-                int pre = c;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int y = __shfl_up(pre, off, 64);
-                    if ((int)lane >= off) pre += y;
-                }
-                const int tot = __shfl(pre, 63, 64);
-                __syncthreads();
-                if (base + tot <= fal::kSparseW) {
-                    int pos = base + pre - c;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (xs[j] != 0.f) {
-                            sc[pos] = (uint16_t)((j & 1) * (d >> 1) + 4 * e + (j >> 1));
-                            sv[pos] = xs[j];
-                            ++pos;
-                        }
-                }
-                base += tot;
-            }
-            __syncthreads();
-            if (base > fal::kSparseW && lane == 0) sc[0] = fal::kColDense;
-            __syncthreads();
-            sp_cols[r * fal::kSparseW + lane] = sc[lane];
-            sp_vals[r * fal::kSparseW + lane] = sv[lane];
-#pragma unroll
-            for (int p = 0; p < kMaxPasses; ++p)
-                if ((uint32_t)p < passes) *reinterpret_cast<float4*>(&acc[256 * p + 4 * lane]) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         __syncthreads();
     }
-    if (OUT_F16 >= 3 && sp_flags && __ballot(neg) != 0ull && lane == 0) atomicOr(sp_flags, 1);
 }
 
 __global__ void to_vector_indices_kernel(const float* __restrict__ mz, int64_t nnz, double min_mz,
@@ -225,8 +167,7 @@ int fal_to_vector_indices(fal_ctx* ctx, const float* mz, int64_t nnz, double min
 
 static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                           const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2,
-                          uint16_t* sp_cols = nullptr, float* sp_vals = nullptr, int32_t* sp_flags = nullptr);
+                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2);
 
 int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                   const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
@@ -256,21 +197,9 @@ int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensit
                           out_f32_image, out_f16);
 }
 
-int fal_vectorize_indexed(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
-                          const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-                          uint32_t low_dim, uint32_t seed, int normalize, int f16_vectors, float* out_f32, void* out_f16,
-                          uint16_t* sp_cols, float* sp_vals, int32_t* sp_flags) {
-    fal::CallScope _call(ctx);
-    FAL_REQUIRE(n == 0 || (out_f16 && out_f32 && sp_cols && sp_vals && sp_flags), FAL_EINVAL, "fal_vectorize_indexed: NULL array");
-    if (ctx && n > 0) FAL_CHECK_HIP(hipMemsetAsync(sp_flags, 0, sizeof(int32_t) * 2, ctx->stream));
-    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize,
-                          f16_vectors ? -4 : -3, out_f32, out_f16, sp_cols, sp_vals, sp_flags);
-}
-
 static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                           const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2,
-                          uint16_t* sp_cols, float* sp_vals, int32_t* sp_flags) {
+                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2) {
     FAL_REQUIRE(ctx, FAL_EINVAL, "fal_vectorize: NULL ctx");
     FAL_REQUIRE(n >= 0 && bin_size > 0 && n_bins > 0, FAL_EINVAL, "fal_vectorize: bad sizes");
     FAL_REQUIRE(low_dim >= 8 && low_dim <= FAL_MAX_LOW_DIM && low_dim % 8 == 0, FAL_EUNSUPPORTED,
@@ -285,19 +214,19 @@ static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity,
         fal::StageScope t(ctx, fal::ST_VECTORIZE);
         if (out_dtype == -4)
             hipLaunchKernelGGL(vectorize_kernel<4>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, sp_cols, sp_vals, sp_flags);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
         else if (out_dtype == -3)
             hipLaunchKernelGGL(vectorize_kernel<3>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, sp_cols, sp_vals, sp_flags);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
         else if (out_dtype == FAL_DTYPE_SPLIT16)
             hipLaunchKernelGGL(vectorize_kernel<2>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, sp_cols, sp_vals, sp_flags);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
         else if (out_dtype == FAL_DTYPE_F16)
             hipLaunchKernelGGL(vectorize_kernel<1>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, sp_cols, sp_vals, sp_flags);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
         else
             hipLaunchKernelGGL(vectorize_kernel<0>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, sp_cols, sp_vals, sp_flags);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
     }
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;

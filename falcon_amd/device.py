@@ -91,9 +91,7 @@ class Context:
         return out
 
     def vectorize(self, mz, intensity, indptr, row_order, min_mz: float, bin_size: float, n_bins: int,
-                  low_dim: int, seed: int = 0, normalize: bool = True, dtype: str = "f32", sparse: bool = False):
-        """`sparse` (with dtype "f32+f16" / "f16+image"): also the rows' sparse form for `ivf_build(sparse=...)`
-        (`fal_vectorize_indexed`) -> (out, out16, (sp_cols u16[n, 64], sp_vals f32[n, 64], sp_flags i32[2]))"""
+                  low_dim: int, seed: int = 0, normalize: bool = True, dtype: str = "f32"):
         torch = _torch()
         mz = self.to_dev(mz, torch.float32)
         intensity = self.to_dev(intensity, torch.float32)
@@ -107,13 +105,6 @@ class Context:
             # one pass over the peaks, two outputs: float32 rows and their float16 rounding ("f16+image": float16 VECTORS --
             # the float32 output is the image of the rounded values, fal_vectorize_f16_image)
             out, out16 = self.empty((n, low_dim), torch.float32), self.empty((n, low_dim), torch.float16)
-            if sparse:
-                sp = (self.empty((n, 64), torch.int16), self.empty((n, 64), torch.float32), self.empty((2,), torch.int32))
-                check(self.lib.fal_vectorize_indexed(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
-                                                     n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
-                                                     int(normalize), int(dtype == "f16+image"), self._p(out), self._p(out16),
-                                                     self._p(sp[0]), self._p(sp[1]), self._p(sp[2])), "fal_vectorize_indexed")
-                return out, out16, sp
             fn = self.lib.fal_vectorize_pair if dtype == "f32+f16" else self.lib.fal_vectorize_f16_image
             check(fn(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
                                               n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
@@ -132,13 +123,12 @@ class Context:
 
     # ------------------------------------------------------------------ a6 / a7
     def ivf_build(self, X, bucket_off: np.ndarray, n_list: np.ndarray, kmeans_iters: int = 10,
-                  X16=None, Xpre=None, Xkm=None, prefilter_which: int = 1, sparse=None) -> "IvfIndex":
+                  X16=None, Xpre=None, Xkm=None, prefilter_which: int = 1) -> "IvfIndex":
         """X: float32 [n, d] (may be None when every bucket is flat and X16 is given);
         X16: optional float16 [n, d] (plain rows) or [n, 2, d] (hi/lo split) for the f16 flat scan;
         Xpre: optional float16 [n, d] copy of X used only as the prefilter of `search_neighbors` (exact results);
         prefilter_which: where Xpre is used: 1 = flat buckets (fused.hip), 2 = buckets with an index (ivf16.hip), 3 = both;
-        Xkm: optional float16 [n, d] copy of X used as the prefilter of the k-means assignment (identical index);
-        sparse: optional (sp_cols, sp_vals, sp_flags) of `vectorize(..., sparse=True)`: the build skips its own pass over X."""
+        Xkm: optional float16 [n, d] copy of X used as the prefilter of the k-means assignment (identical index)."""
         torch = _torch()
         if X is not None:
             assert X.dtype == torch.float32 and X.is_contiguous() and X.device == self.tdev
@@ -151,16 +141,9 @@ class Context:
         h = C.c_void_p()
         if Xkm is not None:
             assert Xkm.dtype == torch.float16 and Xkm.is_contiguous() and Xkm.device == self.tdev and tuple(Xkm.shape) == (n, d)
-        if sparse is not None:
-            assert tuple(sparse[0].shape) == (n, 64) and tuple(sparse[1].shape) == (n, 64) and X is not None
-            check(self.lib.fal_ivf_build_sparse(self._h, self._p(X), self._p(Xkm), self._p(sparse[0]), self._p(sparse[1]),
-                                                self._p(sparse[2]), n, d, bo.ctypes.data_as(C.c_void_p), len(nl),
-                                                nl.ctypes.data_as(C.c_void_p), int(kmeans_iters), C.byref(h)), "fal_ivf_build_sparse")
-        else:
-            check(self.lib.fal_ivf_build_x16(self._h, self._p(X), self._p(Xkm), n, d, bo.ctypes.data_as(C.c_void_p), len(nl),
-                                             nl.ctypes.data_as(C.c_void_p), int(kmeans_iters), C.byref(h)), "fal_ivf_build")
+        check(self.lib.fal_ivf_build_x16(self._h, self._p(X), self._p(Xkm), n, d, bo.ctypes.data_as(C.c_void_p), len(nl),
+                                         nl.ctypes.data_as(C.c_void_p), int(kmeans_iters), C.byref(h)), "fal_ivf_build")
         index = IvfIndex(self, h, X, bo, nl, n, d)
-        index.sparse = sparse                     # (borrowed by the index: kept alive with it)
         index.Xkm = Xkm
         if X16 is not None:
             assert X16.dtype == torch.float16 and X16.is_contiguous() and X16.device == self.tdev

@@ -118,17 +118,6 @@ int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, co
 int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                             const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                             uint32_t low_dim, uint32_t seed, int normalize, float* out_f32_image, void* out_f16);
-/* Everything an index over these rows reads, from ONE pass over the peaks: fal_vectorize_pair's outputs (f16_vectors = 0) or
- * fal_vectorize_f16_image's (f16_vectors = 1), plus the rows' SPARSE form for fal_ivf_build_sparse -- sp_cols u16[n, 64] /
- * sp_vals f32[n, 64]: the non-zero components of out_f32's row in the order of the exact similarity chains (column 0,
- * low_dim / 2, 1, low_dim / 2 + 1, ...; 0xFFFF = unused entry; 0xFFFE in entry 0 = more than 64 non-zeros, read the dense
- * row) -- and sp_flags i32[2]: [0] = 1 if any component is negative or not finite (the float16 prefilters' precondition,
- * see fal_ivf_build_x16).  Without it the index build makes the sparse form itself by re-reading 4 low_dim bytes per row.
- * (README.md:124-131 hashing; the sparse form is this library's) [dev] */
-int fal_vectorize_indexed(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
-                          const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-                          uint32_t low_dim, uint32_t seed, int normalize, int f16_vectors, float* out_f32, void* out_f16,
-                          uint16_t* sp_cols, float* sp_vals, int32_t* sp_flags);
 
 /* ---- a5  precursor-m/z bucket boundaries: reference cluster.py:159-209
  *          `_get_precursor_mz_splits` over the m/z-SORTED float32 precursor array,
@@ -178,11 +167,6 @@ int fal_ivf_build(fal_ctx* ctx, const float* X, int64_t n, int low_dim,
 int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, int low_dim,
                       const int64_t* bucket_off, int64_t n_buckets, const int32_t* n_list,
                       int kmeans_iters, fal_ivf** out);
-/* fal_ivf_build_x16 with the rows' sparse form handed in (fal_vectorize_indexed's sp_cols / sp_vals / sp_flags, borrowed like
- * X: they must outlive the index): the build skips its own pass over the float32 rows.  Identical index. */
-int fal_ivf_build_sparse(fal_ctx* ctx, const float* X, const void* X16, const uint16_t* sp_cols, const float* sp_vals,
-                         const int32_t* sp_flags, int64_t n, int low_dim, const int64_t* bucket_off, int64_t n_buckets,
-                         const int32_t* n_list, int kmeans_iters, fal_ivf** out);
 /* Optional: float16 copies of the vectors, [n, planes, low_dim] in the same (sorted) row order, that
  * the FLAT buckets are then scanned with on the f16 matrix cores: planes = 1 plain float16 rows
  * (fal_vectorize FAL_DTYPE_F16; BASELINE config 5), planes = 2 the hi/lo split of the float32

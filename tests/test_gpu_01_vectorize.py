@@ -87,60 +87,6 @@ def test_vectorize_pair_equals_the_two_single_outputs(ctx, low_dim):
     assert torch.equal(a32.view(torch.int32), b32.view(torch.int32)) and torch.equal(a16.view(torch.int16), b16.view(torch.int16))
 
 
-def sparse_form(X):
-    """numpy statement of the rows' sparse form (ivf.hip / vectorize.hip): the non-zero components in the order of the exact
-    similarity chains -- column 0, d/2, 1, d/2 + 1, ... --, 64 entries per row (0xFFFF = unused), 0xFFFE in entry 0 when
-    the row has more than 64 non-zeros (entries then unspecified beyond what fitted)"""
-    n, d = X.shape
-    chain = np.empty(d, np.int64)
-    chain[0::2] = np.arange(d // 2)
-    chain[1::2] = d // 2 + np.arange(d // 2)
-    cols = np.full((n, 64), 0xFFFF, np.uint16)
-    vals = np.zeros((n, 64), np.float32)
-    dense = np.zeros(n, bool)
-    for i in range(n):
-        c = chain[X[i, chain] != 0]
-        if len(c) > 64:
-            dense[i] = True
-            continue
-        cols[i, :len(c)] = c
-        vals[i, :len(c)] = X[i, c]
-    return cols, vals, dense
-
-
-@pytest.mark.parametrize("low_dim,dtype", [(400, "f32+f16"), (64, "f32+f16"), (128, "f32+f16"), (800, "f16+image")])
-def test_vectorize_indexed_leaves_the_rows_sparse_form(ctx, low_dim, dtype):
-    """`fal_vectorize_indexed`: the same two outputs as the pair / image call, plus the sparse form the index build would make
-    of the float32 rows -- entries in chain order, wide rows flagged, the sign flag clear (and set by a negative intensity)"""
-    import torch
-    from falcon_amd import synth
-    d = synth.generate(2000, seed=9)
-    rng = np.random.default_rng(3)
-    extra_mz = [np.zeros(0, np.float32), np.sort(rng.uniform(101, 1500, 150)).astype(np.float32),      # empty; > 64 non-zeros
-                np.sort(rng.uniform(101, 1500, 66)).astype(np.float32), np.full(40, 500.02, np.float32)]
-    mz = np.concatenate([d["mz"]] + extra_mz)
-    it = np.concatenate([d["intensity"]] + [rng.lognormal(0, 1, len(x)).astype(np.float32) for x in extra_mz])
-    indptr = np.concatenate([d["indptr"], d["indptr"][-1] + np.cumsum([len(x) for x in extra_mz])])
-    n = len(indptr) - 1
-    order = torch.from_numpy(rng.permutation(n).astype(np.int64))
-    _, start, _ = fo.get_dim(101, 1500, 0.05)
-    args = (mz, it, indptr, order, start, 0.05, 27982, low_dim, 0, True)
-    a32, a16 = ctx.vectorize(*args, dtype)
-    b32, b16, (cols, vals, flags) = ctx.vectorize(*args, dtype, sparse=True)
-    assert torch.equal(a32.view(torch.int32), b32.view(torch.int32)) and torch.equal(a16.view(torch.int16), b16.view(torch.int16))
-    X = b32.cpu().numpy()
-    ecols, evals, edense = sparse_form(X)
-    gcols, gvals = cols.cpu().numpy().view(np.uint16), vals.cpu().numpy()
-    assert edense.sum() >= 1 and (gcols[edense, 0] == 0xFFFE).all()
-    assert np.array_equal(gcols[~edense], ecols[~edense])
-    assert np.array_equal(gvals[~edense].view(np.uint32), evals[~edense].view(np.uint32))
-    assert flags.cpu().numpy()[0] == 0
-    it2 = it.copy()
-    it2[5] = -abs(it2[5]) - 1.0                                       # a negative intensity: a negative component
-    *_, (_, _, flags2) = ctx.vectorize(mz, it2, indptr, order, start, 0.05, 27982, low_dim, 0, True, dtype, sparse=True)
-    assert flags2.cpu().numpy()[0] == 1
-
-
 def test_host_helpers(ref_golden):
     from falcon_amd.device import get_dim, hash_lookup
     g = ref_golden

@@ -292,34 +292,3 @@ def test_flat_scan_random_bucket_mixes(ctx):
         for a, b in zip(off[:-1], off[1:]):
             rs, ri = fo.exhaustive_topk(X[a:b], k, base=a)
             assert_topk_exact(sim[a:b], idx[a:b], rs, ri, what=f"case {case} d {d} bucket {a}:{b}")
-
-
-@pytest.mark.parametrize("dtype,low_dim", [("f32+f16", 400), ("f16+image", 800)])
-def test_index_built_from_the_vectorisers_sparse_rows_is_identical(ctx, dtype, low_dim):
-    """`fal_ivf_build_sparse` (the rows' sparse form handed over by `fal_vectorize_indexed`) == `fal_ivf_build_x16` (the build's
-    own pass over the float32 rows): every array of the index and the production search, bit for bit -- on spectra, with a
-    spectrum of more than 64 peaks (dense flag) and empty ones in an indexed bucket"""
-    import torch
-    from falcon_amd import synth
-    from oracle import falcon_oracle as fo
-    d = synth.select_charge(synth.generate(9000, seed=13, mz_lo=500.0, mz_hi=501.5), 2)
-    rng = np.random.default_rng(5)
-    wide = np.sort(rng.uniform(101, 1500, 120)).astype(np.float32)
-    mz = np.concatenate([d["mz"], wide])
-    it = np.concatenate([d["intensity"], rng.lognormal(0, 1, 120).astype(np.float32)])
-    indptr = np.concatenate([d["indptr"], [d["indptr"][-1] + 120, d["indptr"][-1] + 120]])     # + a wide and an empty spectrum
-    n = len(indptr) - 1
-    _, start, _ = fo.get_dim(101, 1500, 0.05)
-    X, X16, sp = ctx.vectorize(mz, it, indptr, None, start, 0.05, 27982, low_dim, 0, True, dtype, sparse=True)
-    off = np.array([0, n // 2, n], np.int64)
-    nl = np.array([64, 32], np.int32)
-    pmz = torch.from_numpy(np.sort(rng.uniform(500, 501, n)).astype(np.float32)).to(ctx.tdev)
-    kw = dict(kmeans_iters=4, Xkm=X16, Xpre=X16, prefilter_which=2)
-    a = ctx.ivf_build(X, off, nl, **kw)
-    b = ctx.ivf_build(X, off, nl, sparse=sp, **kw)
-    for name, x, y in zip(("centroids", "assign", "perm", "list_off"), a.export(), b.export()):
-        assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y), name
-    ra = a.search_neighbors(8, 128, pmz, None, 20.0, "ppm", None, 64)
-    rb = b.search_neighbors(8, 128, pmz, None, 20.0, "ppm", None, 64)
-    assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1].view(torch.int32), rb[1].view(torch.int32))
-    assert int((ra[0] >= 0).sum()) > n
