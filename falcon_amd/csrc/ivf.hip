@@ -149,6 +149,84 @@ __global__ void list_bounds_kernel(const uint32_t* __restrict__ keys_sorted, int
     }
 }
 
+// Stable sort of an IVF bucket's rows by list, one wave per bucket: what the k-means passes need after every assignment (the
+// members of a list in row order).  A global radix sort of all n (list, row) pairs -- rocPRIM, 3 + 2 kernels per call, 11 calls
+// per build -- does the same; here a bucket's rows are counted (LDS histogram of its <= kBucketSortMaxLists lists), the list
+// offsets follow from a wave scan, and the rows are placed chunk by chunk IN ORDER: lanes with the same list find each other
+// with one ballot per list-id bit, rank = earlier peers in the chunk, base = the list's running cursor in LDS.  Identical output
+// (perm, list_off of the bucket's lists); flat buckets keep what the first, global sort of the build wrote.
+constexpr int kBucketSortMaxLists = 2048;
+
+__global__ __launch_bounds__(64) void bucket_list_sort_kernel(const int32_t* __restrict__ assign, const BucketDev* __restrict__ bk, int nb,
+                                                              int32_t* __restrict__ perm, int64_t* __restrict__ list_off) {
+    __shared__ uint32_t cur[kBucketSortMaxLists];
+    if ((int)blockIdx.x >= nb) return;
+    const BucketDev b = bk[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int nl = b.n_list;
+    for (int l = lane; l < nl; l += 64) cur[l] = 0u;
+    wave_lds_sync();
+    constexpr int U = 8;                                    // chunks whose ids are fetched together (the loop is one wave's
+    const int32_t* ids = assign + b.row0;                   //  chain of dependent steps: latency, not bytes)
+    for (int i0 = 0; i0 < b.n; i0 += 64 * U) {
+        int id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 64 * u + lane;
+            id[u] = i < b.n ? ids[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (id[u] >= 0) atomicAdd(&cur[id[u]], 1u);
+    }
+    wave_lds_sync();
+    // exclusive prefix over the lists (64 at a time): cur[l] = first position of list l inside the bucket
+    uint32_t carry = 0u;
+    for (int l0 = 0; l0 < nl; l0 += 64) {
+        const int l = l0 + lane;
+        const uint32_t c = l < nl ? cur[l] : 0u;
+        uint32_t pre = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(pre, off, 64);
+            if (lane >= off) pre += y;
+        }
+        const uint32_t tot = __shfl(pre, 63, 64);
+        if (l < nl) {
+            cur[l] = carry + pre - c;
+            list_off[b.list0 + l] = b.row0 + (int64_t)(carry + pre - c);
+        }
+        carry += tot;
+    }
+    wave_lds_sync();
+    int bits = 1;
+    while ((1 << bits) < nl) ++bits;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int i0 = 0; i0 < b.n; i0 += 64 * U) {
+        int id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 64 * u + lane;
+            id[u] = i < b.n ? ids[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool live = id[u] >= 0;
+            if (__ballot(live) == 0ull) break;
+            unsigned long long peers = __ballot(live);
+            for (int t = 0; t < bits; ++t) {
+                const unsigned long long m = __ballot(live && ((id[u] >> t) & 1));
+                peers &= ((id[u] >> t) & 1) ? m : ~m;
+            }
+            const uint32_t base = live ? cur[id[u]] : 0u;                 // every peer reads the cursor before ...
+            wave_lds_sync();
+            if (live && (peers & lt) == 0ull) cur[id[u]] = base + (uint32_t)__popcll(peers);      // ... the first of them advances it
+            wave_lds_sync();
+            if (live) perm[b.row0 + base + __popcll(peers & lt)] = (int32_t)(b.row0 + i0 + 64 * u + lane);
+        }
+    }
+}
+
 // update: one wave per (bucket, list); the members (sorted rows, in row order) are added one after the other into the wave's
 // LDS accumulators, eight members' entries in flight.  Normalisation: the fixed-order float64 tree of the vectorise kernel.  Empty lists keep their centroid.
 __global__ __launch_bounds__(64) void centroid_update_kernel(const uint16_t* __restrict__ cols, const float* __restrict__ vals,
@@ -619,6 +697,19 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             FAL_CHECK_HIP(hipGetLastError());
             return FAL_OK;
         };
+        // after the first (global) sort every later one only re-orders the rows inside the IVF buckets: one wave per bucket
+        int max_nl_all = 0;
+        for (const BucketDev& b : bk) max_nl_all = std::max(max_nl_all, (int)b.n_list);
+        bool sorted_once = false;
+        auto sort_buckets = [&]() -> int {
+            if (!sorted_once || max_nl_all > kBucketSortMaxLists) {
+                sorted_once = true;
+                return sort_by_list();
+            }
+            hipLaunchKernelGGL(bucket_list_sort_kernel, dim3((unsigned)nbk), dim3(64), 0, st, ivf->assign, bkd, nbk, ivf->perm, ivf->list_off);
+            FAL_CHECK_HIP(hipGetLastError());
+            return FAL_OK;
+        };
         for (int it = 0; it <= kmeans_iters; ++it) {
             if (!hjobs.empty()) {
                 {
@@ -642,13 +733,13 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 B_TRY(launch_assign(ctx, ST_BUILD, X, ivf->centroids, low_dim, ajobs_dev, n_wide, n_wave, n, keys, ivf->assign));
             if (it == kmeans_iters) break;   // final assignment against the final centroids
             StageScope ts(ctx, ST_BUILD);
-            B_TRY(sort_by_list());
+            B_TRY(sort_buckets());
             hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)waves), dim3(64), 0, st, sp_cols, sp_vals, X, low_dim,
                                ivf->perm, ivf->list_off, bkd, nbk, ivf->centroids);
             B_HIP(hipGetLastError());
         }
         StageScope ts(ctx, ST_BUILD);
-        B_TRY(sort_by_list());       // (the sparse rows stay with the index: pairs16.hip evaluates its exact chains over them)
+        B_TRY(sort_buckets());       // (the sparse rows stay with the index: pairs16.hip evaluates its exact chains over them)
         // the float32 rows in list order are made on demand (fal_ivf_ensure_xl: the staged fine scan and the staged coarse scan read
         // them; the default path -- coarse quantiser from the build's keys, float16 prefilter -- does not: 16 GB at 10 M spectra)
         ivf->Xl = nullptr;
