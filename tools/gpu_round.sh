@@ -4,31 +4,39 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out
-timeout 1200 python bench.py > $O/r3_bench.txt 2>&1
-grep '^{' $O/r3_bench.txt | tail -1 > $O/r3_bench_1M.json
+timeout 1200 python bench.py > $O/r4_bench.txt 2>&1
+grep '^{' $O/r4_bench.txt | tail -1 > $O/r4_bench_1M.json
 rm -rf $O/p_trace
-rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 bench.py --partitions pipelined --no-configs --no-cpu-baseline > $O/r3_bench_pipelined_under_rocprof.txt 2>&1
-python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r3_bench_1M_pipelined_kernel_stats.csv
-grep '^{' $O/r3_bench_pipelined_under_rocprof.txt | tail -1 > $O/r3_bench_1M_pipelined_under_rocprof.json
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 bench.py --partitions pipelined --no-configs --no-cpu-baseline > $O/r4_bench_pipelined_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r4_bench_1M_pipelined_kernel_stats.csv
+grep '^{' $O/r4_bench_pipelined_under_rocprof.txt | tail -1 > $O/r4_bench_1M_pipelined_under_rocprof.json
 rm -rf $O/p_trace
-rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 bench.py --no-configs --no-cpu-baseline > $O/r3_bench_under_rocprof.txt 2>&1
-python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r3_bench_1M_kernel_stats.csv
-grep '^{' $O/r3_bench_under_rocprof.txt | tail -1 > $O/r3_bench_1M_under_rocprof.json
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 bench.py --no-configs --no-cpu-baseline > $O/r4_bench_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r4_bench_1M_kernel_stats.csv
+grep '^{' $O/r4_bench_under_rocprof.txt | tail -1 > $O/r4_bench_1M_under_rocprof.json
 rm -rf $O/p_trace
 python3 - <<'PY'
 import json
-j = json.load(open('gpurun_out/r3_bench_1M.json'))
+j = json.load(open('gpurun_out/r4_bench_1M.json'))
 print('value', j['value'], j['ms_per_step'], j['stage_ms'], j.get('value_host_to_host'), j.get('ms_per_step_host_to_host_latency'))
 print('roofline', {k: j['roofline'][k] for k in ('bound', 'frac', 'avg_launch_ms', 'traffic')})
 for c in j.get('configs', []):
     print(c.get('dtype'), c.get('ms_per_step'), c.get('stage_ms'), c.get('error'), {k: c['roofline'][k] for k in ('bound', 'frac', 'avg_launch_ms')} if 'roofline' in c else None)
 print(j.get('cpu_baseline'))
-j = json.load(open('gpurun_out/r3_bench_1M_pipelined_under_rocprof.json')); print('pipelined under rocprof', j['value'], j['roofline']['avg_launch_ms'])
+j = json.load(open('gpurun_out/r4_bench_1M_pipelined_under_rocprof.json')); print('pipelined under rocprof', j['value'], j['roofline']['avg_launch_ms'])
 PY
-grep "dense4_kernel<50>" $O/r3_bench_1M_pipelined_kernel_stats.csv | cut -c1-60,170-260
-grep "dense4_kernel<50>" $O/r3_bench_1M_kernel_stats.csv | cut -c1-60,170-260
+grep "dense4_kernel<50>" $O/r4_bench_1M_pipelined_kernel_stats.csv | cut -c1-60,170-260
+grep "dense4_kernel<50>" $O/r4_bench_1M_kernel_stats.csv | cut -c1-60,170-260
 rm -rf $O/p_trace
-rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 tools/scale_run.py 10000000 > $O/r3_10M_under_rocprof.txt 2>&1
-python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r3_10M_f32_kernel_stats.csv
-tail -2 $O/r3_10M_under_rocprof.txt
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 tools/scale_run.py 10000000 > $O/r4_10M_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r4_10M_f32_kernel_stats.csv
+tail -2 $O/r4_10M_under_rocprof.txt
+rm -rf $O/p_trace
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 tools/scale_run.py 10000000 f32 16 f16 800 > $O/r4_10M_f16_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r4_10M_f16_800_kernel_stats.csv
+tail -2 $O/r4_10M_f16_under_rocprof.txt
+rm -rf $O/p_trace
+rocprofv3 --kernel-trace --stats -d $O/p_trace -o t -- python3 tools/scale_run.py 10000000 f32 32 f32 400 400 600 > $O/r4_10M_c4_under_rocprof.txt 2>&1
+python3 profiles/summarize.py stats $O/p_trace/t_results.db $O/r4_10M_f32_dense_kernel_stats.csv
+tail -2 $O/r4_10M_c4_under_rocprof.txt
 rm -rf $O/p_trace

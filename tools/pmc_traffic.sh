@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic (rocprofv3 PMC: FETCH_SIZE and WRITE_SIZE in SEPARATE passes, with --kernel-trace only) of the dominant cosine
-# kernel of every bench workload -> gpurun_out/r3_pmc_traffic.json (copied to profiles/).  FETCH_SIZE is doubled for gfx950
+# kernel of every bench workload -> gpurun_out/r4_pmc_traffic.json (copied to profiles/).  FETCH_SIZE is doubled for gfx950
 # (MI355X_MICROARCH.md, HBM section); counters are KiB.  Run on the GPU box:  bash tools/pmc_traffic.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -41,7 +41,7 @@ for w, sub in KERNEL.items():
              for k, v in sorted(f.items(), key=lambda kv: -(2 * kv[1][1] + wr.get(kv[0], [0, 0.0])[1]))[:24]}
     out[w] = {"kernel": ", ".join(ks), "launches": n, "fetch_bytes_per_launch": fb / max(n, 1), "write_bytes_per_launch": wb / max(n, 1),
               "hbm_bytes_per_launch": (fb + wb) / max(n, 1), "kernels": table}
-json.dump(out, open(os.path.join(R, "gpurun_out", "r3_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(R, "gpurun_out", "r4_pmc_traffic.json"), "w"), indent=1)
 for w in KERNEL:
     e = out[w]
     print(w, e.get("kernel"), e.get("launches"), "GB/launch", round(e.get("hbm_bytes_per_launch", 0) / 1e9, 3))
