@@ -384,7 +384,10 @@ def main():
         return dt
 
     def staged(parts, run_args):
-        """per-kernel timing (HIP events on the kernels' own stream), outside any timed region"""
+        """per-kernel timing (HIP events on the kernels' own stream), outside any timed region.  The serial pass runs on the
+        pipeline's own context (the timed steps ran on the partition runner's): one untimed pass first, so that this context's
+        scratch has its steady-state size too -- a GB-sized hipMalloc inside a stage shows up as tens of ms of that stage"""
+        step(parts, run_args, [])
         ctx.enable_timing(True)
         stages = []
         step(parts, run_args, stages)
