@@ -42,7 +42,8 @@ struct Assign16Args {
     const AssignJob* jobs;   // (row segment) x (ALL lists of the bucket, <= 128)
     int64_t n_jobs;
     int32_t* assign;         // [n]
-    int32_t* amb_list;       // (row, job) pairs left to the exact kernel over ALL centroids
+    int32_t* amb_list;       // (row, job, 4 contender ids, full-group mask) left to assign_exact_rows_kernel: the 32 centroids of
+                             // every group in the mask + the contenders (mask 0: ALL centroids of the bucket)
     int32_t* amb_count;      // [0] entries of amb_list, [1] entries of pair_list
     int amb_cap;
     int32_t* pair_list;      // (row, job, <= 4 contender ids packed in bytes, 0xFF = none): rows with one contender per
@@ -147,11 +148,13 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void assign16_kernel(Assig
             // reaches thr too, the group's other members are unknown here: all centroids are re-evaluated
             uint32_t pk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};             // four contender ids, 16 bits each (0xFFFF = none)
             bool full = false;
+            uint32_t full_groups = 0;                                // groups whose runner-up reaches thr too
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) {
                 const float b = r_best[par][ww][lane], s2 = r_second[par][ww][lane];
                 if (b >= thr) pk[ww >> 1] = (pk[ww >> 1] & ~(0xFFFFu << (16 * (ww & 1)))) | ((uint32_t)r_id[par][ww][lane] << (16 * (ww & 1)));
                 full = full || s2 >= thr;
+                full_groups |= s2 >= thr ? (1u << ww) : 0u;
             }
             if (!full) {
                 const int at = atomicAdd(a.amb_count + 1, 1);
@@ -165,10 +168,15 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void assign16_kernel(Assig
                 }
             }
             if (full) {
+                // only the groups whose runner-up reaches thr can hide further candidates: their 32 centroids + the other
+                // groups' contenders are re-evaluated (all centroids of the bucket: 3.2 ms and 20 GB per 10 M build)
                 const int at = atomicAdd(a.amb_count, 1);
                 if (at < a.amb_cap) {
-                    a.amb_list[2 * at] = (int32_t)row;
-                    a.amb_list[2 * at + 1] = (int32_t)ji;
+                    a.amb_list[5 * at] = (int32_t)row;
+                    a.amb_list[5 * at + 1] = (int32_t)ji;
+                    a.amb_list[5 * at + 2] = (int32_t)pk[0];
+                    a.amb_list[5 * at + 3] = (int32_t)pk[1];
+                    a.amb_list[5 * at + 4] = (int32_t)full_groups;
                 }
             }
         }
@@ -254,21 +262,48 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void assign16_kernel(Assig
 #undef FAL_FOR_A
 }
 
-// the rows the prefilter could not decide: exact arg-max over all centroids of the bucket (<= 128: two per lane)
+// the rows the prefilter could not decide and could not name the contenders of: exact arg-max over the candidates that are left
+// -- all 32 centroids of every group in the entry's mask + the named contenders of the other groups (mask 0: every centroid of
+// the bucket).  Anything else has an approximate value below thr = best - 2.2 eps and cannot be the exact arg-max.
 __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, const float* __restrict__ X, const float* __restrict__ Cn,
                                                                int d) {
     const int lane = threadIdx.x;
     const int total = min(*a.amb_count, a.amb_cap);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
-        const int64_t row = a.amb_list[2 * t];
-        const AssignJob job = a.jobs[a.amb_list[2 * t + 1]];
+        const int64_t row = a.amb_list[5 * t];
+        const AssignJob job = a.jobs[a.amb_list[5 * t + 1]];
+        const uint32_t pk[2] = {(uint32_t)a.amb_list[5 * t + 2], (uint32_t)a.amb_list[5 * t + 3]};
+        const uint32_t fg = (uint32_t)a.amb_list[5 * t + 4];
         float best = -INFINITY;
         int bid = 0x7fffffff;
-        for (int c = lane; c < job.ncent; c += 64) {
+        auto eval = [&](int c) {
             const float s = exact_dot(X + row * d, Cn + (job.cent0 + c) * d, d);
-            if (s > best) {                                          // (ids ascend: ties keep the lowest)
+            if (s > best || (s == best && c < bid)) {
                 best = s;
                 bid = c;
+            }
+        };
+        if (fg == 0u) {
+            for (int c = lane; c < job.ncent; c += 64) eval(c);
+        } else {
+            const int nfull = 32 * __popc(fg);
+            for (int i = lane; i < nfull + 4; i += 64) {
+                int c = -1;
+                if (i < nfull) {
+                    int g = 0, k = i >> 5;                             // the k-th set bit of the mask
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const bool on = (fg >> b) & 1u;
+                        g = (on && k == 0) ? b : g;
+                        k -= on ? 1 : 0;
+                    }
+                    c = 32 * g + (i & 31);
+                } else {
+                    const int slot = i - nfull;
+                    const uint32_t id = (pk[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu;
+                    c = id == 0xFFFFu ? -1 : (int)id;
+                }
+                if (c >= 0 && c < job.ncent) eval(c);
             }
         }
 #pragma unroll
@@ -365,15 +400,17 @@ __global__ __launch_bounds__(256) void assign16_merge_kernel(Assign16Args a, int
             } else {
                 const int at2 = atomicAdd(a.amb_count, 1);
                 if (at2 < a.amb_cap) {
-                    a.amb_list[2 * at2] = (int32_t)row;
-                    a.amb_list[2 * at2 + 1] = (int32_t)(job_index0 + ji);
+                    a.amb_list[5 * at2] = (int32_t)row;
+                    a.amb_list[5 * at2 + 1] = (int32_t)(job_index0 + ji);
+                    a.amb_list[5 * at2 + 4] = 0;
                 }
             }
         } else {
             const int at = atomicAdd(a.amb_count, 1);
             if (at < a.amb_cap) {
-                a.amb_list[2 * at] = (int32_t)row;
-                a.amb_list[2 * at + 1] = (int32_t)(job_index0 + ji);
+                a.amb_list[5 * at] = (int32_t)row;
+                a.amb_list[5 * at + 1] = (int32_t)(job_index0 + ji);
+                a.amb_list[5 * at + 4] = 0;
             }
         }
     }
@@ -401,12 +438,12 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     // work lists of the exact kernels: a row enters at most one of them once per pass, so n_rows entries never overflow
     int32_t* amb = nullptr;
     const int amb_cap = (int)std::max<int64_t>(n_rows, 1);
-    FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(6 * (size_t)amb_cap + 16), (void**)&amb));
+    FAL_TRY(ctx->reserve(SLOT_FUSED, sizeof(int32_t) * (size_t)(9 * (size_t)amb_cap + 16), (void**)&amb));
     FAL_CHECK_HIP(hipMemsetAsync(amb, 0, sizeof(int32_t) * 16, ctx->stream));
     Assign16Args a{};
     a.X16 = reinterpret_cast<const __half*>(X16); a.C16 = reinterpret_cast<const __half*>(C16);
     a.jobs = jobs; a.n_jobs = n_single; a.assign = assign; a.amb_list = amb + 16; a.amb_count = amb; a.amb_cap = amb_cap;
-    a.pair_list = amb + 16 + 2 * (size_t)amb_cap; a.ckeys = ckeys; a.ckeys_stride = ckeys_stride; a.n = n_rows;
+    a.pair_list = amb + 16 + 5 * (size_t)amb_cap; a.ckeys = ckeys; a.ckeys_stride = ckeys_stride; a.n = n_rows;
     StageScope ts(ctx, stage);
     const dim3 block(256);
 #define FAL_LAUNCH_A16(S)                                                                                  \
