@@ -180,6 +180,10 @@ def main():
                          "numpy generator the parity tests use (~20 s of host time per million spectra)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the exchange step's device work (CSR packing, payload) at 1 GPU too (no collective)")
+    ap.add_argument("--with-strong", action="store_true",
+                    help="N > 1, weak mode: also time the FIXED --spectra-total dataset on the same ranks in the same run "
+                         "(`strong_scaling` in the JSON line: the window-by-window deal of one shared dataset).  Off by default: the "
+                         "driver's scaling runs stay exactly the weak job")
     ap.add_argument("--exchange-only", action="store_true",
                     help="collective self-check: run ONLY the exchange step (SparseGraphExchange: sizes all-gather + one padded "
                          "payload all-gather over RCCL) with synthetic ragged payloads on the N ranks, verify every rank's received "
@@ -406,7 +410,7 @@ def main():
     # ---- N > 1, weak mode: the FIXED dataset (BASELINE configs[2]) on the same ranks as well, so that the line also carries the
     # window-by-window deal of one shared dataset (the weak workload deals whole partitions) -------------------------
     strong_extra = None
-    if world > 1 and not strong and not args.no_configs:
+    if world > 1 and not strong and args.with_strong:
         try:
             del parts
             torch.cuda.empty_cache()

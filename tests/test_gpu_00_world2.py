@@ -66,7 +66,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, 
 
 @pytest.mark.parametrize("scaling,extra", [
     # 2 blocks -> 4 charge partitions, whole partitions per rank; then the line's `strong_scaling` leg: one shared dataset
-    ("weak", ["--spectra", "150000", "--spectra-total", "200000"]),
+    ("weak", ["--spectra", "150000", "--spectra-total", "200000", "--with-strong"]),
     ("strong", ["--spectra-total", "300000", "--no-configs"]),           # one dataset, window by window
 ])
 def test_bench_runs_as_a_two_rank_job(scaling, extra):
