@@ -60,6 +60,7 @@ struct FusedArgs {
     const int32_t* perm;         // [n] list-order position -> sorted row
     const uint16_t* sp_cols;     // [n, 64] the rows' sparse form (ivf.h), or nullptr: pairs16 then reads the dense rows
     const float* sp_vals;
+    int rows_f16;                // 1: every row component is a float16 value (pairs16s keeps its query tile as float16 in LDS)
 };
 
 bool fused_supports(int d);

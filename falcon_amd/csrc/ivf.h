@@ -36,6 +36,7 @@ struct fal_ivf {
     // to the similarity).  1 = some row of an IVF bucket has one (found by the build's pass over the rows): the build and the
     // searches use the exact kernels; 0 = none; -1 = not read back yet (neg_dev holds the flag on the device)
     int rows_signed = 0;
+    int rows_f16 = 0;                // 1 = every component of the indexed rows is a float16 value (float16 vectors: X is the image of X16)
     int32_t* neg_dev = nullptr;
     const void* X16pre = nullptr;    // float16 rows (sorted order) the IVF fine scan gathers its list rows and queries from
                                      // (ivf16.hip), borrowed: fal_ivf_attach_prefilter_ex(which & 2)

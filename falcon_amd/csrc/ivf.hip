@@ -6,6 +6,7 @@
 // ivf_search).  Everything is batched over ALL buckets of a charge partition: one launch per
 // step, never one launch per bucket.
 #include <algorithm>
+#include <hip/hip_fp16.h>
 #include <math.h>
 #include <stdlib.h>
 #include "common.h"
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
     const int r_first = (int)(blockIdx.x - seg_off[lo]) * 256;
     const int r_end = min(b.n, r_first + 256);
     bool neg = false;            // a component that is negative or not finite: the float16 prefilters' error bound needs rows >= 0
+    bool wide = false;           // a component that is not a float16 value (float16 VECTORS, config 5: none -- pairs16.hip then keeps
+                                 // its query tile in LDS as float16, exactly)
     for (int rl = r_first + w; rl < r_end; rl += 4) {
         const int64_t r = b.row0 + rl;
         sc[w][lane] = kColPad;
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
             for (int j = 0; j < 8; ++j) {
                 c += (int)(xs[j] != 0.f);
                 neg |= !(xs[j] >= 0.f) || xs[j] > 65504.f;
+                wide |= __half2float(__float2half_rn(xs[j])) != xs[j];
             }
             int pre = c;
 #pragma unroll
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
         vals[r * kSparseW + lane] = sv[w][lane];
     }
     if (__ballot(neg) != 0ull && lane == 0) atomicOr(neg_flag, 1);
+    if (__ballot(wide) != 0ull && lane == 0) atomicOr(neg_flag + 1, 1);
 }
 
 // global list of every sorted row (bucket by binary search on the bucket table) = the key of the stable sort by list
@@ -436,9 +441,10 @@ int fal_ivf_attach_prefilter_ex(fal_ivf* ivf, const void* X16, int which) {
         if (!ivf->Xpre) ctx->counters[6] |= 2;
     }
     if ((which & 2) && ivf->n_ivf_buckets > 0 && ivf->rows_signed < 0) {
-        FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 4, ivf->neg_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        FAL_CHECK_HIP(hipMemcpyAsync(ctx->fb_host + 6, ivf->neg_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         FAL_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        ivf->rows_signed = ctx->fb_host[4] != 0 ? 1 : 0;
+        ivf->rows_signed = ctx->fb_host[6] != 0 ? 1 : 0;
+        ivf->rows_f16 = ctx->fb_host[7] == 0 ? 1 : 0;
         ctx->counters[6] |= ivf->rows_signed;
     }
     if ((which & 2) && ivf->n_ivf_buckets > 0 && !ivf->X16pre && ivf->rows_signed == 0) {
@@ -604,14 +610,15 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             // the one synchronisation of the build (only when float16 rows were handed in: ~20 us of an empty queue against the
             // tens of ms of the k-means passes that follow)
             if (X16 != nullptr) {
-                B_HIP(hipMemcpyAsync(ctx->fb_host + 4, neg_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                B_HIP(hipMemcpyAsync(ctx->fb_host + 6, neg_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
                 B_HIP(hipStreamSynchronize(st));
-                ivf->rows_signed = ctx->fb_host[4] != 0 ? 1 : 0;
+                ivf->rows_signed = ctx->fb_host[6] != 0 ? 1 : 0;
+                ivf->rows_f16 = ctx->fb_host[7] == 0 ? 1 : 0;
                 ctx->counters[6] |= ivf->rows_signed;
             } else {
                 ivf->rows_signed = -1;        // not known on the host yet: fal_ivf_attach_prefilter_ex reads it if it needs it
                 B_TRY(ctx->pool_alloc(sizeof(int32_t) * 2, (void**)&ivf->neg_dev));
-                B_HIP(hipMemcpyAsync(ivf->neg_dev, neg_dev, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+                B_HIP(hipMemcpyAsync(ivf->neg_dev, neg_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
             }
         }
         // Buckets with few lists (<= kAssignMaxLists) are assigned by the shared-stream kernel (assign.hip): jobs =

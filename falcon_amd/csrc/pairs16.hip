@@ -13,6 +13,7 @@
 //
 // Reference: README.md:107-113, 137-142; see ivf16.hip for the error bound and the rest of the path.
 #include <math.h>
+#include <type_traits>
 #include <limits.h>
 #include <algorithm>
 #include "common.h"
@@ -263,11 +264,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // fetched coalesced, 16 entries of 64 pairs at a time (an instruction covers 16 pairs x 64 bytes of values / 32 pairs x 32 bytes
 // of columns), and transposed through LDS into the lanes that own the pairs.  Rows with more than 64 non-zeros (entry 0 =
 // kColDense) take the dense chain.
+// QH: the query tile in LDS as float16 -- only when every component IS a float16 value (float16 vectors: FusedArgs.rows_f16,
+// checked by the build's pass over the rows), so the conversion back is exact and the chains keep their bits; at low_dim 800 the
+// tile then takes 51 KB instead of 102 and two workgroups share a CU.
+template <bool QH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pairs16s_kernel(FusedArgs a, int d) {
     constexpr int kSlot = 112;                                   // bytes per pair and step: 16 columns + 16 values + 16
+    using QT = typename std::conditional<QH, __half, float>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* qs = reinterpret_cast<float*>(smem);                  // [32][d]
-    unsigned char* tbuf = smem + (size_t)32 * d * 4;             // [4][64 * kSlot]
+    QT* qs = reinterpret_cast<QT*>(smem);                        // [32][d]
+    unsigned char* tbuf = smem + (size_t)32 * d * sizeof(QT);    // [4][64 * kSlot]
     int32_t* off = reinterpret_cast<int32_t*>(tbuf + 4 * 64 * kSlot);   // [33]
     int ji, lt;
     if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     {
         float4* z = reinterpret_cast<float4*>(qs);
-        for (int i = threadIdx.x; i < 8 * d; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = threadIdx.x; i < (int)(8 * d * sizeof(QT) / 4); i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     const int P = off[32];
@@ -313,9 +319,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (q < nqw) {
             if (__shfl(qc[t], 0, 64) == (int)kColDense) {
                 const int64_t row = row_t + q;
-                for (int e = lane; e < d; e += 64) qs[q * d + e] = a.X[row * d + e];
+                for (int e = lane; e < d; e += 64) qs[q * d + e] = (QT)a.X[row * d + e];
             } else if (qc[t] != (int)kColPad) {
-                qs[q * d + qc[t]] = qv[t];
+                qs[q * d + qc[t]] = (QT)qv[t];
             }
         }
     }
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int g = 0; g < 4; ++g) idV[g] = (int64_t)(uint32_t)__shfl((int)id, 16 * g + (lane >> 2), 64) * kSparseW + 4 * (lane & 3);
 #pragma unroll
         for (int g = 0; g < 2; ++g) idC[g] = (int64_t)(uint32_t)__shfl((int)id, 32 * g + (lane >> 1), 64) * kSparseW + 8 * (lane & 1);
-        const float* qrow = qs + q * d;
+        const QT* qrow = qs + q * d;
         float acc = 0.f;
         bool dense = false;
         // every entry of the 64 candidates in flight at once (four steps of 16 entries)
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (first && (c0.x & 0xFFFFu) == (uint32_t)kColDense) dense = true;
             auto term = [&](uint32_t col, float val) {
                 const bool on = col < (uint32_t)kColDense;
-                const float qv = qrow[on ? col : 0u];
+                const float qv = (float)qrow[on ? col : 0u];
                 const float nx = __builtin_fmaf(qv, val, acc);
                 acc = on ? nx : acc;
             };
@@ -391,10 +397,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (__ballot(dense) != 0ull) {                           // (rare) rows kept dense: the dense chain
             if (dense) {
                 const float4* cp = reinterpret_cast<const float4*>(a.X) + (int64_t)id * (2 * dh4);
-                const float4* qp = reinterpret_cast<const float4*>(qrow);
+                auto q4 = [&](int e4) -> float4 {
+                    return make_float4((float)qrow[4 * e4], (float)qrow[4 * e4 + 1], (float)qrow[4 * e4 + 2], (float)qrow[4 * e4 + 3]);
+                };
                 acc = 0.f;
                 for (int jj = 0; jj < dh4; ++jj) {
-                    const float4 cl = cp[jj], chh = cp[dh4 + jj], ql = qp[jj], qh = qp[dh4 + jj];
+                    const float4 cl = cp[jj], chh = cp[dh4 + jj], ql = q4(jj), qh = q4(dh4 + jj);
                     acc = __builtin_fmaf(ql.x, cl.x, acc);
                     acc = __builtin_fmaf(qh.x, chh.x, acc);
                     acc = __builtin_fmaf(ql.y, cl.y, acc);
@@ -437,11 +445,13 @@ int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32
     if (list_tiles32 <= 0) return FAL_OK;
     StageScope ts(ctx, ST_SCAN);
     if (a.sp_cols != nullptr && a.sp_vals != nullptr && d <= 832) {        // (32 query rows of d floats + 28 KB must fit 160 KB of LDS)
-        const size_t lds = (size_t)32 * d * 4 + 4 * 64 * 112 + 34 * 4;
+        const bool qh = a.rows_f16 == 1 && d > 512;              // (below, two workgroups fit a CU with a float32 tile as well)
+        const size_t lds = (size_t)32 * d * (qh ? 2 : 4) + 4 * 64 * 112 + 34 * 4;
         // (per launch: the attribute is per device, and two partition threads may launch at once)
-        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)pairs16s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)std::max<size_t>(96 * 1024, lds)));
-        hipLaunchKernelGGL(pairs16s_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), lds, ctx->stream, a, d);
+        const void* fn = qh ? (const void*)pairs16s_kernel<true> : (const void*)pairs16s_kernel<false>;
+        FAL_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(96 * 1024, lds)));
+        if (qh) hipLaunchKernelGGL(pairs16s_kernel<true>, dim3((unsigned)(list_tiles32 * 8)), dim3(256), lds, ctx->stream, a, d);
+        else hipLaunchKernelGGL(pairs16s_kernel<false>, dim3((unsigned)(list_tiles32 * 8)), dim3(256), lds, ctx->stream, a, d);
     } else {
         hipLaunchKernelGGL(pairs16_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
     }

@@ -559,7 +559,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         fa.keep = nf->keep; fa.nb_idx = nf->nb_idx; fa.nb_dist = nf->nb_dist; fa.nb_count = nf->nb_count;
         fa.ivf = 1; fa.assign = ivf->assign; fa.pos_of_row = ivf->pos_of_row; fa.probes = probes; fa.n_probe = np;
         fa.mask_words = (max_n_list + 31) / 32; fa.list_off = ivf->list_off; fa.perm = ivf->perm;
-        fa.sp_cols = ivf->sp_cols; fa.sp_vals = ivf->sp_vals;
+        fa.sp_cols = ivf->sp_cols; fa.sp_vals = ivf->sp_vals; fa.rows_f16 = ivf->rows_f16;
         FAL_TRY(fused_prepare(ctx, &fa, ivf->n));
         // the exact part: only the (query, candidate) pairs that can matter (pairs16.hip)
         int2* gsel = nullptr;
