@@ -21,6 +21,8 @@ struct Coarse16Args {
     int32_t* ovf_count;          // (launch_coarse16) queries with more members than the wave-level kernel holds
     int32_t* ovf_list;
     int ovf_cap;
+    const uint16_t* sp_cols;     // [n, 64] the rows' sparse form (ivf.h): the exact chains of the close calls walk the query's
+    const float* sp_vals;        // <= 64 entries against the dense centroid instead of low_dim terms (nullptr: dense chains)
 };
 
 int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a);

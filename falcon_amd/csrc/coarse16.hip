@@ -162,13 +162,46 @@ __global__ __launch_bounds__(16 * QPW) void coarse16_kernel(Coarse16Args a) {
 // dependent fmaf behind memory latency, ~30 us: with a chain round per 4 queries -- or per 16 queries but with three of four
 // waves of a workgroup waiting for it -- the kernel spent its time there), then the four rounds rank and emit.  A query with
 // more than 16 members (many equal similarities) is handed to the workgroup-level kernel.
+// The exact chain of a (query, centroid) pair over the query's sparse form: `cols` / `vals` = the query row's <= 64 entries in
+// chain order (LDS; unused entries: column kColPad), `c` = the dense centroid.  A term whose query component is zero leaves the
+// accumulator as it is (0 * c = +0, centroids of non-negative rows are non-negative), so the chain over the entries has the
+// bits of the dense chain (pairs16.hip uses the same fact the other way round) -- at 64 independent 4-byte gathers in four
+// batches instead of 2 x low_dim / 4 dependent 16-byte loads in low_dim / 32 batches: the round of chains is what the kernel
+// waits for.  No early exit (a divergent trip count here is what hipcc miscompiled in round 3): padded entries multiply c[0] by 0.
+__device__ __forceinline__ float coarse_sparse_chain(const uint16_t* cols, const float* vals, const float* __restrict__ c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int e0 = 0; e0 < kSparseW; e0 += 16) {
+        uint32_t col[16];
+        float qv[16], cv[16];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const uint2 c2 = *reinterpret_cast<const uint2*>(cols + e0 + 4 * t4);
+            const float4 v4 = *reinterpret_cast<const float4*>(vals + e0 + 4 * t4);
+            col[4 * t4] = c2.x & 0xFFFFu; col[4 * t4 + 1] = c2.x >> 16; col[4 * t4 + 2] = c2.y & 0xFFFFu; col[4 * t4 + 3] = c2.y >> 16;
+            qv[4 * t4] = v4.x; qv[4 * t4 + 1] = v4.y; qv[4 * t4 + 2] = v4.z; qv[4 * t4 + 3] = v4.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const bool on = col[t] < (uint32_t)kColDense;
+            cv[t] = c[on ? col[t] : 0u];
+            qv[t] = on ? qv[t] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc = __builtin_fmaf(qv[t], cv[t], acc);
+    }
+    return acc;
+}
+
 template <int KPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 6 : 3, 8))) void coarse16w_kernel(Coarse16Args a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5 : 3, 8))) void coarse16w_kernel(Coarse16Args a) {
     constexpr int kCap = 16;
     __shared__ float m_val[16][kCap];
     __shared__ int32_t m_id[16][kCap];
     __shared__ int32_t q_cnt[16];
     __shared__ int64_t q_row[16], q_cbase[16];
+    __shared__ __attribute__((aligned(16))) uint16_t sp_c[8][kSparseW];       // the sparse rows of eight queries at a time
+    __shared__ __attribute__((aligned(16))) float sp_v[8][kSparseW];
     const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
     const int sh = 16 * grp;
     const int np = a.np;
@@ -260,12 +293,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 6
         off[0] = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) off[k + 1] = off[k] + q_cnt[k];
-        for (int i = lane; i < off[16]; i += 64) {
-            int k = 0;
+        if (a.sp_cols == nullptr) {
+            for (int i = lane; i < off[16]; i += 64) {
+                int k = 0;
 #pragma unroll
-            for (int kk = 1; kk < 16; ++kk) k = off[kk] <= i ? kk : k;
-            const int mm = i - off[k];
-            m_val[k][mm] = exact_dot(a.X + q_row[k] * a.d, a.C + (q_cbase[k] + m_id[k][mm]) * (int64_t)a.d, a.d);
+                for (int kk = 1; kk < 16; ++kk) k = off[kk] <= i ? kk : k;
+                const int mm = i - off[k];
+                m_val[k][mm] = exact_dot(a.X + q_row[k] * a.d, a.C + (q_cbase[k] + m_id[k][mm]) * (int64_t)a.d, a.d);
+            }
+        } else {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int lo = off[8 * half], hi = off[8 * half + 8];
+                if (hi > lo) {                                   // (wave-uniform)
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {             // the rows of this half's ambiguous queries: one round trip
+                        const int k = 8 * half + kk;
+                        const bool want = q_cnt[k] > 0;
+                        sp_c[kk][lane] = want ? a.sp_cols[q_row[k] * kSparseW + lane] : kColPad;
+                        sp_v[kk][lane] = want ? a.sp_vals[q_row[k] * kSparseW + lane] : 0.f;
+                    }
+                    wave_lds_sync();
+                    for (int i = lo + lane; i < hi; i += 64) {
+                        int k = 8 * half;
+#pragma unroll
+                        for (int kk = 1; kk < 8; ++kk) k = off[8 * half + kk] <= i ? 8 * half + kk : k;
+                        const int mm = i - off[k];
+                        const float* c = a.C + (q_cbase[k] + m_id[k][mm]) * (int64_t)a.d;
+                        float v;
+                        if (sp_c[k - 8 * half][0] == kColDense) v = exact_dot(a.X + q_row[k] * a.d, c, a.d);     // (more than 64 non-zeros)
+                        else v = coarse_sparse_chain(sp_c[k - 8 * half], sp_v[k - 8 * half], c);
+                        m_val[k][mm] = v;
+                    }
+                    wave_lds_sync();
+                }
+            }
         }
     }
     wave_lds_sync();

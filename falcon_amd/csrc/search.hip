@@ -447,6 +447,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     if (from_keys) {
         Coarse16Args ca{ivf->ckeys, ivf->ckeys_stride, ivf->X, ivf->centroids, d, coarse_dev, (int)coarse.size(), ivf_tiles, nullptr,
                         ivf->perm, np, probes};
+        ca.sp_cols = ivf->sp_cols;
+        ca.sp_vals = ivf->sp_vals;
         FAL_TRY(launch_coarse16(ctx, ca));
     }
     if (!from_keys) FAL_TRY(ivf_ensure_xl(ctx, ivf));
