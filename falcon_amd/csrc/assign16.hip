@@ -58,7 +58,35 @@ struct Assign16Args {
     int64_t n;               // rows (stride of the partial arrays)
     const AssignJob* mjobs;  // merge jobs: (row segment) x (ALL lists of the bucket); the exact kernels' entries refer to these
     int64_t n_mjobs;
+    const uint16_t* sp_cols; // optional [n, 64] the rows' sparse form (ivf.h): assign_exact_rows_kernel walks a row's entries
+    const float* sp_vals;    // against the dense centroids instead of low_dim terms
 };
+
+// The exact chain of (row, centroid) over the ROW's sparse form held across the wave (lane e = entry e: every lane of the wave
+// evaluates the SAME row against its own centroid `c`): the entries come as scalars (v_readlane), the lane gathers c[column] --
+// 16 independent loads per batch, four batches at most.  Zero row components contribute nothing to the dense chain (0 * c = +0,
+// centroids are non-negative), so the bits are those of exact_dot (coarse16.hip / pairs16.hip use the same fact).
+__device__ __forceinline__ float a16_sparse_row_chain(uint32_t col_lane, float val_lane, int n_ent, const float* __restrict__ c) {
+    float acc = 0.f;
+    const int vbits = __float_as_int(val_lane);
+#pragma unroll
+    for (int e0 = 0; e0 < kSparseW; e0 += 16) {
+        if (e0 >= n_ent) break;                                      // (wave-uniform: one row per wave)
+        float cv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, e0 + t);
+            cv[t] = c[ce < (uint32_t)kColDense ? ce : 0u];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, e0 + t);
+            const float ve = ce < (uint32_t)kColDense ? __int_as_float(__builtin_amdgcn_readlane(vbits, e0 + t)) : 0.f;
+            acc = __builtin_fmaf(ve, cv[t], acc);
+        }
+    }
+    return acc;
+}
 
 __device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
 
@@ -276,8 +304,17 @@ __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, c
         const uint32_t fg = (uint32_t)a.amb_list[5 * t + 4];
         float best = -INFINITY;
         int bid = 0x7fffffff;
+        uint32_t col_lane = kColDense;
+        float val_lane = 0.f;
+        if (a.sp_cols) {
+            col_lane = a.sp_cols[row * kSparseW + lane];
+            val_lane = a.sp_vals[row * kSparseW + lane];
+        }
+        const bool sparse = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, 0) != (uint32_t)kColDense;    // (else: > 64 non-zeros)
+        const int n_ent = __popcll(__ballot(col_lane < (uint32_t)kColDense));
         auto eval = [&](int c) {
-            const float s = exact_dot(X + row * d, Cn + (job.cent0 + c) * d, d);
+            const float* cp = Cn + (job.cent0 + c) * d;
+            const float s = sparse ? a16_sparse_row_chain(col_lane, val_lane, n_ent, cp) : exact_dot(X + row * d, cp, d);
             if (s > best || (s == best && c < bid)) {
                 best = s;
                 bid = c;
@@ -433,7 +470,7 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
 // to each other]
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
-                    uint16_t* ckeys, int ckeys_stride) {
+                    uint16_t* ckeys, int ckeys_stride, const uint16_t* sp_cols, const float* sp_vals) {
     if (n_single + n_merge <= 0) return FAL_OK;
     // work lists of the exact kernels: a row enters at most one of them once per pass, so n_rows entries never overflow
     int32_t* amb = nullptr;
@@ -444,6 +481,7 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     a.X16 = reinterpret_cast<const __half*>(X16); a.C16 = reinterpret_cast<const __half*>(C16);
     a.jobs = jobs; a.n_jobs = n_single; a.assign = assign; a.amb_list = amb + 16; a.amb_count = amb; a.amb_cap = amb_cap;
     a.pair_list = amb + 16 + 5 * (size_t)amb_cap; a.ckeys = ckeys; a.ckeys_stride = ckeys_stride; a.n = n_rows;
+    a.sp_cols = sp_cols; a.sp_vals = sp_vals;
     StageScope ts(ctx, stage);
     const dim3 block(256);
 #define FAL_LAUNCH_A16(S)                                                                                  \

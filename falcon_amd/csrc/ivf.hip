@@ -731,7 +731,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                     B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * ivf->ckeys_stride, (void**)&ivf->ckeys));
                 }
                 B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, n_single, n_merge, n_group, n,
-                                      ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr, ivf->ckeys_stride));
+                                      ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr, ivf->ckeys_stride, sp_cols, sp_vals));
             }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,

@@ -75,7 +75,8 @@ bool assign16_supports(int d);
 int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count);
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
-                    uint16_t* ckeys = nullptr, int ckeys_stride = 0);
+                    uint16_t* ckeys = nullptr, int ckeys_stride = 0, const uint16_t* sp_cols = nullptr,
+                    const float* sp_vals = nullptr);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order
