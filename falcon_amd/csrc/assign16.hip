@@ -62,31 +62,6 @@ struct Assign16Args {
     const float* sp_vals;    // against the dense centroids instead of low_dim terms
 };
 
-// The exact chain of (row, centroid) over the ROW's sparse form held across the wave (lane e = entry e: every lane of the wave
-// evaluates the SAME row against its own centroid `c`): the entries come as scalars (v_readlane), the lane gathers c[column] --
-// 16 independent loads per batch, four batches at most.  Zero row components contribute nothing to the dense chain (0 * c = +0,
-// centroids are non-negative), so the bits are those of exact_dot (coarse16.hip / pairs16.hip use the same fact).
-__device__ __forceinline__ float a16_sparse_row_chain(uint32_t col_lane, float val_lane, int n_ent, const float* __restrict__ c) {
-    float acc = 0.f;
-    const int vbits = __float_as_int(val_lane);
-#pragma unroll
-    for (int e0 = 0; e0 < kSparseW; e0 += 16) {
-        if (e0 >= n_ent) break;                                      // (wave-uniform: one row per wave)
-        float cv[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, e0 + t);
-            cv[t] = c[ce < (uint32_t)kColDense ? ce : 0u];
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, e0 + t);
-            const float ve = ce < (uint32_t)kColDense ? __int_as_float(__builtin_amdgcn_readlane(vbits, e0 + t)) : 0.f;
-            acc = __builtin_fmaf(ve, cv[t], acc);
-        }
-    }
-    return acc;
-}
 
 __device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
 
@@ -314,7 +289,7 @@ __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, c
         const int n_ent = __popcll(__ballot(col_lane < (uint32_t)kColDense));
         auto eval = [&](int c) {
             const float* cp = Cn + (job.cent0 + c) * d;
-            const float s = sparse ? a16_sparse_row_chain(col_lane, val_lane, n_ent, cp) : exact_dot(X + row * d, cp, d);
+            const float s = sparse ? sparse_row_chain(col_lane, val_lane, n_ent, cp) : exact_dot(X + row * d, cp, d);
             if (s > best || (s == best && c < bid)) {
                 best = s;
                 bid = c;

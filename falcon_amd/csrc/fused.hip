@@ -657,7 +657,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 why = 3;
             } else {
                 float s = 0.f;
-                if (inE) s = exact_dot(a.X + row * d, a.X + (row0 + mid) * d, d);
+                if (a.sp_cols) {
+                    // the query's sparse form across the wave (lane e = entry e), every member lane gathers its own row at the
+                    // query's columns (simtile.h: sparse_row_chain -- the bits of exact_dot)
+                    const uint32_t qc = a.sp_cols[row * kSparseW + lane];
+                    const float qv = a.sp_vals[row * kSparseW + lane];
+                    const bool sparse = (uint32_t)__builtin_amdgcn_readlane((int)qc, 0) != (uint32_t)kColDense;
+                    const int n_ent = __popcll(__ballot(qc < (uint32_t)kColDense));
+                    if (sparse) {
+                        const float sv = sparse_row_chain(qc, qv, n_ent, a.X + (row0 + (inE ? mid : 0u)) * d);
+                        s = inE ? sv : 0.f;
+                    } else if (inE) {
+                        s = exact_dot(a.X + row * d, a.X + (row0 + mid) * d, d);
+                    }
+                } else if (inE) {
+                    s = exact_dot(a.X + row * d, a.X + (row0 + mid) * d, d);
+                }
                 const uint32_t u = inE ? max(f32_sortable(s), 1u) : 0u;
                 const uint32_t id = (uint32_t)(row0 + mid);
                 int rank = 0;                                // members of E with a better key

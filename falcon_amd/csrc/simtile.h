@@ -103,6 +103,33 @@ struct CandStream {
     }
 };
 
+// The exact chain of (row, other vector) over the ROW's sparse form (ivf.h: <= 64 (column, value) entries in chain order, column
+// 0xFFFF = unused, 0xFFFE in entry 0 = read the dense row) held across the wave (lane e = entry e: every lane of the wave
+// evaluates the SAME row against its own dense vector `c` -- a centroid, a member row): the entries come as scalars (v_readlane), the lane gathers c[column] --
+// 16 independent loads per batch, four batches at most.  Zero row components contribute nothing to the dense chain (0 * c = +0,
+// centroids are non-negative), so the bits are those of exact_dot (coarse16.hip / pairs16.hip use the same fact).
+__device__ __forceinline__ float sparse_row_chain(uint32_t col_lane, float val_lane, int n_ent, const float* __restrict__ c) {
+    float acc = 0.f;
+    const int vbits = __float_as_int(val_lane);
+#pragma unroll
+    for (int e0 = 0; e0 < 64; e0 += 16) {
+        if (e0 >= n_ent) break;                                      // (wave-uniform: one row per wave)
+        float cv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, e0 + t);
+            cv[t] = c[ce < 0xFFFEu ? ce : 0u];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, e0 + t);
+            const float ve = ce < 0xFFFEu ? __int_as_float(__builtin_amdgcn_readlane(vbits, e0 + t)) : 0.f;
+            acc = __builtin_fmaf(ve, cv[t], acc);
+        }
+    }
+    return acc;
+}
+
 // the exact similarity on the vector ALU: the k-ordered fmaf chain of simtile.h, bit for bit
 __device__ __forceinline__ float exact_dot(const float* __restrict__ a, const float* __restrict__ b, int d) {
     const int dh4 = d >> 3;
