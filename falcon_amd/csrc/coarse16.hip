@@ -363,6 +363,204 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
     }
 }
 
+// Buckets with 129..512 lists: the same algorithm with ALL 64 lanes on one query (8 keys per lane), sixteen queries per wave one
+// after the other.  The 16-lanes-per-query form holds 32 keys per lane there (168 registers: three waves per SIMD) and pays
+// 17 x 32 compare + ballot steps per round of four queries; here a lane holds 8 keys, the per-query state of the two phases
+// lives in LDS, the wave runs at eight per SIMD, and the round of exact chains is still one per sixteen queries.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void coarse16x_kernel(Coarse16Args a) {
+    constexpr int kCap = 16;
+    __shared__ float m_val[16][kCap];
+    __shared__ int32_t m_id[16][kCap];
+    __shared__ int32_t q_cnt[16], q_need[16], q_nmem[16], q_want[16], q_flag[16];      // flag: 1 emit, 2 ambiguous
+    __shared__ int64_t q_row[16], q_cbase[16], q_pos[16];
+    __shared__ uint8_t s_hi[16][64], s_mem[16][64];                      // per query and lane: which of the lane's 8 keys
+    __shared__ uint32_t hist[320];
+    __shared__ __attribute__((aligned(16))) uint16_t sp_c[8][kSparseW];
+    __shared__ __attribute__((aligned(16))) float sp_v[8][kSparseW];
+    const int lane = threadIdx.x;
+    const int np = a.np;
+    auto wcnt = [&](bool pred) -> int { return __popcll(__ballot(pred)); };
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int qi = 0; qi < 16; ++qi) {
+        const int64_t g = (int64_t)blockIdx.x * 16 + qi;                 // tile-order slot of the query
+        const int64_t t = g >> 5;
+        const int ql = (int)(g & 31);
+        bool live = t < a.n_tiles;
+        DenseJob job{};
+        if (live) job = a.jobs[a.tile_job[t]];
+        const int lt = (int)(t - job.tile0);
+        live = live && 32 * lt + ql < job.nq;
+        const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;
+        const int64_t row = live ? a.perm[p] : 0;
+        const int nl = live ? job.nc : 0;
+        uint32_t u[8];
+        {
+            uint4 raw = make_uint4(0, 0, 0, 0);
+            if (live && lane * 8 < nl) raw = *reinterpret_cast<const uint4*>(a.ckeys + row * (int64_t)a.stride + lane * 8);
+            const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = (lane * 8 + j < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
+        }
+        const int wnt = min(np, nl);
+        // T = the wnt-th largest u: two histogram levels in LDS (high byte, then the low byte inside the bin that holds it), as in
+        // select16_kernel -- 2 x 8 LDS atomics + two suffix sums over the lanes instead of 17 x 8 compare-and-count steps
+        uint32_t T = 0;
+        if (wnt > 0) {
+            auto level = [&](auto bin_of_key, int kk, int* above) -> int {
+                hist[lane] = 0u; hist[lane + 64] = 0u; hist[lane + 128] = 0u; hist[lane + 192] = 0u; hist[lane + 256] = 0u;
+                wave_lds_sync();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int b = bin_of_key(u[i]);
+                    if (b >= 0) __hip_atomic_fetch_add(&hist[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                wave_lds_sync();
+                uint32_t c[5];                                            // bins 5 lane .. 5 lane + 4
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) c[jj] = hist[5 * lane + jj];
+                const int own = (int)(c[0] + c[1] + c[2] + c[3] + c[4]);
+                int suf = own;                                            // keys in this lane's bins and all higher ones
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(suf, off, 64);
+                    if (lane + off < 64) suf += o;
+                }
+                const unsigned long long reach = __ballot(suf >= kk);     // (a prefix of the lanes: suf falls with the lane)
+                const int L = 63 - __clzll(reach);
+                int acc = suf - own, bin = 5 * lane;
+#pragma unroll
+                for (int jj = 4; jj >= 0; --jj) {
+                    if (acc + (int)c[jj] >= kk) { bin = 5 * lane + jj; break; }
+                    acc += (int)c[jj];
+                }
+                *above = __shfl(acc, L, 64);
+                const int res = __shfl(bin, L, 64);
+                wave_lds_sync();
+                return res;
+            };
+            int above1 = 0, above2 = 0;
+            const int b1 = level([&](uint32_t key) -> int { return key ? (int)min(key >> 8, 255u) : -1; }, wnt, &above1);
+            const int b2 = level([&](uint32_t key) -> int { return (key && (int)min(key >> 8, 255u) == b1) ? (int)key - (b1 << 8) : -1; },
+                                 wnt - above1, &above2);
+            T = (uint32_t)((b1 << 8) + b2);
+        }
+        const float Tv = (float)(max(T, 1u) - 1u) * (1.f / 65535.f);
+        const float e = 1.3e-3f * Tv + 1.2e-5f;
+        const int delta = 2 * ((int)ceilf(e * 65535.f) + 1) + 2;
+        int n_hi = 0, n_mem = 0;
+        uint32_t h = 0, m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int df = (int)u[j] - (int)T;
+            const bool h1 = u[j] != 0u && df > delta;
+            const bool m1 = u[j] != 0u && df <= delta && df >= -delta;
+            h |= h1 ? (1u << j) : 0u;
+            m |= m1 ? (1u << j) : 0u;
+            n_hi += wcnt(h1);
+            n_mem += wcnt(m1);
+        }
+        const int nd = wnt - n_hi;
+        bool ambiguous = wnt > 0 && n_mem > nd;
+        bool handed = false;
+        if (ambiguous && n_mem > kCap) {                                 // too many members for the wave's lists
+            if (lane == 0) {
+                const int at = atomicAdd(a.ovf_count, 1);
+                if (at < a.ovf_cap) a.ovf_list[at] = (int32_t)g;
+            }
+            handed = true;
+            ambiguous = false;
+        }
+        if (lane == 0) {
+            q_cnt[qi] = ambiguous ? n_mem : 0;
+            q_row[qi] = row;
+            q_cbase[qi] = job.c_row0;
+            q_need[qi] = nd;
+            q_nmem[qi] = n_mem;
+            q_want[qi] = wnt;
+            q_pos[qi] = p;
+            q_flag[qi] = ((live && wnt > 0 && !handed) ? 1 : 0) | (ambiguous ? 2 : 0);
+        }
+        s_hi[qi][lane] = (uint8_t)h;
+        s_mem[qi][lane] = (uint8_t)m;
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool m1 = ((m >> j) & 1u) && ambiguous;
+            const unsigned long long gm = __ballot(m1);
+            if (m1) m_id[qi][base + __popcll(gm & lt_mask)] = lane * 8 + j;
+            base += __popcll(gm);
+        }
+        if (live && !handed)
+            for (int i = wnt + lane; i < np; i += 64) a.probes[p * np + i] = -1;
+    }
+    wave_lds_sync();
+    {
+        int off[17];
+        off[0] = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) off[k + 1] = off[k] + q_cnt[k];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int lo = off[8 * half], hi = off[8 * half + 8];
+            if (hi > lo) {                                               // (wave-uniform)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int k = 8 * half + kk;
+                    const bool want = q_cnt[k] > 0;
+                    sp_c[kk][lane] = want ? a.sp_cols[q_row[k] * kSparseW + lane] : kColPad;
+                    sp_v[kk][lane] = want ? a.sp_vals[q_row[k] * kSparseW + lane] : 0.f;
+                }
+                wave_lds_sync();
+                for (int i = lo + lane; i < hi; i += 64) {
+                    int k = 8 * half;
+#pragma unroll
+                    for (int kk = 1; kk < 8; ++kk) k = off[8 * half + kk] <= i ? 8 * half + kk : k;
+                    const int mm = i - off[k];
+                    const float* c = a.C + (q_cbase[k] + m_id[k][mm]) * (int64_t)a.d;
+                    float v;
+                    if (sp_c[k - 8 * half][0] == kColDense) v = exact_dot(a.X + q_row[k] * a.d, c, a.d);
+                    else v = coarse_sparse_chain(sp_c[k - 8 * half], sp_v[k - 8 * half], c);
+                    m_val[k][mm] = v;
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+    wave_lds_sync();
+    for (int qi = 0; qi < 16; ++qi) {
+        const int flag = q_flag[qi];
+        if (!(flag & 1)) continue;                                       // (wave-uniform)
+        uint32_t m = s_mem[qi][lane];
+        const uint32_t h = s_hi[qi][lane];
+        if (flag & 2) {
+            const int nm = q_nmem[qi], need = q_need[qi];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (!((m >> j) & 1u)) continue;
+                const int me = lane * 8 + j;
+                float mine = 0.f;
+                for (int i = 0; i < nm; ++i) mine = m_id[qi][i] == me ? m_val[qi][i] : mine;
+                int rank = 0;
+                for (int i = 0; i < nm; ++i) {
+                    const float v = m_val[qi][i];
+                    const int id = m_id[qi][i];
+                    rank += (v > mine || (v == mine && id < me)) ? 1 : 0;
+                }
+                if (rank >= need) m &= ~(1u << j);
+            }
+        }
+        int32_t* out = a.probes + q_pos[qi] * np;
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool in = ((h | m) >> j) & 1u;
+            const unsigned long long gm = __ballot(in);
+            if (in) out[base + __popcll(gm & lt_mask)] = lane * 8 + j;
+            base += __popcll(gm);
+        }
+    }
+}
+
 __global__ void tile_job_c16_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t n_tiles, int32_t* __restrict__ tile_job) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n_tiles) tile_job[i] = find_job(jobs, n_jobs, i);
@@ -389,7 +587,8 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
         hipLaunchKernelGGL((coarse16w_kernel<8>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL((coarse16_kernel<8, 16>), dim3(list_grid), dim3(256), 0, ctx->stream, a);
     } else {
-        hipLaunchKernelGGL((coarse16w_kernel<32>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+        if (a.sp_cols) hipLaunchKernelGGL(coarse16x_kernel, dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((coarse16w_kernel<32>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL((coarse16_kernel<32, 8>), dim3(list_grid), dim3(128), 0, ctx->stream, a);
     }
     FAL_CHECK_HIP(hipGetLastError());
