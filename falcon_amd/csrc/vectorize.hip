@@ -16,6 +16,8 @@
 //     sqrt and the divide in float64 (both correctly rounded on gfx950; the f32 v_sqrt is not);
 //   * rows leave as 16 B/lane (f32) or 8 B/lane (f16) coalesced stores straight from LDS.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "hash.h"
 
@@ -43,7 +45,7 @@ template <int OUT_F16>
 __global__ __launch_bounds__(64) void vectorize_kernel(
     const float* __restrict__ mz, const float* __restrict__ inten, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out, void* __restrict__ out2) {
+    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out, void* __restrict__ out2, int chunk) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t passes = (d + 255) / 256;
     float* acc = reinterpret_cast<float*>(smem);                 // passes*256 floats
@@ -54,9 +56,46 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
     for (uint32_t i = lane; i < d; i += 64) tag[i] = 0xFFFFFFFFu;
     __syncthreads();
 
-    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const int64_t s = row_order ? row_order[r] : r;
-        const int64_t beg = indptr[s], end = indptr[s + 1];
+    // A wave takes `chunk` CONSECUTIVE output rows at a time: their row_order / indptr entries come by one coalesced load and one
+    // gather for the whole chunk (lane i = row i of the chunk) instead of two dependent round trips per row, and the first 64
+    // peaks of row i + 1 are in flight while row i is hashed and written -- per row the kernel used to wait for a chain of three
+    // dependent loads (order -> indptr -> peaks), which, not the bytes, set its time (0.45 of the HBM roof).
+    for (int64_t c0 = (int64_t)blockIdx.x * chunk; c0 < n; c0 += (int64_t)gridDim.x * chunk) {
+    const int n_rows = (int)min<int64_t>(chunk, n - c0);
+    int64_t beg_l = 0, end_l = 0;
+    if ((int)lane < n_rows) {
+        const int64_t s = row_order ? row_order[c0 + lane] : c0 + lane;
+        beg_l = indptr[s];
+        end_l = indptr[s + 1];
+    }
+    auto row_range = [&](int i, int64_t* b, int64_t* e) {
+        *b = ((int64_t)__builtin_amdgcn_readlane((int)(beg_l >> 32), i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)beg_l, i);
+        *e = ((int64_t)__builtin_amdgcn_readlane((int)(end_l >> 32), i) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)end_l, i);
+    };
+    float mz_n = 0.f, x_n = 0.f;                                 // the next row's first 64 peaks (lane = peak)
+    {
+        int64_t b0, e0;
+        row_range(0, &b0, &e0);
+        if (b0 + lane < e0) {
+            mz_n = mz[b0 + lane];
+            x_n = inten[b0 + lane];
+        }
+    }
+    for (int ri = 0; ri < n_rows; ++ri) {
+        const int64_t r = c0 + ri;
+        int64_t beg, end;
+        row_range(ri, &beg, &end);
+        const float mz_c = mz_n, x_c = x_n;
+        if (ri + 1 < n_rows) {                                   // (uniform)
+            int64_t b1, e1;
+            row_range(ri + 1, &b1, &e1);
+            mz_n = 0.f;
+            x_n = 0.f;
+            if (b1 + lane < e1) {
+                mz_n = mz[b1 + lane];
+                x_n = inten[b1 + lane];
+            }
+        }
         for (int64_t p0 = beg; p0 < end; p0 += 64) {
             const int64_t p = p0 + lane;
             bool pending = false;
@@ -64,8 +103,9 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
             float x = 0.f;
             if (p < end) {
                 int32_t b;
-                x = inten[p];
-                if (bin_of(mz[p], min_mz, bin_size, n_bins, &b)) {
+                const bool first = p0 == beg;                    // (uniform) the prefetched peaks; later chunks of a long spectrum: loaded here
+                x = first ? x_c : inten[p];
+                if (bin_of(first ? mz_c : mz[p], min_mz, bin_size, n_bins, &b)) {
                     pending = true;
                     h = fal::murmur3_32((uint32_t)b, seed) % d;
                 }
@@ -140,6 +180,7 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
         }
         __syncthreads();
     }
+    }
 }
 
 __global__ void to_vector_indices_kernel(const float* __restrict__ mz, int64_t nnz, double min_mz,
@@ -209,24 +250,28 @@ static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity,
     ctx->stage_reset(fal::ST_VECTORIZE);
     const uint32_t passes = (low_dim + 255) / 256;
     const size_t lds = (size_t)(passes * 256 + low_dim) * 4;
-    const int grid = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 32);
+    // rows per wave and turn: 16 at most (measured: 4..16 equal, 64 loses the balance again), fewer while the waves (32 per CU)
+    // would get less than four turns each
+    int chunk = 16;
+    while (chunk > 1 && n / chunk < (int64_t)ctx->num_cus * 32 * 4) chunk >>= 1;
+    const int grid = (int)std::min<int64_t>(fal::ceil_div(n, chunk), (int64_t)ctx->num_cus * 32);
     {
         fal::StageScope t(ctx, fal::ST_VECTORIZE);
         if (out_dtype == -4)
             hipLaunchKernelGGL(vectorize_kernel<4>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
         else if (out_dtype == -3)
             hipLaunchKernelGGL(vectorize_kernel<3>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
         else if (out_dtype == FAL_DTYPE_SPLIT16)
             hipLaunchKernelGGL(vectorize_kernel<2>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
         else if (out_dtype == FAL_DTYPE_F16)
             hipLaunchKernelGGL(vectorize_kernel<1>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
         else
             hipLaunchKernelGGL(vectorize_kernel<0>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2);
+                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
     }
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
