@@ -238,7 +238,8 @@ __global__ __launch_bounds__(64) void centroid_update_kernel(const uint16_t* __r
                                                              const float* __restrict__ X, int d,
                                                              const int32_t* __restrict__ rows_sorted,
                                                              const int64_t* __restrict__ list_off,
-                                                             const BucketDev* __restrict__ bk, int nb, float* __restrict__ C) {
+                                                             const BucketDev* __restrict__ bk, int nb, float* __restrict__ C,
+                                                             __half* __restrict__ C16) {
     __shared__ float acc[FAL_MAX_LOW_DIM];
     const BucketDev b = bk[find_bucket(bk, nb, blockIdx.x)];
     const int li = (int)(blockIdx.x - b.wave0);
@@ -293,10 +294,21 @@ __global__ __launch_bounds__(64) void centroid_update_kernel(const uint16_t* __r
     const double nr = wave_xor_sum_d(part);
     const float inv = nr > 0.0 ? (float)__ddiv_rn(1.0, __dsqrt_rn(nr)) : 0.f;
     float4* o = reinterpret_cast<float4*>(C + (b.list0 + li) * d);
+    uint2* o16 = C16 ? reinterpret_cast<uint2*>(C16 + (b.list0 + li) * d) : nullptr;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int e = 64 * p + lane;
-        if (p < passes && e < d / 4) o[e] = make_float4(r[p].x * inv, r[p].y * inv, r[p].z * inv, r[p].w * inv);
+        if (p < passes && e < d / 4) {
+            const float4 v = make_float4(r[p].x * inv, r[p].y * inv, r[p].z * inv, r[p].w * inv);
+            o[e] = v;
+            if (o16) {                           // the float16 copy the next assignment pass reads (cvt_f16_kernel's rounding)
+                const __half2 a = __floats2half2_rn(v.x, v.y), bb = __floats2half2_rn(v.z, v.w);
+                uint2 pk;
+                pk.x = *reinterpret_cast<const uint32_t*>(&a);
+                pk.y = *reinterpret_cast<const uint32_t*>(&bb);
+                o16[e] = pk;
+            }
+        }
     }
 }
 
@@ -719,7 +731,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         };
         for (int it = 0; it <= kmeans_iters; ++it) {
             if (!hjobs.empty()) {
-                {
+                if (it == 0) {                   // (later passes: centroid_update_kernel writes the float16 copy of what it changes)
                     StageScope ts(ctx, ST_BUILD);
                     B_TRY(launch_cvt_f16(ctx, ivf->centroids, C16, total * low_dim));
                 }
@@ -742,7 +754,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             StageScope ts(ctx, ST_BUILD);
             B_TRY(sort_buckets());
             hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)waves), dim3(64), 0, st, sp_cols, sp_vals, X, low_dim,
-                               ivf->perm, ivf->list_off, bkd, nbk, ivf->centroids);
+                               ivf->perm, ivf->list_off, bkd, nbk, ivf->centroids, reinterpret_cast<__half*>(C16));
             B_HIP(hipGetLastError());
         }
         StageScope ts(ctx, ST_BUILD);
