@@ -561,9 +561,11 @@ def main():
                 big_key = (n_cfg, hi)
             pc = params(**kw)
             ra = (20.0, "ppm", None, 0.05, args.batch_size, pc)
-            steps_c = 3 if chunks == 1 else 2
+            # (five timed steps after three priming passes: with three a single late scratch growth -- a GB-sized hipMalloc of
+            #  one of the two partition contexts -- showed up as + 40 ms on the mean of a 120 ms step)
+            steps_c = 5 if chunks == 1 else 2
             try:
-                dtc = timed(big, ra, steps_c, 1, prime=2, chunks=chunks)
+                dtc = timed(big, ra, steps_c, 1, prime=3 if chunks == 1 else 2, chunks=chunks)
                 sc = None
                 if chunks == 1:
                     sc = summarize(staged(big, ra), pc.low_dim, pc, 2 if name == "f16" else 4)

@@ -54,7 +54,10 @@ def cluster_partition(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
     G = G.maximum(G.T)                                          # sklearn wants a symmetric neighbourhood graph
     from sklearn.neighbors import sort_graph_by_row_values
     G = sort_graph_by_row_values(G.tocsr(), warn_when_not_sorted=False)
-    db = DBSCAN(eps=eps, min_samples=2, metric="precomputed").fit(G).labels_.astype(np.int32)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                         # (sklearn's EfficiencyWarning about row order: timing only)
+        db = DBSCAN(eps=eps, min_samples=2, metric="precomputed").fit(G).labels_.astype(np.int32)
     t["filter_dbscan"] = time.perf_counter() - t0
     labels = np.empty(N, np.int32)
     labels[order] = db
