@@ -1,6 +1,10 @@
 #!/bin/bash
-# A/B proof for the assign_kernel DMA race: round 3's library (tools/ab/libfalcon_hip_r3.so, kept out of history) against
-# the current build, under second-stream HBM traffic at low_dim 64 and 128.  Output: gpurun_out/stress_ab.txt
+# A/B proof for the assign_kernel DMA race: round 3's library against the current build, under second-stream HBM traffic at
+# low_dim 64 and 128.  Output: gpurun_out/stress_ab.txt (the run of round 4: profiles/r4_stress_ab.txt).
+# The old library is not kept in the tree; rebuild it with
+#   mkdir -p /tmp/r3src tools/ab && git archive 22c84f5 falcon_amd/csrc include | tar -x -C /tmp/r3src &&
+#   make -C /tmp/r3src/falcon_amd/csrc -j8 && cp /tmp/r3src/falcon_amd/libfalcon_hip.so tools/ab/libfalcon_hip_r3.so
+# (without it the script runs the current build only).
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/stress_ab.txt
 : > $O
