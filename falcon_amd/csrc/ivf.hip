@@ -763,8 +763,12 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         // them; the default path -- coarse quantiser from the build's keys, float16 prefilter -- does not: 16 GB at 10 M spectra)
         ivf->Xl = nullptr;
     } else {
-        hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, ivf->counts, total, ivf->list_off);
-        B_HIP(hipGetLastError());
+        // every bucket is flat: the list offsets ARE the bucket offsets -- known on the host, uploaded, no kernel (a one-workgroup
+        // scan here sat 585 us in the two-stream trace of the headline, waiting for a CU behind the other partition's matrix kernel)
+        std::vector<int64_t> off_host((size_t)total + 1, 0);
+        for (int64_t b = 0; b < n_buckets; ++b) off_host[(size_t)ivf->list_base[b] + 1] = bucket_off[b + 1];
+        for (int64_t g = 1; g <= total; ++g) off_host[(size_t)g] = std::max(off_host[(size_t)g], off_host[(size_t)g - 1]);
+        B_TRY(ctx->upload(ivf->list_off, off_host.data(), sizeof(int64_t) * (size_t)(total + 1)));
         ivf->Xl = X;
     }
     B_HIP(hipGetLastError());
