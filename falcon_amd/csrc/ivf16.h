@@ -33,6 +33,7 @@ struct Select16Args {
     int n_jobs;
     int64_t tile_begin;
     const int32_t* tile_job;     // (filled by launch_select16)
+    const int32_t* tile_p0;      // (filled by launch_select16) list-order position of a tile's first query
     const int64_t* q_sim_off;
     const int32_t* perm;
     QThr* thr;                   // hand-off (fused.h), by sorted row

@@ -31,6 +31,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "scan.h"
 #include "ivf.h"
@@ -270,94 +271,229 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wcount(bool p) { return __popcll(__ballot(p)); }
 
-// One query: its keys sit in registers (R per lane), u = key + 1 (0 = no key).
-//  1. T = the k-th largest u (bitwise search, ballot counts);  e = bound of |key / 65535 - exact| around T, in key units
+constexpr int kSelect16Copies = 1;       // copies of the high-byte histogram (select16_body)
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t x, uint32_t y) {           // two 16-bit lanes, wrapping
+    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, x) - __builtin_bit_cast(ushort2v, y)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, x) + __builtin_bit_cast(ushort2v, y)));
+}
+// (inline asm: hipcc has no packed selection for the saturating subtraction and turns min(sat(x - y), 1) into two compares, two
+// selects and a byte permute per word)
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t x, uint32_t y) {       // max(x - y, 0) per 16-bit lane
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t x, uint32_t y) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t x, uint32_t y) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// minimum over the 64 lanes (non-negative values), DPP network as in wave_prefix_sum
+__device__ __forceinline__ int wave_min(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x111, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x112, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x114, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x118, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x142, 0xA, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum over the 64 lanes on the DPP network (no LDS traffic): Hillis-Steele inside the rows of 16, then the
+// row totals handed up (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
+__device__ __forceinline__ int wave_prefix_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);            // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);            // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);            // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);            // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);            // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);            // row_bcast:31
+    return v;
+}
+
+// A value loaded early and needed late: the empty asm is its first use, so hipcc's wait for the load sits HERE and not where its
+// scheduler would have hoisted the first arithmetic on it (right behind the load, in front of every later load).
+__device__ __forceinline__ int late_use(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// One query: its keys stay PACKED, two 16-bit keys per register (R keys = R / 2 registers per lane), and are counted with the
+// packed 16-bit VALU operations; slots outside the query's stream hold key 0 ("pads": they sit below every rank that is asked
+// for -- nc > k -- and are taken out of the one count they can enter).  The first version unpacked every key into its own
+// register and tested its position per key: 44 VALU instructions per key and the kernel was VALU-bound.
+//  1. T = the k-th largest key (two 256-bin histogram levels in LDS);  e = bound of |key / 65535 - exact| around T, in key units
 //  2. thresholds for the exact tail: [L, U] holds the exact k-th best similarity; n_hi = keys certainly above U
 //  3. "members": the keys within 2e of T, as (value, stream position) -- resolve_kernel turns the positions into rows for the
-//     few queries that turn out to have an ambiguous window candidate (no probe table / list offsets / perm gathers here: the
-//     kernel is bound by the latency of its dependent loads)
+//     few queries that turn out to have an ambiguous window candidate (no probe table / list offsets / perm gathers here)
 template <int R>
 __device__ __forceinline__ void select16_body(const Select16Args& a, const uint16_t* __restrict__ row, int nc, int k, int lane,
-                                              int64_t out_row, uint32_t* hist) {
-    // Keys in 16-byte pieces (8 per load instruction and lane; a 2-byte load per key made the kernel wait for its R load
-    // instructions): the stream is read from the 16-byte boundary in front of it, `lead` keys early; key t of piece (j, lane) is
-    // stream position 8 (64 j + lane) + t - lead.
-    uint32_t u[R];
-    const int lead = (int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1);
-    auto pos_of = [&](int i) -> int { return 8 * (64 * (i >> 3) + lane) + (i & 7) - lead; };
+                                              int out_row_loaded, uint32_t* hist) {
+    constexpr int P = R / 8, W = R / 2;
+    // Keys in 16-byte pieces (8 per load instruction and lane): the stream is read from the 16-byte boundary in front of it,
+    // `lead` keys early; key t of piece (j, lane) is stream position 8 (64 j + lane) + t - lead; word 4 j + m holds t = 2 m
+    // (low half) and 2 m + 1.
+    nc = __builtin_amdgcn_readfirstlane(nc);                                // (one query per wave: the masks below are scalar work)
+    const int lead = __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1));
+    const int span = nc + lead;
+    uint32_t w[W];
     {
-        const uint4* base = reinterpret_cast<const uint4*>(reinterpret_cast<uintptr_t>(row) & ~(uintptr_t)15);
-        uint4 raw[R / 8];
+        const uint4* base = reinterpret_cast<const uint4*>(row - lead);
+        uint4 raw[P];
 #pragma unroll
-        for (int j = 0; j < R / 8; ++j) raw[j] = base[64 * j + lane];       // unclamped: the buffer has kSimsSlack floats of slack
+        for (int j = 0; j < P; ++j) raw[j] = base[64 * j + lane];           // unclamped: the buffer has kSimsSlack floats of slack
 #pragma unroll
-        for (int j = 0; j < R / 8; ++j) {
-            const uint32_t wv[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+        for (int j = 0; j < P; ++j) { w[4 * j] = raw[j].x; w[4 * j + 1] = raw[j].y; w[4 * j + 2] = raw[j].z; w[4 * j + 3] = raw[j].w; }
+        // pads -> 0.  Behind the stream: piece p = 64 j + lane is whole for p < span / 8, holds span % 8 keys for p == span / 8
+        // (both wave-uniform per group), nothing behind; in front: the first `lead` keys of piece 0.
+        const int q_all = span >> 3, r = span & 7;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int pos = pos_of(8 * j + t);
-                u[8 * j + t] = (pos >= 0 && pos < nc) ? ((wv[t >> 1] >> (16 * (t & 1))) & 0xFFFFu) + 1u : 0u;
+        for (int j = 0; j < P; ++j) {
+            const int q = q_all - 64 * j;
+            if (q < 64) {                                                    // wave-uniform (one group per query, two with R = 64)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint32_t part = (2 * m < r ? 0xFFFFu : 0u) | (2 * m + 1 < r ? 0xFFFF0000u : 0u);
+                    w[4 * j + m] &= lane < q ? 0xFFFFFFFFu : (lane == q ? part : 0u);
+                }
+            }
+        }
+        if (lead) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint32_t keep = (2 * m >= lead ? 0xFFFFu : 0u) | (2 * m + 1 >= lead ? 0xFFFF0000u : 0u);
+                w[m] &= lane == 0 ? keep : 0xFFFFFFFFu;
             }
         }
     }
-    // T = the k-th largest key (nc > k, so T >= 1).  Two histogram levels in LDS -- 256 bins of the key's high byte, then the
-    // low byte inside the bin that holds the k-th key -- instead of a bitwise search with R ballot counts per bit (17 x R
-    // compare + count + add against 2 x R LDS atomics and two suffix sums over the lanes).
+    const int n_pads = 64 * R - nc;
+    auto pos_of = [&](int i) -> int { return 8 * (64 * (i >> 3) + lane) + (i & 7) - lead; };
+    // T = the k-th largest key (nc > k).  Two histogram levels in LDS -- 256 bins of the key's high byte, then the low byte
+    // inside the bin that holds the k-th key; after the atomics: bins 4 lane .. 4 lane + 3 per lane, suffix sums over the lanes.
     uint32_t T;
     {
-        auto level = [&](auto bin_of_key, int kk, int* above) -> int {        // -> bin of the kk-th largest, *above = keys in higher bins
-            hist[lane] = 0u; hist[lane + 64] = 0u; hist[lane + 128] = 0u; hist[lane + 192] = 0u; hist[lane + 256] = 0u;
+        // C copies of every bin (copy = lane % C, a bin's copies side by side): the keys of a query crowd into a few bins of
+        // the high byte (most similarities are small), and LDS atomics of one instruction to ONE address are taken one after
+        // the other -- with a single copy they were all of the kernel's time.
+        auto clear = [&](auto copies) {
+            constexpr int C = decltype(copies)::value;
+#pragma unroll
+            for (int q = 0; q < C; ++q) *reinterpret_cast<uint4*>(&hist[4 * (C * lane + q)]) = make_uint4(0u, 0u, 0u, 0u);
             wave_lds_sync();
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                const int b = bin_of_key(u[i]);
-                if (b >= 0) __hip_atomic_fetch_add(&hist[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+        };
+        auto find = [&](auto copies, int kk, int* above) -> int {           // -> bin of the kk-th largest, *above = keys in higher bins
+            constexpr int C = decltype(copies)::value;
             wave_lds_sync();
-            uint32_t c[5];                                                    // bins 5 lane .. 5 lane + 4
+            int c[4];                                                         // bins 4 lane .. 4 lane + 3
 #pragma unroll
-            for (int j = 0; j < 5; ++j) c[j] = hist[5 * lane + j];
-            const int own = (int)(c[0] + c[1] + c[2] + c[3] + c[4]);
-            int suf = own;                                                    // keys in this lane's bins and all higher ones
+            for (int j = 0; j < 4; ++j) {
+                c[j] = 0;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_down(suf, off, 64);
-                if (lane + off < 64) suf += o;
+                for (int q = 0; q < C; q += (C >= 4 ? 4 : C)) {
+                    if (C >= 4) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(&hist[(4 * lane + j) * C + q]);
+                        c[j] += (int)(v.x + v.y + v.z + v.w);
+                    } else if (C == 2) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(&hist[(4 * lane + j) * C + q]);
+                        c[j] += (int)(v.x + v.y);
+                    } else c[j] += (int)hist[4 * lane + j];
+                }
             }
+            const int own = c[0] + c[1] + c[2] + c[3];
+            const int pre = wave_prefix_sum(own);
+            const int suf = __builtin_amdgcn_readlane(pre, 63) - pre + own;   // keys in this lane's bins and all higher ones
             const unsigned long long reach = __ballot(suf >= kk);             // (a prefix of the lanes: suf falls with the lane)
             const int L = 63 - __clzll(reach);
-            int acc = suf - own, bin = 5 * lane;
+            int acc = suf - own, bin = 4 * lane;
 #pragma unroll
-            for (int j = 4; j >= 0; --j) {
-                if (acc + (int)c[j] >= kk) { bin = 5 * lane + j; break; }
-                acc += (int)c[j];
+            for (int j = 3; j >= 0; --j) {
+                if (acc + c[j] >= kk) { bin = 4 * lane + j; break; }
+                acc += c[j];
             }
-            *above = __shfl(acc, L, 64);
-            const int res = __shfl(bin, L, 64);
+            *above = __builtin_amdgcn_readlane(acc, L);
+            const int res = __builtin_amdgcn_readlane(bin, L);
             wave_lds_sync();
             return res;
         };
+        constexpr int C1 = kSelect16Copies;
+        const std::integral_constant<int, C1> many{};
+        const std::integral_constant<int, 1> one{};
         int above1 = 0, above2 = 0;
-        const int b1 = level([&](uint32_t key) -> int { return key ? (int)min(key >> 8, 255u) : -1; }, k, &above1);
-        const int b2 = level([&](uint32_t key) -> int { return (key && (int)min(key >> 8, 255u) == b1) ? (int)key - (b1 << 8) : -1; },
-                             k - above1, &above2);
-        T = (uint32_t)((b1 << 8) + b2);
+        clear(many);
+        // A lower bound of T first, so that the crowd of small keys stays out of the histogram: every lane's second largest
+        // key has two keys of that lane at or above it, so the smallest of the 64 has 128 >= k (packed running top-2 per
+        // 16-bit half, then across the halves and, on the DPP network, across the lanes).
+        uint32_t LB = 0u;
+        if (k <= 128) {
+            uint32_t m1 = 0u, m2 = 0u;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                const uint32_t t = pk_min(m1, w[i]);
+                m1 = pk_max(m1, w[i]);
+                m2 = pk_max(m2, t);
+            }
+            const uint32_t a1 = m1 & 0xFFFFu, b1h = m1 >> 16, a2 = m2 & 0xFFFFu, b2 = m2 >> 16;
+            LB = (uint32_t)wave_min((int)max(min(a1, b1h), max(a2, b2)));
+        }
+        uint32_t* mine = hist + (lane & (C1 - 1));
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            if ((w[i] & 0xFFFFu) >= LB)
+                __hip_atomic_fetch_add(&mine[((w[i] >> 8) & 0xFFu) * C1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((w[i] >> 16) >= LB)
+                __hip_atomic_fetch_add(&mine[(w[i] >> 24) * C1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const int b1 = find(many, k, &above1);
+        clear(one);
+        const uint32_t pat = (uint32_t)b1 * 0x01000100u;
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            const uint32_t x = w[i] ^ pat;                                    // a key of bin b1: its high byte is 0 now
+            const bool lo = (x & 0xFF00u) == 0u, hi = x < 0x01000000u;
+            if (__ballot(lo || hi)) {                                         // wave-uniform; the bin holds a few keys of the query
+                if (lo) __hip_atomic_fetch_add(&hist[x & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hi) __hip_atomic_fetch_add(&hist[(x >> 16) & 0xFFu], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        const int b2 = find(one, k - above1, &above2);
+        T = (uint32_t)((b1 << 8) + b2);                                      // (as a key; the hand-off counts in key + 1)
     }
-    const float Tv = (float)(T - 1u) * (1.f / 65535.f);
+    const float Tv = (float)T * (1.f / 65535.f);
     const float e = 1.3e-3f * Tv + 1.2e-5f;
     const int delta_e = (int)ceilf(e * 65535.f) + 1;
     const int delta = 2 * delta_e + 2;
-    int n_hi = 0, n_mem = 0;
+    // n_hi = keys > T + delta; members = keys in [T - delta, T + delta]: per word  min(sat(x - hi), 1)  and, with y = x - lo
+    // (wrapping: keys below lo turn large),  f = min(sat(y - (hi - lo)), 1) = 1 for keys OUTSIDE the range
+    const uint32_t c_hi = (uint32_t)min((int)T + delta, 65535) * 0x00010001u;
+    const int lo_key = max((int)T - delta, 0);
+    const uint32_t c_lo = (uint32_t)lo_key * 0x00010001u;
+    const uint32_t c_w = c_hi - c_lo;                                        // (no borrow between the halves: hi >= lo)
+    uint32_t f[W], acc_hi = 0u, acc_out = 0u;
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        n_hi += wcount(u[i] > T + (uint32_t)delta);
-        const int df = (int)u[i] - (int)T;
-        n_mem += wcount(u[i] != 0u && df <= delta && df >= -delta);
+    for (int i = 0; i < W; ++i) {
+        acc_hi = pk_add(acc_hi, pk_min(pk_sub_sat(w[i], c_hi), 0x00010001u));
+        f[i] = pk_min(pk_sub_sat(pk_sub(w[i], c_lo), c_w), 0x00010001u);
+        acc_out = pk_add(acc_out, f[i]);
     }
+    int n_hi, n_mem;
+    {
+        const int both = (int)((acc_hi & 0xFFFFu) + (acc_hi >> 16)) | ((int)((acc_out & 0xFFFFu) + (acc_out >> 16)) << 16);
+        const int tot = __builtin_amdgcn_readlane(wave_prefix_sum(both), 63);      // (each sum <= 64 R <= 4,096)
+        n_hi = tot & 0xFFFF;
+        n_mem = 64 * R - (tot >> 16) - (lo_key == 0 ? n_pads : 0);          // pads (key 0) are inside the range iff it reaches 0
+    }
+    const int64_t out_row = late_use(out_row_loaded);
     QThr t;
     t.T = Tv;
-    t.L = ((float)(T - 1u) - (float)delta_e) * (1.f / 65535.f);
-    t.U = ((float)(T - 1u) + (float)delta_e) * (1.f / 65535.f);
+    t.L = ((float)T - (float)delta_e) * (1.f / 65535.f);
+    t.U = ((float)T + (float)delta_e) * (1.f / 65535.f);
     t.eps = 0.5f * ((float)delta + 0.5f) * (1.f / 65535.f);     // resolve_kernel: members are |v - T| <= 2 eps
     t.bstar = 1 << 30;                                           // (no histogram bins here: nothing "above the bin")
     t.nabove = n_hi;
@@ -369,29 +505,33 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
     t.mc = min(n_mem, FAL_FUSED_MEM / 2) | (max(n_mem - FAL_FUSED_MEM / 2, 0) << 16);
     if (lane == 0) {
         a.thr[out_row] = t;
-        if (a.gsel) a.gsel[out_row] = make_int2((int)T - delta, (int)T + delta);
+        if (a.gsel) a.gsel[out_row] = make_int2((int)T + 1 - delta, (int)T + 1 + delta);
     }
     if (n_mem == 0) return;
     float* gv = a.gmem_v + out_row * FAL_FUSED_MEM;
     uint32_t* gi = a.gmem_id + out_row * FAL_FUSED_MEM;
     int base = 0;
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int df = (int)u[i] - (int)T;
-        const bool in = u[i] != 0u && df <= delta && df >= -delta;
-        const unsigned long long mask = __ballot(in);
-        if (mask) {                                              // wave-uniform
-            if (in) {
-                const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-                gv[slot] = (float)(u[i] - 1u) * (1.f / 65535.f);
-                gi[slot] = (uint32_t)pos_of(i);                  // stream position (resolve_kernel: -> row)
+    for (int i = 0; i < W; ++i) {
+        if (__ballot(f[i] != 0x00010001u)) {                     // wave-uniform: some lane holds a member in this word
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int slot_i = 8 * (i >> 2) + 2 * (i & 3) + h, pos = pos_of(slot_i);
+                const bool in = ((f[i] >> (16 * h)) & 0xFFFFu) == 0u && pos >= 0 && pos < nc;
+                const unsigned long long mask = __ballot(in);
+                if (in) {
+                    const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    gv[slot] = (float)((w[i] >> (16 * h)) & 0xFFFFu) * (1.f / 65535.f);
+                    gi[slot] = (uint32_t)pos;                    // stream position (resolve_kernel: -> row)
+                }
+                base += __popcll(mask);
             }
-            base += __popcll(mask);
         }
     }
 }
 
-__device__ __forceinline__ void select16_trivial(const Select16Args& a, int64_t out_row, int flags, int lane) {
+__device__ __forceinline__ void select16_trivial(const Select16Args& a, int out_row_loaded, int flags, int lane) {
+    const int64_t out_row = late_use(out_row_loaded);
     if (lane == 0) {
         QThr t0{};
         t0.L = t0.U = -INFINITY;
@@ -409,7 +549,7 @@ __device__ __forceinline__ void select16_trivial(const Select16Args& a, int64_t 
 // the common n_probe = 16 case at its register count
 template <bool BIG, bool WIDE>
 __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
-    __shared__ uint32_t hist_all[4][320];                        // a wave's key histogram (select16_body)
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][256 * kSelect16Copies];      // a wave's key histogram (select16_body)
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* hist = hist_all[w];
     const int n_big = BIG ? min(*a.big_count, a.big_cap) : 0;
@@ -422,13 +562,14 @@ __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
             slot = 32 * a.tile_begin + item;
             if (item >= 32 * a.n_tiles) return;
         }
+        // Two round trips in front of the keys, not five: the offsets and the tile's first list-order position (one table entry,
+        // tile_job16_kernel) travel together, then perm[p] next to the key loads (it is needed for the stores only).
+        const int64_t t = slot >> 5;
         const int64_t o0 = a.q_sim_off[slot], o1 = a.q_sim_off[slot + 1];
+        const int32_t p0 = late_use(a.tile_p0[t - a.tile_begin]);            // (used here: hipcc would sink the load behind the wait for o0)
         const int nc = (int)(o1 - o0);
         if (nc > 0) {                                            // (0: padding slot of a bucket's last tile)
-            const int64_t t = slot >> 5;
-            const DenseJob job = a.jobs[a.tile_job[t - a.tile_begin]];
-            const int64_t p = job.q_row0 + 32 * (t - job.tile0) + (slot & 31);      // query position in list order
-            const int64_t out_row = a.perm[p];
+            const int out_row = a.perm[(int64_t)p0 + (slot & 31)];           // query position in list order -> sorted row; used late
             const uint16_t* row = a.keys + (o0 - a.keys_base);
             const int k = a.k;
             const int span = nc + (int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1);      // keys from the 16-byte boundary in front
@@ -453,9 +594,13 @@ __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
 }
 
 __global__ void tile_job16_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t tile_begin, int64_t n_tiles,
-                                  int32_t* __restrict__ tile_job) {
+                                  int32_t* __restrict__ tile_job, int32_t* __restrict__ tile_p0) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n_tiles) tile_job[i] = find_job(jobs, n_jobs, tile_begin + i);
+    if (i < n_tiles) {
+        const int j = find_job(jobs, n_jobs, tile_begin + i);
+        tile_job[i] = j;
+        tile_p0[i] = (int32_t)(jobs[j].q_row0 + 32 * (tile_begin + i - jobs[j].tile0));      // list-order position of the tile's query 0
+    }
 }
 
 // pos_of_row[perm[p]] = p
@@ -504,16 +649,18 @@ int launch_select16(fal_ctx* ctx, const Select16Args& a_in, int64_t n_tiles) {
     // tile -> job table, then the list of queries with more than 2,048 keys (count in front)
     int32_t* tj = nullptr;
     ctx->release(SLOT_TILEJOB);        // a launcher-local table: the previous launcher's pointer is dead
-    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(n_tiles, 1 << 16) + 32 * n_tiles + 64), (void**)&tj));
+    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(n_tiles, 1 << 16) + 33 * n_tiles + 64), (void**)&tj));
     a.big_count = tj + std::max<int64_t>(n_tiles, 1 << 16);
     a.big_list = a.big_count + 16;
+    int32_t* tp0 = a.big_list + 32 * n_tiles;
     a.big_cap = (int)std::min<int64_t>(32 * n_tiles, INT32_MAX);
     FAL_REQUIRE(n_tiles * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
     StageScope ts(ctx, ST_SELECT);
     FAL_CHECK_HIP(hipMemsetAsync(a.big_count, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(tile_job16_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
-                       a.tile_begin, n_tiles, tj);
+                       a.tile_begin, n_tiles, tj, tp0);
     a.tile_job = tj;
+    a.tile_p0 = tp0;
     if (a.max_keys > 2048) hipLaunchKernelGGL((select16_kernel<false, true>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL((select16_kernel<false, false>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
     if (a.max_keys > 2048)
