@@ -20,6 +20,7 @@ namespace fal {
 
 // total candidates of each query = sum of the sizes of its probed lists (0 where probes are -1),
 // stored at the query's TILE-ORDER slot 32 * tile + lane (unused lanes of a last tile stay 0)
+template <int NPV>      // probes per query / 4 loaded as 16-byte pieces in front of the list-size gathers (0: any n_probe)
 __global__ void probe_totals_kernel(const int32_t* __restrict__ probes, int np, const DenseJob* __restrict__ jobs,
                                     int n_jobs, int64_t n_tiles, const int64_t* __restrict__ list_off,
                                     int64_t* __restrict__ totals) {
@@ -31,9 +32,26 @@ __global__ void probe_totals_kernel(const int32_t* __restrict__ probes, int np, 
         const int lt = (int)(t - job.tile0), ql = (int)(g & 31);
         if (32 * lt + ql < job.nq) {
             const int64_t p = job.q_row0 + 32 * (int64_t)lt + ql;
-            for (int j = 0; j < np; ++j) {
-                const int l = probes[p * np + j];
-                if (l >= 0) tot += list_off[job.c_row0 + l + 1] - list_off[job.c_row0 + l];
+            const int64_t* lo = list_off + job.c_row0;
+            if (NPV > 0) {
+                int4 pr[NPV > 0 ? NPV : 1];
+                const int4* src = reinterpret_cast<const int4*>(probes + p * np);
+#pragma unroll
+                for (int v = 0; v < NPV; ++v) pr[v] = src[v];
+                int64_t part[NPV > 0 ? 4 * NPV : 1];
+#pragma unroll
+                for (int v = 0; v < NPV; ++v) {
+                    const int l[4] = {pr[v].x, pr[v].y, pr[v].z, pr[v].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) part[4 * v + c] = l[c] >= 0 ? lo[l[c] + 1] - lo[l[c]] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4 * NPV; ++j) tot += part[j];
+            } else {
+                for (int j = 0; j < np; ++j) {
+                    const int l = probes[p * np + j];
+                    if (l >= 0) tot += lo[l + 1] - lo[l];
+                }
             }
             totals[g] = tot;      // slot g = 32 * tile + lane (tile order, padded)
         }
@@ -117,6 +135,10 @@ __global__ __launch_bounds__(1024) void probe_hist_bucket_kernel(const int32_t* 
 // bucket walks the bucket's queries chunk by chunk, cursors in LDS.  The fine-scan kernels stream a list's queries in table
 // order; the ~64 lists of a bucket that run concurrently on an XCD then sweep the bucket's rows together and share them in L2
 // (with the arrival order of global atomics the gathers came from HBM: 4.2 TB/s for 128 GB at 10 M spectra).
+// Nothing the scatter of a query needs is loaded inside its probe loop: the bucket's list sizes and table offsets sit in LDS,
+// the query's probes arrive as 16-byte pieces before the first of them is used (the first version paid three dependent global
+// round trips per probe: probe -> list_off pair / inv_off, 32 times per query and chunk).
+template <int NPV>      // probes per query / 4 held in registers (0: any n_probe, the plain loop)
 __global__ __launch_bounds__(1024) void probe_scatter_bucket_kernel(const int32_t* __restrict__ probes, int np,
                                                                     const DenseJob* __restrict__ jobs,
                                                                     const int64_t* __restrict__ list_off,
@@ -124,25 +146,40 @@ __global__ __launch_bounds__(1024) void probe_scatter_bucket_kernel(const int32_
                                                                     const int64_t* __restrict__ inv_off, int32_t* __restrict__ inv_q,
                                                                     int64_t* __restrict__ inv_dest, const int32_t* __restrict__ perm,
                                                                     int32_t* __restrict__ inv_row) {
-    extern __shared__ int32_t cur[];                         // entries written so far, per list of the bucket
+    extern __shared__ int64_t lds64[];
     const DenseJob job = jobs[blockIdx.x];
     const int nl = job.nc;
-    for (int i = threadIdx.x; i < nl; i += blockDim.x) cur[i] = 0;
+    int64_t* at = lds64;                                     // [nl] where the list's next table entry goes
+    int32_t* len = reinterpret_cast<int32_t*>(lds64 + nl);   // [nl] rows of the list
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+        const int64_t b = list_off[job.c_row0 + i], e = list_off[job.c_row0 + i + 1];
+        len[i] = (int32_t)(e - b);
+        at[i] = inv_off[job.c_row0 + i];
+    }
     __syncthreads();
     for (int q0 = 0; q0 < job.nq; q0 += blockDim.x) {
         const int ql = q0 + threadIdx.x;
         if (ql < job.nq) {
             const int64_t p = job.q_row0 + ql;
             int64_t dest = q_sim_off[32 * (job.tile0 + (ql >> 5)) + (ql & 31)];
-            for (int j = 0; j < np; ++j) {
-                const int l = probes[p * np + j];
-                if (l < 0) continue;
-                const int64_t G = job.c_row0 + l;
-                const int64_t e = inv_off[G] + atomicAdd(&cur[l], 1);
+            const int32_t row = inv_row ? perm[p] : 0;       // (the f16 list scan gathers its queries by sorted row)
+            auto put = [&](int l) {
+                if (l < 0) return;
+                const int64_t e = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(&at[l]), 1ull);
                 inv_q[e] = (int32_t)p;
                 inv_dest[e] = dest;
-                if (inv_row) inv_row[e] = perm[p];           // (the f16 list scan gathers its queries by sorted row)
-                dest += list_off[G + 1] - list_off[G];
+                if (inv_row) inv_row[e] = row;
+                dest += len[l];
+            };
+            if (NPV > 0) {
+                int4 pr[NPV > 0 ? NPV : 1];
+                const int4* src = reinterpret_cast<const int4*>(probes + p * np);
+#pragma unroll
+                for (int v = 0; v < NPV; ++v) pr[v] = src[v];
+#pragma unroll
+                for (int v = 0; v < NPV; ++v) { put(pr[v].x); put(pr[v].y); put(pr[v].z); put(pr[v].w); }
+            } else {
+                for (int j = 0; j < np; ++j) put(probes[p * np + j]);
             }
         }
         __syncthreads();                                     // chunk after chunk: the order inside a list follows the queries
@@ -464,8 +501,16 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     }
     {
         StageScope ts(ctx, ST_COARSE);
-        hipLaunchKernelGGL(probe_totals_kernel, dim3((unsigned)ceil_div(n_slots, 256)), dim3(256), 0, st, probes, np,
-                           coarse_dev, (int)coarse.size(), ivf_tiles, ivf->list_off, totals);
+        const dim3 tg((unsigned)ceil_div(n_slots, 256));
+        if (np == 16)
+            hipLaunchKernelGGL(probe_totals_kernel<4>, tg, dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(), ivf_tiles,
+                               ivf->list_off, totals);
+        else if (np == 32)
+            hipLaunchKernelGGL(probe_totals_kernel<8>, tg, dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(), ivf_tiles,
+                               ivf->list_off, totals);
+        else
+            hipLaunchKernelGGL(probe_totals_kernel<0>, tg, dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(), ivf_tiles,
+                               ivf->list_off, totals);
         FAL_TRY(device_scan_i64(ctx, totals, n_slots, q_sim_off, SLOT_MISC2));      // (millions of slots: multi-block)
     }
     // fine-scan tiles: groups of four 32-row list slices for the 4-wave shared-stream kernels (ivf_fine.hip, ivf16.hip)
@@ -499,10 +544,19 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         const dim3 tg((unsigned)std::min<int64_t>(ceil_div(TL, 256), 1024));
         hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, group_shift, ltiles);
         FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
-        if (max_n_list <= 16384)
-            hipLaunchKernelGGL(probe_scatter_bucket_kernel, dim3((unsigned)coarse.size()), dim3(1024), sizeof(int32_t) * (size_t)max_n_list,
-                               st, probes, np, coarse_dev, ivf->list_off, q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
-        else
+        if (max_n_list <= 16384) {
+            const size_t lds = (sizeof(int64_t) + sizeof(int32_t)) * (size_t)max_n_list;
+            const dim3 sg((unsigned)coarse.size());
+            if (np == 16)
+                hipLaunchKernelGGL(probe_scatter_bucket_kernel<4>, sg, dim3(1024), lds, st, probes, np, coarse_dev, ivf->list_off,
+                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
+            else if (np == 32)
+                hipLaunchKernelGGL(probe_scatter_bucket_kernel<8>, sg, dim3(1024), lds, st, probes, np, coarse_dev, ivf->list_off,
+                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
+            else
+                hipLaunchKernelGGL(probe_scatter_bucket_kernel<0>, sg, dim3(1024), lds, st, probes, np, coarse_dev, ivf->list_off,
+                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
+        } else
             hipLaunchKernelGGL(probe_scatter_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
                                ivf_tiles, ivf->list_off, q_sim_off, inv_off, cursor, inv_q, inv_dest);
     }

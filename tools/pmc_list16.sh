@@ -8,12 +8,14 @@ export PYTHONPATH=$R
 RX=${1:-list16_kernel}; shift
 ARGS=${@:-10000000}
 i=0
+NG=${NGRP:-5}
 for grp in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" \
   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAVES SQ_INST_CYCLES_VMEM_WR" \
   "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_RD" \
   "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum" ; do
+  [ $i -ge $NG ] && break
   rm -rf /tmp/pl_$i
   timeout 600 rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "$RX" -d /tmp/pl_$i -o c -- python3 $R/tools/scale_run.py $ARGS > /tmp/pl_$i.txt 2>&1
   tail -1 /tmp/pl_$i.txt | cut -c1-120
