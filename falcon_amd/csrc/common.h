@@ -153,6 +153,38 @@ __device__ __forceinline__ void wave_lds_sync() {
     asm volatile("" ::: "memory");
 }
 
+// ---- reductions over the 64 lanes on the DPP network (VALU only: no ds_bpermute, no LDS round trip per step) ----------------
+// Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then the row results handed up: row_bcast15 into rows 1 and 3,
+// row_bcast31 into rows 2 and 3.  Lane L ends with the reduction of lanes 0 .. L; lane 63 with the whole wave's.
+#define FAL_DPP_SCAN(v, OP, IDENT)                                                                  \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x111, 0xF, 0xF, false));                       \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x112, 0xF, 0xF, false));                       \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x114, 0xF, 0xF, false));                       \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x118, 0xF, 0xF, false));                       \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x142, 0xA, 0xF, false));                       \
+    v = OP(v, __builtin_amdgcn_update_dpp(IDENT, v, 0x143, 0xC, 0xF, false));
+__device__ __forceinline__ int fal_add_i(int a, int b) { return a + b; }
+__device__ __forceinline__ int fal_min_i(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int fal_max_i(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_prefix_sum(int v) {         // inclusive prefix sum over the lanes
+    FAL_DPP_SCAN(v, fal_add_i, 0)
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {                // (signed compare: callers pass values below 2^31)
+    FAL_DPP_SCAN(v, fal_min_i, 0x7FFFFFFF)
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t u) {  // unsigned, any value: order-preserving flip into the signed range
+    int v = (int)(u ^ 0x80000000u);
+    FAL_DPP_SCAN(v, fal_min_i, 0x7FFFFFFF)
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63) ^ 0x80000000u;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t u) {
+    int v = (int)(u ^ 0x80000000u);
+    FAL_DPP_SCAN(v, fal_max_i, (int)0x80000000)
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63) ^ 0x80000000u;
+}
+
 // Workgroup barrier behind LDS-DMA (`global_load_lds`): s_barrier does not wait for a wave's outstanding DMA, and hipcc's own
 // s_waitcnt insertion for the builtin lost the wait on a loop back-edge (round 3, assign.hip).  Every wave drains its vector
 // memory queue, then arrives: past the barrier every wave's DMA issued before it has landed in LDS.

@@ -296,28 +296,6 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t x, uint32_t y) {
     asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
-// minimum over the 64 lanes (non-negative values), DPP network as in wave_prefix_sum
-__device__ __forceinline__ int wave_min(int v) {
-    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x111, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x112, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x114, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x118, 0xF, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x142, 0xA, 0xF, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, 0x143, 0xC, 0xF, false));
-    return __builtin_amdgcn_readlane(v, 63);
-}
-// inclusive prefix sum over the 64 lanes on the DPP network (no LDS traffic): Hillis-Steele inside the rows of 16, then the
-// row totals handed up (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
-__device__ __forceinline__ int wave_prefix_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);            // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);            // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);            // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);            // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);            // row_bcast:15
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);            // row_bcast:31
-    return v;
-}
-
 // A value loaded early and needed late: the empty asm is its first use, so hipcc's wait for the load sits HERE and not where its
 // scheduler would have hoisted the first arithmetic on it (right behind the load, in front of every later load).
 __device__ __forceinline__ int late_use(int v) {

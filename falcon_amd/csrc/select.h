@@ -73,11 +73,8 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
             mn = min(mn, u[i] ? u[i] : 0xFFFFFFFFu);
             mx = max(mx, u[i]);
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_xor((int)mn, off, 64));
-            mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-        }
+        mn = wave_min_u32(mn);                                  // (DPP network: no LDS round trips)
+        mx = wave_max_u32(mx);
         int shift = 32 - __clz((int)(mn ^ mx));                 // low bits in which the keys differ (0: all keys equal)
         if (mn == mx) shift = 0;
         uint32_t prefix = shift >= 32 ? 0u : (mx >> shift) << shift;
@@ -100,12 +97,8 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
             const uint4 cv = *reinterpret_cast<const uint4*>(hist + 4 * lane);      // bins 4 lane .. 4 lane + 3
             const int c[4] = {(int)cv.x, (int)cv.y, (int)cv.z, (int)cv.w};
             const int own = c[0] + c[1] + c[2] + c[3];
-            int suf = own;                                      // keys in this lane's bins and in all higher ones
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_down(suf, off, 64);
-                if (lane + off < 64) suf += o;
-            }
+            const int pre = wave_prefix_sum(own);
+            const int suf = __builtin_amdgcn_readlane(pre, 63) - pre + own;        // keys in this lane's bins and in all higher ones
             const int L = 63 - __clzll((unsigned long long)__ballot(suf >= kk));    // the lane whose bins hold the kk-th largest
             int acc = suf - own, bin = 4 * lane, cj = c[0];
 #pragma unroll
@@ -113,9 +106,9 @@ __device__ __forceinline__ int select_round(const SelectArgs& a, const SelQuery&
                 if (acc + c[j] >= kk) { bin = 4 * lane + j; cj = c[j]; break; }
                 acc += c[j];
             }
-            acc = __shfl(acc, L, 64);
-            bin = __shfl(bin, L, 64);
-            cj = __shfl(cj, L, 64);
+            acc = __builtin_amdgcn_readlane(acc, L);            // (L is wave-uniform)
+            bin = __builtin_amdgcn_readlane(bin, L);
+            cj = __builtin_amdgcn_readlane(cj, L);
             kk -= acc;
             prefix |= (uint32_t)bin << shift;
             exact = cj == kk;
