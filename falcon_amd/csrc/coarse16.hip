@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
         const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;
         const int64_t row = live ? a.perm[p] : 0;
         const int nl = live ? job.nc : 0;
-        uint32_t u[KPL];
+        uint32_t u[KPL], pw[KPL / 2];
 #pragma unroll
         for (int q = 0; q < KPL / 8; ++q) {
             uint4 raw = make_uint4(0, 0, 0, 0);
@@ -233,15 +233,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
             const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[8 * q + j] = (id_of(8 * q + j) < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
+            // the same keys packed, two per register, lists the bucket does not have as key 0 (below every rank asked for)
+            const int nv = nl - (16 * q + sub) * 8;                  // keys of this piece that exist
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                pw[4 * q + m] = wv[m] & ((2 * m < nv ? 0xFFFFu : 0u) | (2 * m + 1 < nv ? 0xFFFF0000u : 0u));
         }
         const int wnt = min(np, nl);
+        // T = the wnt-th largest key + 1 (0: no list), bit by bit: the keys at or above the candidate are counted lane-locally
+        // with the packed 16-bit operations (two keys per instruction), then once over the query's 16 lanes on the DPP network --
+        // the first form paid a compare, a shifted ballot and a count per KEY and bit and was VALU-bound on exactly that.
         uint32_t T = 0;
-        for (int bit = 16; bit >= 0; --bit) {
-            const uint32_t c = T | (1u << bit);
-            int cnt = 0;
+        {
+            uint32_t Tk = 0;
+            for (int bit = 15; bit >= 0; --bit) {
+                const uint32_t c = Tk | (1u << bit);
+                const uint32_t cm1 = (c - 1u) * 0x00010001u;
+                uint32_t acc = 0u;
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) cnt += gcount(u[j] >= c);
-            if (cnt >= wnt && wnt > 0) T = c;
+                for (int m = 0; m < KPL / 2; ++m) acc = pk_add(acc, pk_min(pk_sub_sat(pw[m], cm1), 0x00010001u));
+                const int cnt = row16_sum((int)((acc & 0xFFFFu) + (acc >> 16)));
+                Tk = cnt >= wnt ? c : Tk;
+            }
+            T = wnt > 0 ? Tk + 1u : 0u;
         }
         const float Tv = (float)(max(T, 1u) - 1u) * (1.f / 65535.f);
         const float e = 1.3e-3f * Tv + 1.2e-5f;

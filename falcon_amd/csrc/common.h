@@ -153,6 +153,32 @@ __device__ __forceinline__ void wave_lds_sync() {
     asm volatile("" ::: "memory");
 }
 
+// ---- two 16-bit keys per register: packed VALU operations ----------------------------------------------------------------
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub(uint32_t x, uint32_t y) {           // two 16-bit lanes, wrapping
+    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, x) - __builtin_bit_cast(ushort2v, y)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t x, uint32_t y) {
+    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, x) + __builtin_bit_cast(ushort2v, y)));
+}
+// (inline asm: hipcc has no packed selection for the saturating subtraction and turns min(sat(x - y), 1) into two compares, two
+// selects and a byte permute per word)
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t x, uint32_t y) {       // max(x - y, 0) per 16-bit lane
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t x, uint32_t y) {
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t x, uint32_t y) {
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // ---- reductions over the 64 lanes on the DPP network (VALU only: no ds_bpermute, no LDS round trip per step) ----------------
 // Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then the row results handed up: row_bcast15 into rows 1 and 3,
 // row_bcast31 into rows 2 and 3.  Lane L ends with the reduction of lanes 0 .. L; lane 63 with the whole wave's.
@@ -183,6 +209,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t u) {
     int v = (int)(u ^ 0x80000000u);
     FAL_DPP_SCAN(v, fal_max_i, (int)0x80000000)
     return (uint32_t)__builtin_amdgcn_readlane(v, 63) ^ 0x80000000u;
+}
+
+// sum over the 16 lanes of a DPP row (a quarter wave), every lane of the row gets it: four rotations inside the row
+__device__ __forceinline__ int row16_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);            // row_ror:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xF, 0xF, false);            // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, false);            // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);            // row_ror:8
+    return v;
 }
 
 // Workgroup barrier behind LDS-DMA (`global_load_lds`): s_barrier does not wait for a wave's outstanding DMA, and hipcc's own

@@ -272,30 +272,6 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16_kernel(List16A
 __device__ __forceinline__ int wcount(bool p) { return __popcll(__ballot(p)); }
 
 constexpr int kSelect16Copies = 1;       // copies of the high-byte histogram (select16_body)
-typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_sub(uint32_t x, uint32_t y) {           // two 16-bit lanes, wrapping
-    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, x) - __builtin_bit_cast(ushort2v, y)));
-}
-__device__ __forceinline__ uint32_t pk_add(uint32_t x, uint32_t y) {
-    return __builtin_bit_cast(uint32_t, (ushort2v)(__builtin_bit_cast(ushort2v, x) + __builtin_bit_cast(ushort2v, y)));
-}
-// (inline asm: hipcc has no packed selection for the saturating subtraction and turns min(sat(x - y), 1) into two compares, two
-// selects and a byte permute per word)
-__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t x, uint32_t y) {       // max(x - y, 0) per 16-bit lane
-    uint32_t r;
-    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_min(uint32_t x, uint32_t y) {
-    uint32_t r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ uint32_t pk_max(uint32_t x, uint32_t y) {
-    uint32_t r;
-    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
 // A value loaded early and needed late: the empty asm is its first use, so hipcc's wait for the load sits HERE and not where its
 // scheduler would have hoisted the first arithmetic on it (right behind the load, in front of every later load).
 __device__ __forceinline__ int late_use(int v) {
