@@ -446,12 +446,17 @@ def main():
             return up, ev
 
         k2 = max(1, min(args.steps, 20))
+        # one step alone (latency).  Two streams: the runner takes the pinned host columns themselves -- it uploads the
+        # partitions one after the other on a copy stream and starts a partition's kernels when its own bytes have arrived
+        # (PartitionRunner.run); one stream: upload, then compute.
+        host_parts = [SpectrumDataset(*ts) for ts in pinned]
+        one = (lambda: step(host_parts, run_args)) if concurrent["on"] and shard is None else (lambda: step(upload()[0], run_args))
         for _ in range(2):
-            step(upload()[0], run_args)
+            one()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(k2):                                   # one step alone: upload, then compute (latency)
-            step(upload()[0], run_args)
+        for _ in range(k2):
+            one()
         torch.cuda.synchronize()
         h2h_latency = (time.perf_counter() - t0) / k2
         # a stream of datasets: the upload of step i + 1 (copy stream, PCIe) under the kernels of step i, into two sets of

@@ -92,6 +92,20 @@ class SpectrumDataset:
     def __len__(self):
         return int(self.precursor_mz.shape[0])
 
+    def columns(self):
+        return (self.precursor_mz, self.retention_time, self.mz, self.intensity, self.indptr)
+
+    def on_host(self) -> bool:
+        """True when the columns are numpy arrays or CPU tensors (they have to cross PCIe before the path can start)"""
+        return not any(hasattr(t, "is_cuda") and t.is_cuda for t in self.columns())
+
+    def to_device(self, dev, non_blocking: bool = True) -> "SpectrumDataset":
+        """-> the same dataset with its columns on `dev`, copies enqueued on the CURRENT stream (asynchronous from pinned memory)"""
+        import torch
+        up = [(t if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(t))).to(dev, non_blocking=non_blocking)
+              for t in self.columns()]
+        return SpectrumDataset(*up, self.precursor_charge)
+
     @classmethod
     def from_table(cls, table):
         """pyarrow Table / pandas DataFrame with the Lance schema of falcon.py:275-285."""
@@ -433,10 +447,12 @@ class PartitionRunner:
                 self.pipelines.append(self._tls.pipe)
         return self._tls.pipe, self._tls.stream
 
-    def _run_one(self, ds, args, kwargs, shard):
+    def _run_one(self, ds, args, kwargs, shard, arrived=None):
         import torch
         pipe, stream = self._pipeline()
         with torch.cuda.stream(stream):
+            if arrived is not None:
+                stream.wait_event(arrived)                     # the partition's bytes (uploaded by `run` on the copy stream)
             if shard is not None and shard[1] > 1:
                 out = pipe.run_many([ds], *args, shard=shard, **kwargs)[0]       # this rank's windows of the partition
                 pipe.last = pipe.lasts[0]
@@ -460,8 +476,22 @@ class PartitionRunner:
             owners = self._planner.plan_shards(self._planner.ctx, datasets, args[4], p, shard[1])      # (waits for the counts)
             shards = [(shard[0], shard[1], [owners[i]]) for i in range(len(datasets))]
             order = [i for i in order if (owners[i] == shard[0]).any()]        # partitions this rank has windows of
-        futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs, shards[i]) for i in order}
         dev = torch.device("cuda", self.device)
+        # Host-resident partitions (the reference hands numpy columns over: cluster.py:73-85) cross PCIe on ONE copy stream,
+        # largest partition first, each followed by an event: a partition's kernels start when ITS bytes have arrived, the
+        # next partition's upload travels under them (pinned memory makes the copies asynchronous).
+        arrived = {}
+        if any(datasets[i].on_host() for i in order):
+            if not hasattr(self, "_copy_stream"):
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            datasets = list(datasets)
+            with torch.cuda.stream(self._copy_stream):
+                for i in order:
+                    if datasets[i].on_host():
+                        datasets[i] = datasets[i].to_device(dev)
+                        arrived[i] = torch.cuda.Event()
+                        arrived[i].record(self._copy_stream)
+        futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs, shards[i], arrived.get(i)) for i in order}
         nothing = lambda: ((torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev)),
                            {"rows": torch.empty(0, dtype=torch.int64, device=dev)})
         res = [futs[i].result()[::2] if i in futs else nothing() for i in range(len(datasets))]

@@ -392,11 +392,19 @@ def test_partition_runner_concurrent_streams_equal_run(ctx):
         lab, med = pipe.run(ds, *args)
         ref.append((lab.cpu().numpy(), med.cpu().numpy()))
     assert int(pipe.last["n_list"].max()) > 1
+    # the same partitions as the runner may be handed them: numpy columns (the reference's hand-over), pinned host tensors
+    # (uploaded partition by partition on the runner's copy stream, each partition's kernels behind its own bytes) and
+    # tensors already on the device
+    as_t = lambda ds, f: SpectrumDataset(*[f(torch.from_numpy(np.ascontiguousarray(t))) for t in ds.columns()])
+    forms = {"numpy": parts, "pinned": [as_t(ds, lambda t: t.pin_memory()) for ds in parts],
+             "device": [as_t(ds, lambda t: t.cuda()) for ds in parts]}
+    assert parts[0].on_host() and forms["pinned"][0].on_host() and not forms["device"][0].on_host()
     runner = PartitionRunner(0, 2)
     try:
-        for _ in range(3):
-            outs = runner.run(parts, *args)
-            for (lab, med), (rl, rm) in zip(outs, ref):
-                assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm)
+        for rep in range(3):
+            for form, dss in forms.items():
+                outs = runner.run(dss, *args)
+                for (lab, med), (rl, rm) in zip(outs, ref):
+                    assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm), (form, rep)
     finally:
         runner.close()
