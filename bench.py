@@ -683,16 +683,18 @@ def main():
             "rccl": rccl_info(),
         }
         if h2h is not None:
-            # SURVEY 8d's contractual timing: peak arrays in pinned host memory -> labels on the host.  `value_host_to_host` keeps
-            # the definition of rounds 1-2 (ONE step alone: upload, then compute); the stream form (upload of step i + 1 on a copy
-            # stream under the kernels of step i) has its own key since round 4 (round 3 reported it under the old one)
+            # SURVEY 8d's contractual timing: peak arrays in pinned host memory -> labels on the host.  `value_host_to_host` is ONE
+            # step alone (with two partition streams the runner uploads partition by partition and starts a partition's kernels
+            # behind its own bytes); the stream form (upload of step i + 1 on a copy stream under the kernels of step i) has its
+            # own key since round 4 (round 3 reported it under the old one)
             out["value_host_to_host"] = n_total / h2h_latency
             out["ms_per_step_host_to_host"] = h2h_latency * 1e3
             out["value_host_to_host_pipelined"] = n_total / h2h
             out["ms_per_step_host_to_host_pipelined"] = h2h * 1e3
             out["value_note"] = ("`value` = inputs resident in HBM when the timed region starts (the bench contract); "
-                                 "`value_host_to_host` = SURVEY 8d's host-to-host figure, one step alone (PCIe upload of 409 MB, then "
-                                 "compute); `value_host_to_host_pipelined` = a stream of datasets, the next upload under the current "
+                                 "`value_host_to_host` = SURVEY 8d's host-to-host figure, one step alone (409 MB over PCIe, a charge "
+                                 "partition's kernels start when its own bytes have arrived: PartitionRunner.run on host columns; one "
+                                 "stream: upload, then compute); `value_host_to_host_pipelined` = a stream of datasets, the next upload under the current "
                                  "step's kernels")
         if strong_extra is not None:
             out["strong_scaling"] = strong_extra

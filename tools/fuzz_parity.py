@@ -19,7 +19,7 @@ for case in range(n_cases):
     n = int(rng.choice([3000, 9000, 20000]))
     d = synth.select_charge(synth.generate(n, seed=int(rng.integers(1, 10 ** 6))), int(rng.choice([2, 3])))
     opts = dict(eps=float(rng.choice([0.05, 0.1, 0.3])), low_dim=int(rng.choice([64, 128, 256, 400])),
-                n_probe=int(rng.choice([2, 16])), n_neighbors=int(rng.choice([8, 64])),
+                n_probe=int(rng.choice([2, 5, 16, 32])), n_neighbors=int(rng.choice([8, 64])),
                 n_neighbors_ann=int(rng.choice([16, 128, 200])), mz_interval=float(rng.choice([0.0, 1.0])),
                 kmeans_iters=int(rng.choice([2, 10])))
     tol = (20.0, "ppm") if rng.random() < 0.6 else (0.02, "Da")
