@@ -445,14 +445,15 @@ def main():
                 ev.record(on)
             return up, ev
 
-        k2 = max(1, min(args.steps, 20))
+        k2 = 30 if args.steps >= 20 else max(1, args.steps)    # (its own step count: a 20-step average of a 12 ms latency is noisy)
         # one step alone (latency).  Two streams: the runner takes the pinned host columns themselves -- it uploads the
         # partitions one after the other on a copy stream and starts a partition's kernels when its own bytes have arrived
         # (PartitionRunner.run); one stream: upload, then compute.
         host_parts = [SpectrumDataset(*ts) for ts in pinned]
-        one = (lambda: step(host_parts, run_args)) if concurrent["on"] and shard is None else (lambda: step(upload()[0], run_args))
-        for _ in range(2):
-            one()
+        via_runner = concurrent["on"] and shard is None and not os.environ.get("FALCON_BENCH_H2H_UPFRONT")      # (A/B switch)
+        one = (lambda: step(host_parts, run_args)) if via_runner else (lambda: step(upload()[0], run_args))
+        for _ in range(5):                                     # (the copy stream's allocator pool and the runner's slots reach
+            one()                                              #  their steady state within three steps: tools/h2h_timeline.py)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(k2):
