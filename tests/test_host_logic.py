@@ -263,3 +263,19 @@ def test_device_generator_matches_the_numpy_recipe_statistically():
         assert abs(np.linalg.norm(b["intensity"][b["indptr"][i]:b["indptr"][i + 1]].astype(np.float64)) - 1) < 1e-5
     c2 = synth.select_charge_device(synth.generate_device(5000, torch.device("cpu")), 2)
     assert int(c2["indptr"][-1]) == c2["mz"].numel() and (c2["precursor_charge"] == 2).all()
+
+
+def test_spectrum_dataset_knows_where_its_columns_live():
+    """`PartitionRunner.run` uploads host-resident partitions itself (cluster.py: SpectrumDataset.on_host / to_device): numpy
+    columns and CPU tensors count as host-resident; the column order is the one `generate_clusters` reads (cluster.py:73-85)"""
+    import torch
+    from falcon_amd.cluster.cluster import SpectrumDataset
+    cols = (np.zeros(3, np.float32), np.ones(3, np.float32), np.arange(5, dtype=np.float32), np.ones(5, np.float32),
+            np.array([0, 2, 2, 5], np.int64))
+    ds = SpectrumDataset(*cols)
+    assert ds.on_host() and len(ds) == 3
+    assert [c is d for c, d in zip(ds.columns(), cols)] == [True] * 5
+    dt = SpectrumDataset(*[torch.from_numpy(c) for c in cols])
+    assert dt.on_host() and len(dt) == 3
+    moved = dt.to_device(torch.device("cpu"))                    # (same code path as the upload, no GPU needed)
+    assert all(torch.equal(a, b) for a, b in zip(moved.columns(), dt.columns()))
