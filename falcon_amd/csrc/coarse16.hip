@@ -395,22 +395,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const int np = a.np;
     auto wcnt = [&](bool pred) -> int { return __popcll(__ballot(pred)); };
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // The wave's 16 queries are consecutive slots of ONE tile: its job is looked up once, the 16 sorted rows come by one load
+    // (lane = query), and query qi + 1's keys are in flight while query qi is worked on -- the first form paid four dependent
+    // round trips (tile -> job -> perm -> keys) per query, sixteen times in a row per wave.
+    const int64_t g0 = (int64_t)blockIdx.x * 16;
+    const int64_t t = g0 >> 5;
+    const bool live_w = t < a.n_tiles;
+    DenseJob job{};
+    if (live_w) job = a.jobs[a.tile_job[t]];
+    const int lt = (int)(t - job.tile0);
+    const int ql0 = (int)(g0 & 31);
+    const int n_live = live_w ? max(0, min(16, job.nq - (32 * lt + ql0))) : 0;      // queries 0 .. n_live - 1 of the wave exist
+    const int64_t p0 = job.q_row0 + 32 * (int64_t)lt + ql0;
+    const int row_lane = lane < n_live ? a.perm[p0 + lane] : 0;
+    const int nl_w = n_live > 0 ? job.nc : 0;
+    auto keys_of = [&](int qi) -> uint4 {
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        const int64_t rw = (int64_t)(uint32_t)__builtin_amdgcn_readlane(row_lane, qi);
+        if (qi < n_live && lane * 8 < nl_w) raw = *reinterpret_cast<const uint4*>(a.ckeys + rw * (int64_t)a.stride + lane * 8);
+        return raw;
+    };
+    uint4 raw_next = keys_of(0);
     for (int qi = 0; qi < 16; ++qi) {
-        const int64_t g = (int64_t)blockIdx.x * 16 + qi;                 // tile-order slot of the query
-        const int64_t t = g >> 5;
-        const int ql = (int)(g & 31);
-        bool live = t < a.n_tiles;
-        DenseJob job{};
-        if (live) job = a.jobs[a.tile_job[t]];
-        const int lt = (int)(t - job.tile0);
-        live = live && 32 * lt + ql < job.nq;
-        const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;
-        const int64_t row = live ? a.perm[p] : 0;
+        const int64_t g = g0 + qi;                                       // tile-order slot of the query
+        const bool live = qi < n_live;
+        const int64_t p = live ? p0 + qi : 0;
+        const int64_t row = live ? (int64_t)(uint32_t)__builtin_amdgcn_readlane(row_lane, qi) : 0;
         const int nl = live ? job.nc : 0;
         uint32_t u[8];
         {
-            uint4 raw = make_uint4(0, 0, 0, 0);
-            if (live && lane * 8 < nl) raw = *reinterpret_cast<const uint4*>(a.ckeys + row * (int64_t)a.stride + lane * 8);
+            const uint4 raw = raw_next;
+            if (qi + 1 < 16) raw_next = keys_of(qi + 1);
             const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[j] = (lane * 8 + j < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
@@ -433,12 +448,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 #pragma unroll
                 for (int jj = 0; jj < 5; ++jj) c[jj] = hist[5 * lane + jj];
                 const int own = (int)(c[0] + c[1] + c[2] + c[3] + c[4]);
-                int suf = own;                                            // keys in this lane's bins and all higher ones
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int o = __shfl_down(suf, off, 64);
-                    if (lane + off < 64) suf += o;
-                }
+                const int pre = wave_prefix_sum(own);                     // (DPP network)
+                const int suf = __builtin_amdgcn_readlane(pre, 63) - pre + own;      // keys in this lane's bins and all higher ones
                 const unsigned long long reach = __ballot(suf >= kk);     // (a prefix of the lanes: suf falls with the lane)
                 const int L = 63 - __clzll(reach);
                 int acc = suf - own, bin = 5 * lane;
@@ -447,8 +458,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                     if (acc + (int)c[jj] >= kk) { bin = 5 * lane + jj; break; }
                     acc += (int)c[jj];
                 }
-                *above = __shfl(acc, L, 64);
-                const int res = __shfl(bin, L, 64);
+                *above = __builtin_amdgcn_readlane(acc, L);
+                const int res = __builtin_amdgcn_readlane(bin, L);
                 wave_lds_sync();
                 return res;
             };
