@@ -211,25 +211,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
     int need[4], nmem[4], want[4];
     int64_t pq[4];
     bool emit[4], amb[4];
+    // The wave's 16 queries are consecutive slots of ONE tile: one job lookup, one load of their sorted rows (lane = query), and --
+    // with 8 keys per lane -- the keys of all four rounds in flight before the first is worked on (the first form paid the chain
+    // tile -> job -> perm -> keys once per round).
+    const int64_t g0 = (int64_t)blockIdx.x * 16;
+    const int64_t t_w = g0 >> 5;
+    const bool live_w = t_w < a.n_tiles;
+    DenseJob job{};
+    if (live_w) job = a.jobs[a.tile_job[t_w]];
+    const int lt = (int)(t_w - job.tile0);
+    const int ql0 = (int)(g0 & 31);
+    const int n_live = live_w ? max(0, min(16, job.nq - (32 * lt + ql0))) : 0;      // queries 0 .. n_live - 1 of the wave exist
+    const int64_t p0 = job.q_row0 + 32 * (int64_t)lt + ql0;
+    const int row_lane = lane < n_live ? a.perm[p0 + lane] : 0;
+    auto keys_of = [&](int rd, int q) -> uint4 {
+        const int qi = 4 * rd + grp;
+        const int64_t rw = (int64_t)(uint32_t)__shfl(row_lane, qi, 64);
+        uint4 raw = make_uint4(0, 0, 0, 0);
+        if (qi < n_live && (16 * q + sub) * 8 < job.nc) raw = *reinterpret_cast<const uint4*>(a.ckeys + rw * (int64_t)a.stride + (16 * q + sub) * 8);
+        return raw;
+    };
+    uint4 ahead[KPL == 8 ? 4 : 1];
+    if constexpr (KPL == 8) {
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) ahead[rd] = keys_of(rd, 0);
+    }
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
         const int qi = 4 * rd + grp;
-        const int64_t g = (int64_t)blockIdx.x * 16 + qi;             // tile-order slot of this 16-lane group's query
-        const int64_t t = g >> 5;
-        const int ql = (int)(g & 31);
-        bool live = t < a.n_tiles;
-        DenseJob job{};
-        if (live) job = a.jobs[a.tile_job[t]];
-        const int lt = (int)(t - job.tile0);
-        live = live && 32 * lt + ql < job.nq;
-        const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;
-        const int64_t row = live ? a.perm[p] : 0;
+        const int64_t g = g0 + qi;                                   // tile-order slot of this 16-lane group's query
+        const bool live = qi < n_live;
+        const int64_t p = live ? p0 + qi : 0;
+        const int64_t row = live ? (int64_t)(uint32_t)__shfl(row_lane, qi, 64) : 0;
         const int nl = live ? job.nc : 0;
         uint32_t u[KPL], pw[KPL / 2];
 #pragma unroll
         for (int q = 0; q < KPL / 8; ++q) {
-            uint4 raw = make_uint4(0, 0, 0, 0);
-            if (live && (16 * q + sub) * 8 < nl) raw = *reinterpret_cast<const uint4*>(a.ckeys + row * (int64_t)a.stride + (16 * q + sub) * 8);
+            uint4 raw;
+            if constexpr (KPL == 8) raw = ahead[rd]; else raw = keys_of(rd, q);
             const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[8 * q + j] = (id_of(8 * q + j) < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
