@@ -145,16 +145,23 @@ __global__ __launch_bounds__(1024) void probe_scatter_bucket_kernel(const int32_
                                                                     const int64_t* __restrict__ q_sim_off,
                                                                     const int64_t* __restrict__ inv_off, int32_t* __restrict__ inv_q,
                                                                     int64_t* __restrict__ inv_dest, const int32_t* __restrict__ perm,
-                                                                    int32_t* __restrict__ inv_row) {
+                                                                    int32_t* __restrict__ inv_row, int lds_lists) {
     extern __shared__ int64_t lds64[];
     const DenseJob job = jobs[blockIdx.x];
     const int nl = job.nc;
+    // lds_lists >= the launch's largest list count: 12 bytes of LDS per list (table position + size); otherwise (buckets with
+    // thousands of lists: 12 bytes each would not fit) only a 4-byte cursor per list, offsets and sizes from global memory
+    const bool full = nl <= lds_lists;
     int64_t* at = lds64;                                     // [nl] where the list's next table entry goes
-    int32_t* len = reinterpret_cast<int32_t*>(lds64 + nl);   // [nl] rows of the list
+    int32_t* len = reinterpret_cast<int32_t*>(lds64 + (full ? nl : 0));   // [nl] rows of the list | (else) entries written so far
     for (int i = threadIdx.x; i < nl; i += blockDim.x) {
-        const int64_t b = list_off[job.c_row0 + i], e = list_off[job.c_row0 + i + 1];
-        len[i] = (int32_t)(e - b);
-        at[i] = inv_off[job.c_row0 + i];
+        if (full) {
+            const int64_t b = list_off[job.c_row0 + i], e = list_off[job.c_row0 + i + 1];
+            len[i] = (int32_t)(e - b);
+            at[i] = inv_off[job.c_row0 + i];
+        } else {
+            len[i] = 0;
+        }
     }
     __syncthreads();
     for (int q0 = 0; q0 < job.nq; q0 += blockDim.x) {
@@ -165,11 +172,20 @@ __global__ __launch_bounds__(1024) void probe_scatter_bucket_kernel(const int32_
             const int32_t row = inv_row ? perm[p] : 0;       // (the f16 list scan gathers its queries by sorted row)
             auto put = [&](int l) {
                 if (l < 0) return;
-                const int64_t e = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(&at[l]), 1ull);
+                int64_t e;
+                int32_t rows;
+                if (full) {
+                    e = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(&at[l]), 1ull);
+                    rows = len[l];
+                } else {
+                    const int64_t G = job.c_row0 + l;
+                    e = inv_off[G] + atomicAdd(&len[l], 1);
+                    rows = (int32_t)(list_off[G + 1] - list_off[G]);
+                }
                 inv_q[e] = (int32_t)p;
                 inv_dest[e] = dest;
                 if (inv_row) inv_row[e] = row;
-                dest += len[l];
+                dest += rows;
             };
             if (NPV > 0) {
                 int4 pr[NPV > 0 ? NPV : 1];
@@ -184,6 +200,16 @@ __global__ __launch_bounds__(1024) void probe_scatter_bucket_kernel(const int32_
         }
         __syncthreads();                                     // chunk after chunk: the order inside a list follows the queries
     }
+}
+
+// lists per bucket up to which the probe table kernel keeps 12 bytes per list in LDS (48 KB)
+static int probe_lds_lists() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FALCON_PROBE_LDS_LISTS");
+        v = e ? std::max(0, std::min(4096, atoi(e))) : 4096;
+    }
+    return v;
 }
 
 static size_t sims_capacity_floats() {
@@ -545,17 +571,19 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         hipLaunchKernelGGL(list_tiles_kernel, tg, dim3(256), 0, st, cnt, ivf->list_off, TL, group_shift, ltiles);
         FAL_TRY(device_scan_i32(ctx, ltiles, TL, ltile_off, SLOT_MISC2));
         if (max_n_list <= 16384) {
-            const size_t lds = (sizeof(int64_t) + sizeof(int32_t)) * (size_t)max_n_list;
+            // (dynamic LDS stays at or below 64 KB: 12 bytes per list up to 4,096 lists, else 4)
+            const int lds_lists = max_n_list <= probe_lds_lists() ? max_n_list : 0;
+            const size_t lds = lds_lists ? (sizeof(int64_t) + sizeof(int32_t)) * (size_t)max_n_list : sizeof(int32_t) * (size_t)max_n_list;
             const dim3 sg((unsigned)coarse.size());
             if (np == 16)
                 hipLaunchKernelGGL(probe_scatter_bucket_kernel<4>, sg, dim3(1024), lds, st, probes, np, coarse_dev, ivf->list_off,
-                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
+                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row, lds_lists);
             else if (np == 32)
                 hipLaunchKernelGGL(probe_scatter_bucket_kernel<8>, sg, dim3(1024), lds, st, probes, np, coarse_dev, ivf->list_off,
-                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
+                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row, lds_lists);
             else
                 hipLaunchKernelGGL(probe_scatter_bucket_kernel<0>, sg, dim3(1024), lds, st, probes, np, coarse_dev, ivf->list_off,
-                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row);
+                                   q_sim_off, inv_off, inv_q, inv_dest, ivf->perm, inv_row, lds_lists);
         } else
             hipLaunchKernelGGL(probe_scatter_kernel, dim3(pg), dim3(256), 0, st, probes, np, coarse_dev, (int)coarse.size(),
                                ivf_tiles, ivf->list_off, q_sim_off, inv_off, cursor, inv_q, inv_dest);
