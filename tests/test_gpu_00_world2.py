@@ -98,3 +98,27 @@ def test_bench_runs_as_a_two_rank_job(scaling, extra):
     assert out["rccl"]["ranks"] == 2
     if scaling == "weak":
         assert out["strong_scaling"]["value"] > 0 and out["strong_scaling"]["scaling"] == "strong", out["strong_scaling"]
+
+
+def test_environment_switches_do_not_change_results(tmp_path):
+    """`FALCON_PROBE_LDS_LISTS=0` (the inverted probe table built with 4-byte cursors in LDS and offsets from global memory: the form
+    for buckets with thousands of lists) and `FALCON_DEBUG_POISON=1` give the labels and medoids of the default run, bit for bit.
+    Each setting is read once per process: fresh processes (this file runs before the pytest process owns a GPU context)."""
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.fail("this pytest process already owns a GPU context: tests/test_gpu_00_world2.py must run first / on its own")
+    outs = {}
+    for name, extra in (("default", {}), ("small_lds", {"FALCON_PROBE_LDS_LISTS": "0"}), ("poison", {"FALCON_DEBUG_POISON": "1"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("FALCON_PROBE_LDS_LISTS", "FALCON_DEBUG_POISON")}
+        env.update(extra)
+        out = os.path.join(tmp_path, name + ".npz")
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "env_switch_worker.py"), out], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert proc.returncode == 0, proc.stdout[-3000:]
+        outs[name] = np.load(out)
+    ref = outs["default"]
+    assert int(ref["n_list_max16"]) > 1                                         # the indexed path ran
+    assert (np.bincount(ref["labels16"]) > 1).sum() > 20                        # a non-trivial clustering
+    for name in ("small_lds", "poison"):
+        for key in ref.files:
+            assert np.array_equal(outs[name][key], ref[key]), (name, key)
