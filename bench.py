@@ -112,6 +112,9 @@ def cpu_baseline(hosts, params, budget_s=75.0):
             entry[kind] = {"value": n_sel / dt, "unit": "spectra/s", "seconds": round(dt, 2)}
         sizes.append(entry)
     ran = [e for e in sizes if isinstance(e.get("port"), dict)]
+    if not ran:                                      # a dataset below the smallest size: nothing was timed
+        return {"value": None, "unit": "spectra/s", "cores": cores, "kind": "port",
+                "sample": f"not run: the dataset ({n_all} spectra) is smaller than the smallest baseline size", "sizes": sizes}
     best = ran[-1]
     main = {"value": best["port"]["value"], "unit": "spectra/s", "cores": cores, "kind": "port",
             "sample": f"{best['spectra']} spectra ({best['sample']}), both charge partitions, same parameters; "
@@ -704,7 +707,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             hosts = [{k: getattr(x, k).cpu().numpy() for k in ("precursor_mz", "retention_time", "mz", "intensity", "indptr")}
                      for x in parts]
-            out["cpu_baseline"] = cpu_baseline(hosts, p)
+            try:
+                out["cpu_baseline"] = cpu_baseline(hosts, p)
+            except Exception as e:                                # the GPU figures above must not be lost to the baseline leg
+                out["cpu_baseline"] = {"value": None, "unit": "spectra/s", "cores": os.cpu_count() or 1, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
         line = json.dumps(out)
     if runner is not None:
         runner.close()

@@ -97,13 +97,22 @@ class SpectrumDataset:
 
     def on_host(self) -> bool:
         """True when the columns are numpy arrays or CPU tensors (they have to cross PCIe before the path can start)"""
-        return not any(hasattr(t, "is_cuda") and t.is_cuda for t in self.columns())
+        return not any(t is not None and hasattr(t, "is_cuda") and t.is_cuda for t in self.columns())
 
     def to_device(self, dev, non_blocking: bool = True) -> "SpectrumDataset":
         """-> the same dataset with its columns on `dev`, copies enqueued on the CURRENT stream (asynchronous from pinned memory)"""
         import torch
-        up = [(t if isinstance(t, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(t))).to(dev, non_blocking=non_blocking)
-              for t in self.columns()]
+        # the dtypes the path expects (float32 columns, int64 offsets); a column that is None (retention_time: legal, _front
+        # checks for it) stays None
+        want = (torch.float32, torch.float32, torch.float32, torch.float32, torch.int64)
+        up = []
+        for t, dt in zip(self.columns(), want):
+            if t is None:
+                up.append(None)
+                continue
+            if not isinstance(t, torch.Tensor):
+                t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32 if dt == torch.float32 else np.int64))
+            up.append(t.to(dev, dtype=dt, non_blocking=non_blocking))
         return SpectrumDataset(*up, self.precursor_charge)
 
     @classmethod

@@ -287,19 +287,23 @@ __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, c
         }
         const bool sparse = (uint32_t)__builtin_amdgcn_readlane((int)col_lane, 0) != (uint32_t)kColDense;    // (else: > 64 non-zeros)
         const int n_ent = __popcll(__ballot(col_lane < (uint32_t)kColDense));
-        auto eval = [&](int c) {
-            const float* cp = Cn + (job.cent0 + c) * d;
+        // Every chain runs under FULL EXEC: sparse_row_chain fetches the row's entries with v_readlane from lanes 0 .. n_ent - 1,
+        // and a lane that a divergent branch had switched off would hand it an undefined register (the loops below are
+        // wave-uniform, a lane without a candidate evaluates centroid 0 and drops the result).
+        auto eval = [&](int c, bool valid) {
+            const float* cp = Cn + (job.cent0 + (valid ? c : 0)) * d;
             const float s = sparse ? sparse_row_chain(col_lane, val_lane, n_ent, cp) : exact_dot(X + row * d, cp, d);
-            if (s > best || (s == best && c < bid)) {
+            if (valid && (s > best || (s == best && c < bid))) {
                 best = s;
                 bid = c;
             }
         };
         if (fg == 0u) {
-            for (int c = lane; c < job.ncent; c += 64) eval(c);
+            for (int c0 = 0; c0 < job.ncent; c0 += 64) eval(c0 + lane, c0 + lane < job.ncent);
         } else {
             const int nfull = 32 * __popc(fg);
-            for (int i = lane; i < nfull + 4; i += 64) {
+            for (int i0 = 0; i0 < nfull + 4; i0 += 64) {
+                const int i = i0 + lane;
                 int c = -1;
                 if (i < nfull) {
                     int g = 0, k = i >> 5;                             // the k-th set bit of the mask
@@ -310,12 +314,12 @@ __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, c
                         k -= on ? 1 : 0;
                     }
                     c = 32 * g + (i & 31);
-                } else {
+                } else if (i < nfull + 4) {
                     const int slot = i - nfull;
                     const uint32_t id = (pk[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu;
                     c = id == 0xFFFFu ? -1 : (int)id;
                 }
-                if (c >= 0 && c < job.ncent) eval(c);
+                eval(c, c >= 0 && c < job.ncent);
             }
         }
 #pragma unroll

@@ -97,6 +97,7 @@ struct fal_ctx {
     uint64_t slot_epoch[32] = {};
     uint32_t slot_gen[32] = {};
     std::vector<void*> retired;
+    std::vector<bool> retired_held;       // parallel to `retired`: the slot had been reserved in the call that retired the block
     void release_retired();
     int reserve(int slot, size_t bytes, void** out);
     // the caller holds no pointer into the slot any more (kernels already enqueued keep their block: it is retired, not freed,

@@ -21,6 +21,7 @@ void fal_ctx::release_retired() {
     (void)hipStreamSynchronize(stream);
     for (void* p : retired) (void)hipFree(p);
     retired.clear();
+    retired_held.clear();
 }
 
 int fal_ctx::reserve(int slot, size_t bytes, void** out) {
@@ -34,6 +35,8 @@ int fal_ctx::reserve(int slot, size_t bytes, void** out) {
             }
             if (call_depth > 0) {
                 retired.push_back(s.ptr);        // kernels of this call may still use it; freed when the next call begins
+                // a block whose slot was reserved earlier in THIS call may still be addressed by a pointer on the host
+                retired_held.push_back(slot_epoch[slot] == call_epoch);
             } else {
                 FAL_CHECK_HIP(hipStreamSynchronize(stream));
                 FAL_CHECK_HIP(hipFree(s.ptr));
@@ -43,10 +46,30 @@ int fal_ctx::reserve(int slot, size_t bytes, void** out) {
         }
         const size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&s.ptr, want);
-        if (e == hipErrorOutOfMemory && !retired.empty()) {     // (the retired blocks are what does not fit: let them go)
+        if (e == hipErrorOutOfMemory && !retired.empty()) {
+            // Out of memory with retired blocks around: the ones nobody can hold a pointer into any more (their slot had been
+            // released, or was last reserved by an earlier call) go once the stream has drained; a block retired from a slot
+            // this call had reserved stays -- CallScope's contract -- and the call fails with FAL_ENOMEM instead.
             (void)hipGetLastError();
-            release_retired();
+            (void)hipStreamSynchronize(stream);
+            size_t kept = 0;
+            for (size_t i = 0; i < retired.size(); ++i) {
+                if (retired_held[i]) {
+                    retired[kept] = retired[i];
+                    retired_held[kept++] = true;
+                } else {
+                    (void)hipFree(retired[i]);
+                }
+            }
+            retired.resize(kept);
+            retired_held.resize(kept);
             e = hipMalloc(&s.ptr, want);
+            if (e == hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                fal::set_error("out of device memory: scratch slot %d needs %zu bytes (%zu retired block(s) of this call are still "
+                               "referenced and cannot be freed before it returns)", slot, want, kept);
+                return FAL_ENOMEM;
+            }
         }
         FAL_CHECK_HIP(e);
         s.cap = want;

@@ -192,8 +192,10 @@ __device__ __forceinline__ int64_t window_of(float mz, double interval, int64_t 
     // mz_interval (0.05 -> the table ends at 819 m/z) a clamp sent most of the dataset to one unit = one rank;
     // wrapped, a slot holds whole windows w, w + n_windows, ... : still a valid deal unit (buckets never cross a window),
     // and the load stays spread.  (NaN / negative -> slot 0)
+    // (+inf, or a quotient too large for the integer cast: the last slot -- fmod(inf, n) is NaN and its cast undefined)
     const double w = floor((double)mz / interval);
     if (!(w >= 0.0)) return 0;
+    if (!(w < 9.0e15)) return n_windows - 1;
     return w < (double)n_windows ? (int64_t)w : (int64_t)fmod(w, (double)n_windows);
 }
 

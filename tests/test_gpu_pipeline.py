@@ -406,5 +406,10 @@ def test_partition_runner_concurrent_streams_equal_run(ctx):
                 outs = runner.run(dss, *args)
                 for (lab, med), (rl, rm) in zip(outs, ref):
                     assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm), (form, rep)
+        # host partitions WITHOUT retention times (rt_tol None: the column is never read) and with float64 precursors
+        no_rt = [SpectrumDataset(ds.precursor_mz.astype(np.float64), None, ds.mz, ds.intensity, ds.indptr) for ds in parts]
+        outs = runner.run(no_rt, *args)
+        for (lab, med), (rl, rm) in zip(outs, ref):
+            assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm)
     finally:
         runner.close()

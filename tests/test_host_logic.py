@@ -279,3 +279,11 @@ def test_spectrum_dataset_knows_where_its_columns_live():
     assert dt.on_host() and len(dt) == 3
     moved = dt.to_device(torch.device("cpu"))                    # (same code path as the upload, no GPU needed)
     assert all(torch.equal(a, b) for a, b in zip(moved.columns(), dt.columns()))
+    # a dataset without retention times (legal: the front end checks for it) and with float64 / int32 host columns: the
+    # upload passes None through and hands the path the dtypes it expects
+    odd = SpectrumDataset(cols[0].astype(np.float64), None, cols[2].astype(np.float64), cols[3], cols[4].astype(np.int32))
+    assert odd.on_host()
+    up = odd.to_device(torch.device("cpu"))
+    assert up.retention_time is None
+    assert [t.dtype for t in (up.precursor_mz, up.mz, up.intensity, up.indptr)] == [torch.float32] * 3 + [torch.int64]
+    assert torch.equal(up.indptr, torch.from_numpy(cols[4])) and torch.equal(up.mz, torch.from_numpy(cols[2]))
