@@ -75,6 +75,7 @@ int launch_kept16(fal_ctx* ctx, const Kept16Args& a, int64_t n_tiles);        //
 int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32);
 int launch_pos_of_row(fal_ctx* ctx, const int32_t* perm, int64_t n, int32_t* pos_of_row);
 int launch_list16(fal_ctx* ctx, const List16Args& a);
+int launch_list16r(fal_ctx* ctx, const List16Args& a);      // list16r.hip (called by launch_list16)
 int launch_select16(fal_ctx* ctx, const Select16Args& a, int64_t n_tiles);
 
 }  // namespace fal

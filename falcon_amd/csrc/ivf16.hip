@@ -574,6 +574,16 @@ int launch_pos_of_row(fal_ctx* ctx, const int32_t* perm, int64_t n, int32_t* pos
     return FAL_OK;
 }
 
+// FALCON_LIST16 = "r": list16r_kernel (list16r.hip: the list's rows in LDS, every wave its own query chunks; low_dim <= 400)
+// instead of list16_kernel (rows in registers, shared query ring, four waves in lockstep).  Same keys, bit for bit
+// (tests/test_gpu_ivf16.py); measured SLOWER (profiles/NOTES.md r5: both forms issue ~900 instructions per 32-query chunk
+// for its 65 MFMAs, and the lockstep form runs them on two waves per SIMD), so the lockstep form stays the default.  Read at
+// every launch: tests and tools/list16_ab.py switch it inside one process.
+static int list16_form() {
+    const char* e = getenv("FALCON_LIST16");
+    return (e && !strcmp(e, "r")) ? 1 : 0;
+}
+
 int launch_list16(fal_ctx* ctx, const List16Args& a_in) {
     if (a_in.n_tiles_max <= 0) return FAL_OK;
     const int64_t per_xcd = (a_in.n_tiles_max + 7) / 8;
@@ -582,6 +592,7 @@ int launch_list16(fal_ctx* ctx, const List16Args& a_in) {
     const List16Args& a = a_in;
     StageScope ts(ctx, ST_SCAN);
     StageScope tk(ctx, ST_KERNEL);
+    if (a.d <= 400 && list16_form() == 1) return launch_list16r(ctx, a);
     switch (a.d / 16) {
         case 4: hipLaunchKernelGGL((list16_kernel<4>), grid, block, 0, ctx->stream, a); break;
         case 8: hipLaunchKernelGGL((list16_kernel<8>), grid, block, 0, ctx->stream, a); break;

@@ -67,6 +67,22 @@ def test_ivf_prefilter_neighbours_bit_identical_to_the_staged_path(ctx, d, n_pro
     assert n_fb < 0.05 * off[-1], n_fb                        # the prefiltered path did the work, not the fallback
 
 
+@pytest.mark.parametrize("d,n_probe,k_ann,keep", [(400, 16, 128, 64), (256, 12, 100, 50), (128, 16, 128, 64), (64, 16, 64, 16)])
+def test_list16r_form_of_the_fine_scan_gives_the_same_lists(ctx, monkeypatch, d, n_probe, k_ann, keep):
+    """FALCON_LIST16=r: list16r_kernel (list16r.hip: the list's rows resident in LDS, every wave walks its own 32-query chunks,
+    no workgroup barrier in the stream) writes the keys of list16_kernel bit for bit, so the neighbour lists stay those of the
+    staged path -- lists of 1 to 4 slices, lists of more than 128 rows (several tiles), probe streams shorter than four
+    chunks (waves without work), exact ties."""
+    monkeypatch.setenv("FALCON_LIST16", "r")
+    sizes = [6000, 300, 2500, 9000, 40, 1300, 5000]
+    nl = np.array([64, 1, 32, 128, 1, 16, 32], np.int32)      # ~94 / 78 / 70 / 81 / 156 rows per list
+    off, X, mz, rt = _buckets(sizes, d, 37)
+    X[off[3] + 10:off[3] + 16] = X[off[3] + 10]
+    e_idx, n_fb = _staged_and_prefiltered(ctx, X, off, nl, mz, None, n_probe, k_ann, keep, 20.0, "ppm", None)
+    assert (e_idx >= 0).sum() > off[-1] // 8
+    assert n_fb < 0.05 * off[-1], n_fb
+
+
 @pytest.mark.parametrize("d,n_probe,k_ann,keep,tol,mode,rt_tol", [
     (400, 16, 128, 64, 20.0, "ppm", None), (400, 8, 32, 8, 0.05, "Da", 30.0), (128, 16, 64, 16, 20.0, "ppm", None),
     (64, 4, 32, 16, 60.0, "ppm", None),
