@@ -54,7 +54,7 @@ class AnnParams:
     ivf_prefilter: bool = True    # float32 buckets with an index: fine scan on the f16 matrix cores to 16-bit keys, the k-th best
                                   # key of every query bracketed from them, exact float32 work only inside the precursor
                                   # window and where it decides the k-th key (ivf16.hip); bit-identical neighbour lists
-    kmeans_prefilter: bool = True # IVF buckets with <= 512 lists: k-means assignment on the f16 matrix cores, rows whose two
+    kmeans_prefilter: bool = True # IVF buckets with <= 2,048 lists: k-means assignment on the f16 matrix cores, rows whose two
                                   # best centroids are closer than the float16 error bound re-evaluated exactly in float32
                                   # (assign16.hip): the index is identical, the build several times faster
     rescore: bool = False         # re-score the ANN neighbours with the reference's matched-peak cosine
@@ -255,7 +255,7 @@ class ClusterPipeline:
                 which |= 1
             if p.ivf_prefilter and not keep_intermediates and ok16 and bool((n_list > 1).any()):
                 which |= 2
-            want_km = p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 512)).any())
+            want_km = p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 2048)).any())      # (scan.h kAssignMergeLists)
             if want_km or which:
                 X, x16 = vec("f32+f16")            # the float16 rounding of the same rows, from the same pass over the peaks
                 Xkm = x16 if want_km else None

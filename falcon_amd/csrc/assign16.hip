@@ -50,11 +50,12 @@ struct Assign16Args {
                              // 32-centroid group at most -- the exact kernel evaluates just those
     uint16_t* ckeys;         // optional [n, ckeys_stride]: round(approximate similarity * 65535) of every (row, centroid) pair -- the
     int ckeys_stride;        // final pass leaves them for the coarse quantiser of the search (coarse16.hip)
-    // buckets with more than 128 lists (<= 512): one job per (row segment, group of 128 centroids) leaves the best / runner-up /
-    // best id of its four 32-centroid subgroups per row (PARTIAL), assign16_merge_kernel decides over all subgroups of the row
-    float* part_b;           // [16, n] best value of subgroup sg = 4 * group + wave
-    float* part_s;           // [16, n] its runner-up
-    int32_t* part_id;        // [16, n] bucket-local id of its best
+    // buckets with more than 128 lists (<= kAssignMergeLists): one job per (row segment, group of 128 centroids) leaves the best /
+    // runner-up / best id of its four 32-centroid subgroups per row (PARTIAL), assign16_merge_kernel decides over all subgroups
+    // of the row
+    float* part_b;           // [n_sub, n] best value of subgroup sg = 4 * group + wave (n_sub = the launch's most lists / 32)
+    float* part_s;           // [n_sub, n] its runner-up
+    int32_t* part_id;        // [n_sub, n] bucket-local id of its best
     int64_t n;               // rows (stride of the partial arrays)
     const AssignJob* mjobs;  // merge jobs: (row segment) x (ALL lists of the bucket); the exact kernels' entries refer to these
     int64_t n_mjobs;
@@ -445,11 +446,11 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
 
 // jobs: device table of `n_jobs` jobs, each covering ALL (<= 128) lists of its bucket
 // jobs: device table [single jobs (n_single): (row segment) x (ALL <= 128 lists of the bucket)] [merge jobs (n_merge): (row
-// segment) x (all 129..512 lists)] [group jobs (n_group): (row segment) x (128 of those lists), the groups of a segment next
+// segment) x (all 129..kAssignMergeLists lists)] [group jobs (n_group): (row segment) x (128 of those lists), the groups of a segment next
 // to each other]
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
-                    uint16_t* ckeys, int ckeys_stride, const uint16_t* sp_cols, const float* sp_vals) {
+                    uint16_t* ckeys, int ckeys_stride, const uint16_t* sp_cols, const float* sp_vals, int merge_max_lists) {
     if (n_single + n_merge <= 0) return FAL_OK;
     // work lists of the exact kernels: a row enters at most one of them once per pass, so n_rows entries never overflow
     int32_t* amb = nullptr;
@@ -485,8 +486,10 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     if (n_single > 0) FAL_TRY(run(false));
     if (n_merge > 0) {
         float* part = nullptr;
-        FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * 3 * 16 * (size_t)n_rows, (void**)&part));
-        a.part_b = part; a.part_s = part + 16 * n_rows; a.part_id = reinterpret_cast<int32_t*>(part + 32 * n_rows);
+        const size_t n_sub = 4 * (size_t)std::max(1, (merge_max_lists + kAssignGroup - 1) / kAssignGroup);      // four per group job, whole groups
+        FAL_REQUIRE(merge_max_lists <= kAssignMergeLists, FAL_EINTERNAL, "assign16: a merge job with %d lists", merge_max_lists);
+        FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * 3 * n_sub * (size_t)n_rows, (void**)&part));
+        a.part_b = part; a.part_s = part + n_sub * (size_t)n_rows; a.part_id = reinterpret_cast<int32_t*>(part + 2 * n_sub * (size_t)n_rows);
         a.jobs = jobs + n_single + n_merge; a.n_jobs = n_group;
         FAL_TRY(run(true));
         a.mjobs = jobs + n_single; a.n_mjobs = n_merge;

@@ -7,7 +7,7 @@ namespace fal {
 
 struct Coarse16Args {
     const uint16_t* ckeys;       // [n, stride] by sorted row
-    int stride;                  // 128 x groups (<= 512)
+    int stride;                  // 128 x groups (<= 2,048)
     const float* X;              // [n, d] float32 rows, sorted order (exact re-evaluation of close calls)
     const float* C;              // [total_lists, d] centroids
     int d;

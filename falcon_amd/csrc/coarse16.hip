@@ -18,6 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "scan.h"
 #include "ivf.h"
@@ -400,13 +401,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
 // after the other.  The 16-lanes-per-query form holds 32 keys per lane there (168 registers: three waves per SIMD) and pays
 // 17 x 32 compare + ballot steps per round of four queries; here a lane holds 8 keys, the per-query state of the two phases
 // lives in LDS, the wave runs at eight per SIMD, and the round of exact chains is still one per sixteen queries.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void coarse16x_kernel(Coarse16Args a) {
+// G > 1 (round 5): 8 G keys per lane for buckets with up to 512 G lists (1,024 / 2,048: `--batch_size 65536` on windows of
+// 40 k+ spectra, SURVEY 8d's C4 row) -- key (g, j) of a lane is list 512 g + 8 lane + j, one 16-byte load per g.
+template <int G>
+__device__ __forceinline__ void coarse16x_body(const Coarse16Args& a) {
     constexpr int kCap = 16;
+    constexpr int KX = 8 * G;                                            // keys per lane
+    typedef typename std::conditional<G == 1, uint8_t, uint32_t>::type MaskT;
     __shared__ float m_val[16][kCap];
     __shared__ int32_t m_id[16][kCap];
     __shared__ int32_t q_cnt[16], q_need[16], q_nmem[16], q_want[16], q_flag[16];      // flag: 1 emit, 2 ambiguous
     __shared__ int64_t q_row[16], q_cbase[16], q_pos[16];
-    __shared__ uint8_t s_hi[16][64], s_mem[16][64];                      // per query and lane: which of the lane's 8 keys
+    __shared__ MaskT s_hi[16][64], s_mem[16][64];                        // per query and lane: which of the lane's 8 G keys
     __shared__ uint32_t hist[320];
     __shared__ __attribute__((aligned(16))) uint16_t sp_c[8][kSparseW];
     __shared__ __attribute__((aligned(16))) float sp_v[8][kSparseW];
@@ -428,26 +434,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     const int64_t p0 = job.q_row0 + 32 * (int64_t)lt + ql0;
     const int row_lane = lane < n_live ? a.perm[p0 + lane] : 0;
     const int nl_w = n_live > 0 ? job.nc : 0;
-    auto keys_of = [&](int qi) -> uint4 {
-        uint4 raw = make_uint4(0, 0, 0, 0);
+    struct KeyRegs { uint4 v[G]; };
+    auto id_of = [&](int x) -> int { return 512 * (x >> 3) + lane * 8 + (x & 7); };      // list of the lane's key x = 8 g + j
+    auto keys_of = [&](int qi) -> KeyRegs {
+        KeyRegs raw;
         const int64_t rw = (int64_t)(uint32_t)__builtin_amdgcn_readlane(row_lane, qi);
-        if (qi < n_live && lane * 8 < nl_w) raw = *reinterpret_cast<const uint4*>(a.ckeys + rw * (int64_t)a.stride + lane * 8);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            raw.v[g] = make_uint4(0, 0, 0, 0);
+            if (qi < n_live && 512 * g + lane * 8 < nl_w)
+                raw.v[g] = *reinterpret_cast<const uint4*>(a.ckeys + rw * (int64_t)a.stride + 512 * g + lane * 8);
+        }
         return raw;
     };
-    uint4 raw_next = keys_of(0);
+    KeyRegs raw_next = keys_of(0);
     for (int qi = 0; qi < 16; ++qi) {
         const int64_t g = g0 + qi;                                       // tile-order slot of the query
         const bool live = qi < n_live;
         const int64_t p = live ? p0 + qi : 0;
         const int64_t row = live ? (int64_t)(uint32_t)__builtin_amdgcn_readlane(row_lane, qi) : 0;
         const int nl = live ? job.nc : 0;
-        uint32_t u[8];
+        uint32_t u[KX];
         {
-            const uint4 raw = raw_next;
+            const KeyRegs raw = raw_next;
             if (qi + 1 < 16) raw_next = keys_of(qi + 1);
-            const uint32_t wv[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) u[j] = (lane * 8 + j < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
+            for (int g = 0; g < G; ++g) {
+                const uint32_t wv[4] = {raw.v[g].x, raw.v[g].y, raw.v[g].z, raw.v[g].w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    u[8 * g + j] = (id_of(8 * g + j) < nl) ? ((wv[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) + 1u : 0u;
+            }
         }
         const int wnt = min(np, nl);
         // T = the wnt-th largest u: two histogram levels in LDS (high byte, then the low byte inside the bin that holds it), as in
@@ -458,7 +475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
                 hist[lane] = 0u; hist[lane + 64] = 0u; hist[lane + 128] = 0u; hist[lane + 192] = 0u; hist[lane + 256] = 0u;
                 wave_lds_sync();
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < KX; ++i) {
                     const int b = bin_of_key(u[i]);
                     if (b >= 0) __hip_atomic_fetch_add(&hist[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -494,7 +511,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         int n_hi = 0, n_mem = 0;
         uint32_t h = 0, m = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KX; ++j) {
             const int df = (int)u[j] - (int)T;
             const bool h1 = u[j] != 0u && df > delta;
             const bool m1 = u[j] != 0u && df <= delta && df >= -delta;
@@ -524,14 +541,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
             q_pos[qi] = p;
             q_flag[qi] = ((live && wnt > 0 && !handed) ? 1 : 0) | (ambiguous ? 2 : 0);
         }
-        s_hi[qi][lane] = (uint8_t)h;
-        s_mem[qi][lane] = (uint8_t)m;
+        s_hi[qi][lane] = (MaskT)h;
+        s_mem[qi][lane] = (MaskT)m;
         int base = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KX; ++j) {
             const bool m1 = ((m >> j) & 1u) && ambiguous;
             const unsigned long long gm = __ballot(m1);
-            if (m1) m_id[qi][base + __popcll(gm & lt_mask)] = lane * 8 + j;
+            if (m1) m_id[qi][base + __popcll(gm & lt_mask)] = id_of(j);
             base += __popcll(gm);
         }
         if (live && !handed)
@@ -579,9 +596,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         if (flag & 2) {
             const int nm = q_nmem[qi], need = q_need[qi];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < KX; ++j) {
                 if (!((m >> j) & 1u)) continue;
-                const int me = lane * 8 + j;
+                const int me = id_of(j);
                 float mine = 0.f;
                 for (int i = 0; i < nm; ++i) mine = m_id[qi][i] == me ? m_val[qi][i] : mine;
                 int rank = 0;
@@ -596,12 +613,119 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
         int32_t* out = a.probes + q_pos[qi] * np;
         int base = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KX; ++j) {
             const bool in = ((h | m) >> j) & 1u;
             const unsigned long long gm = __ballot(in);
-            if (in) out[base + __popcll(gm & lt_mask)] = lane * 8 + j;
+            if (in) out[base + __popcll(gm & lt_mask)] = id_of(j);
             base += __popcll(gm);
         }
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void coarse16x_kernel(Coarse16Args a) { coarse16x_body<1>(a); }
+__global__ __launch_bounds__(64) void coarse16x2_kernel(Coarse16Args a) { coarse16x_body<2>(a); }      // <= 1,024 lists
+__global__ __launch_bounds__(64) void coarse16x4_kernel(Coarse16Args a) { coarse16x_body<4>(a); }      // <= 2,048 lists
+
+// Buckets with more than 512 lists: the queries coarse16x{2,4}_kernel hands over (more than 16 keys within the bound of the
+// n_probe-th: many equal similarities -- rare).  One 256-thread workgroup per query, thread t holds the keys of lists t,
+// t + 256, ...; the n_probe-th largest key by the bitwise search with workgroup-wide counts, EVERY member re-evaluated by the
+// exact chain and ranked against all members (value descending, list id ascending: the staged order), the chosen lists
+// appended through an LDS cursor (any order: nothing depends on it).
+template <int KPT>      // keys per thread: 256 KPT >= the launch's most lists
+__global__ __launch_bounds__(256) void coarse16_big_kernel(Coarse16Args a) {
+    constexpr int kMem = 256 * KPT;
+    __shared__ float m_val[kMem];
+    __shared__ int32_t m_id[kMem];
+    __shared__ int32_t s_cnt[4], s_nmem, s_out;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t n_items = (int64_t)min(*a.ovf_count, a.ovf_cap);
+    auto block_count = [&](bool pred) -> int {                          // (every thread calls it the same number of times)
+        const int c = __popcll(__ballot(pred));
+        __syncthreads();
+        if (lane == 0) s_cnt[wv] = c;
+        __syncthreads();
+        return s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    };
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int64_t g = a.ovf_list[item];                             // tile-order slot of the query
+        const int64_t t = g >> 5;
+        const int ql = (int)(g & 31);
+        bool live = t < a.n_tiles;
+        DenseJob job{};
+        if (live) job = a.jobs[a.tile_job[t]];
+        const int lt = (int)(t - job.tile0);
+        live = live && 32 * lt + ql < job.nq;
+        const int64_t p = live ? job.q_row0 + 32 * (int64_t)lt + ql : 0;
+        const int64_t row = live ? a.perm[p] : 0;
+        const int nl = live ? job.nc : 0;
+        const int np = a.np;
+        uint32_t u[KPT];
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int id = tid + 256 * k;
+            u[k] = id < nl ? (uint32_t)a.ckeys[row * (int64_t)a.stride + id] + 1u : 0u;
+        }
+        const int want = min(np, nl);
+        uint32_t T = 0;
+        for (int bit = 16; bit >= 0; --bit) {
+            const uint32_t c = T | (1u << bit);
+            int mine = 0;
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) mine += u[k] >= c ? 1 : 0;
+            int cnt = 0;                                                // sum of `mine` over the workgroup: KPT + 1 one-bit rounds
+#pragma unroll
+            for (int b = 0; (1 << b) <= KPT; ++b) cnt += block_count((mine >> b) & 1) << b;
+            if (cnt >= want && want > 0) T = c;
+        }
+        const float Tv = (float)(max(T, 1u) - 1u) * (1.f / 65535.f);
+        const float e = 1.3e-3f * Tv + 1.2e-5f;
+        const int delta = 2 * ((int)ceilf(e * 65535.f) + 1) + 2;
+        if (tid == 0) { s_nmem = 0; s_out = 0; }
+        __syncthreads();
+        int32_t* out = a.probes + p * np;
+        int n_hi_mine = 0;
+        uint32_t memb = 0;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int df = (int)u[k] - (int)T;
+            const bool h1 = u[k] != 0u && df > delta;
+            const bool m1 = u[k] != 0u && df <= delta && df >= -delta;
+            n_hi_mine += h1 ? 1 : 0;
+            if (h1 && live && want > 0) out[atomicAdd(&s_out, 1)] = tid + 256 * k;      // certainly among the n_probe best
+            if (m1) {
+                memb |= 1u << k;
+                const int at = atomicAdd(&s_nmem, 1);
+                m_id[at] = tid + 256 * k;
+            }
+        }
+        int n_hi = 0;
+#pragma unroll
+        for (int b = 0; (1 << b) <= KPT; ++b) n_hi += block_count((n_hi_mine >> b) & 1) << b;
+        __syncthreads();
+        const int n_mem = s_nmem;
+        const int need = want - n_hi;                                   // places left for the members
+        for (int i = tid; i < n_mem; i += 256)
+            m_val[i] = exact_dot(a.X + row * a.d, a.C + (job.c_row0 + m_id[i]) * (int64_t)a.d, a.d);
+        __syncthreads();
+        if (live && want > 0) {
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                if (!((memb >> k) & 1u)) continue;
+                const int me = tid + 256 * k;
+                float mine = 0.f;
+                for (int i = 0; i < n_mem; ++i) mine = m_id[i] == me ? m_val[i] : mine;
+                int rank = 0;
+                for (int i = 0; i < n_mem; ++i) {
+                    const float v = m_val[i];
+                    const int id = m_id[i];
+                    rank += (v > mine || (v == mine && id < me)) ? 1 : 0;
+                }
+                if (rank < need) out[atomicAdd(&s_out, 1)] = me;
+            }
+        }
+        if (live)
+            for (int i = want + tid; i < np; i += 256) out[i] = -1;
+        __syncthreads();
     }
 }
 
@@ -630,6 +754,17 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
     if (a.stride <= 128) {
         hipLaunchKernelGGL((coarse16w_kernel<8>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL((coarse16_kernel<8, 16>), dim3(list_grid), dim3(256), 0, ctx->stream, a);
+    } else if (a.stride > 512) {
+        // 513..2,048 lists per bucket (`--batch_size 65536` on 40 k+-row windows): 16 / 32 keys per lane, workgroup-level overflow
+        FAL_REQUIRE(a.sp_cols && a.stride <= 2048, FAL_EINTERNAL, "coarse16: stride %d without the rows' sparse form", a.stride);
+        const unsigned big_grid = (unsigned)std::min<int64_t>(a.n_tiles * 32, (int64_t)ctx->num_cus * 8);
+        if (a.stride <= 1024) {
+            hipLaunchKernelGGL(coarse16x2_kernel, dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL((coarse16_big_kernel<4>), dim3(big_grid), dim3(256), 0, ctx->stream, a);
+        } else {
+            hipLaunchKernelGGL(coarse16x4_kernel, dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
+            hipLaunchKernelGGL((coarse16_big_kernel<8>), dim3(big_grid), dim3(256), 0, ctx->stream, a);
+        }
     } else {
         if (a.sp_cols) hipLaunchKernelGGL(coarse16x_kernel, dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
         else hipLaunchKernelGGL((coarse16w_kernel<32>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);

@@ -654,12 +654,14 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         const int64_t wseg = std::min<int64_t>(kAssignSeg, std::max<int64_t>(256, ceil_div(wave_rows, (int64_t)ctx->num_cus * 16 * 32) * 32));
         // buckets with <= 128 lists and float16 rows at hand: the prefiltered assignment (assign16.hip; identical results)
         const bool use16 = X16 != nullptr && assign16_supports(low_dim) && ivf->rows_signed == 0;
-        std::vector<AssignJob> hjobs, mjobs, gjobs;    // single-group jobs; merge jobs and their group jobs (129..512 lists)
+        std::vector<AssignJob> hjobs, mjobs, gjobs;    // single-group jobs; merge jobs and their group jobs (129..kAssignMergeLists lists)
+        int merge_max_lists = 0;
         for (const BucketDev& b : bk) {
             if (use16 && b.n_list <= kAssignGroup) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg)
                     hjobs.push_back({b.row0 + s0, b.list0, (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0), b.n_list, 0, 0});
-            } else if (use16 && b.n_list <= 4 * kAssignGroup) {
+            } else if (use16 && b.n_list <= kAssignMergeLists) {
+                merge_max_lists = std::max(merge_max_lists, (int)b.n_list);
                 for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg) {
                     const int32_t nr = (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0);
                     mjobs.push_back({b.row0 + s0, b.list0, nr, b.n_list, 0, 0});
@@ -743,7 +745,8 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                     B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * ivf->ckeys_stride, (void**)&ivf->ckeys));
                 }
                 B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, n_single, n_merge, n_group, n,
-                                      ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr, ivf->ckeys_stride, sp_cols, sp_vals));
+                                      ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr, ivf->ckeys_stride, sp_cols, sp_vals,
+                                      merge_max_lists));
             }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,

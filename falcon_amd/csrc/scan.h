@@ -57,6 +57,10 @@ int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* 
 // Shared-stream list assignment (assign.hip): job = (a segment of a bucket's rows) x (up to 128 of its centroids)
 constexpr int kAssignSeg = 2048;      // rows per segment
 constexpr int kAssignGroup = 128;     // centroids per job: one 32-centroid tile per wave
+constexpr int kAssignMergeLists = 2048;     // lists per bucket up to which the float16 assignment runs in groups of 128 + a merge
+                                            // (16 groups = 64 subgroups of 32; round 4 stopped at 512 and sent a 1,024-list
+                                            // bucket -- `--batch_size 65536` on 45 k-row windows -- to the exact fp32 kernels:
+                                            // build 584 ms instead of 77 per 10 M spectra, profiles/NOTES.md r5)
 struct AssignJob {
     int64_t row0;        // first row of the segment (sorted rows = rows of X)
     int64_t cent0;       // global row of the group's first centroid
@@ -70,13 +74,13 @@ struct AssignJob {
 int launch_assign(fal_ctx* ctx, int stage, const float* X, const float* centroids, int d, const AssignJob* jobs, int64_t n_jobs,
                   int64_t n_wave_jobs, int64_t n, unsigned long long* keys, int32_t* assign);
 // Assignment with a float16 prefilter (assign16.hip): buckets with <= 128 lists in one job per row segment, buckets with
-// <= 512 lists in groups of 128 + a merge over the groups; identical results.  Job table layout: see launch_assign16
+// <= kAssignMergeLists lists in groups of 128 + a merge over the groups; identical results.  Job table layout: see launch_assign16
 bool assign16_supports(int d);
 int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count);
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
                     uint16_t* ckeys = nullptr, int ckeys_stride = 0, const uint16_t* sp_cols = nullptr,
-                    const float* sp_vals = nullptr);
+                    const float* sp_vals = nullptr, int merge_max_lists = 4 * kAssignGroup);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order

@@ -506,7 +506,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     FAL_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (size_t)(n_slots + 2), (void**)&totals));
     FAL_CHECK_HIP(hipMemsetAsync(totals, 0, sizeof(int64_t) * (size_t)(n_slots + 2), st));
     // the final k-means pass left the (row, centroid) similarities behind as 16-bit keys: no second scan (coarse16.hip)
-    const bool from_keys = ivf->ckeys != nullptr && ivf->X != nullptr && ivf->ckeys_stride <= 512;
+    const bool from_keys = ivf->ckeys != nullptr && ivf->X != nullptr &&
+                           (ivf->ckeys_stride <= 512 || (ivf->ckeys_stride <= 2048 && ivf->sp_cols != nullptr));
     if (from_keys) {
         Coarse16Args ca{ivf->ckeys, ivf->ckeys_stride, ivf->X, ivf->centroids, d, coarse_dev, (int)coarse.size(), ivf_tiles, nullptr,
                         ivf->perm, np, probes};

@@ -184,6 +184,35 @@ def test_coarse_quantiser_from_the_build_keys_with_up_to_512_lists(ctx):
         assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
 
 
+def test_float16_assignment_and_keyed_quantiser_with_1024_and_2048_lists(ctx):
+    """buckets with 513..2,048 lists (`--batch_size 65536` on windows of 40 k+ spectra: SURVEY 8d's C4 row is n_list 1,024): the
+    float16 assignment merges up to 16 groups of 128 centroids, the keys have up to 2,048 columns, the quantiser holds 16 / 32
+    keys per lane (coarse16x2 / x4) and hands queries with many equal keys to the workgroup-level kernel -- index and search equal
+    the exactly built index's bit for bit.  (Round 4 sent such buckets to the exact fp32 kernels: 7.5 x the build time.)"""
+    import torch
+    sizes = [24000, 3000, 43000]
+    nl = np.array([1024, 64, 2048], np.int32)
+    off, X, mz, rt = _buckets(sizes, 128, 69)
+    for b in (0, 2):                                            # 40 identical k-means seeds -> 40 identical centroids: exact ties,
+        seeds = off[b] + (np.arange(nl[b], dtype=np.int64) * sizes[b]) // nl[b]      # more members than a wave's lists hold
+        X[seeds[5:45]] = X[seeds[5]]
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    plain = ctx.ivf_build(Xd, off, nl, kmeans_iters=3)
+    keyed = ctx.ivf_build(Xd, off, nl, kmeans_iters=3, Xkm=Xd.to(torch.float16).contiguous())
+    for a, b in zip(plain.export(), keyed.export()):
+        assert torch.equal(a, b)                                # centroids, assignment, lists: the same index
+    for n_probe in (32, 5):
+        s0, i0 = plain.search(n_probe, 64)
+        s1, i1 = keyed.search(n_probe, 64)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    mz_d = torch.from_numpy(mz).to(ctx.tdev)
+    n0 = plain.search_neighbors(32, 64, mz_d, None, 20.0, "ppm", None, 32)
+    pre = ctx.ivf_build(Xd, off, nl, kmeans_iters=3, Xkm=Xd.to(torch.float16).contiguous(), Xpre=Xd.to(torch.float16).contiguous(),
+                        prefilter_which=2)
+    n1 = pre.search_neighbors(32, 64, mz_d, None, 20.0, "ppm", None, 32)
+    assert torch.equal(n0[0], n1[0]) and torch.equal(n0[1].view(torch.int32), n1[1].view(torch.int32))
+
+
 @pytest.mark.parametrize("d,n_probe", [(400, 16), (400, 3), (128, 8), (64, 1)])
 def test_coarse_quantiser_from_the_build_keys_gives_the_same_search(ctx, d, n_probe):
     """an index built with the float16 k-means prefilter keeps the final pass's (row, centroid) similarities as 16-bit keys and

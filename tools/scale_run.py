@@ -8,6 +8,7 @@ dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"
 low_dim = int(sys.argv[5]) if len(sys.argv) > 5 else 400
 mz_lo = float(sys.argv[6]) if len(sys.argv) > 6 else 400.0      # a narrower precursor range = denser buckets (BASELINE configs[3] regime)
 mz_hi = float(sys.argv[7]) if len(sys.argv) > 7 else 1200.0
+batch_size = int(sys.argv[8]) if len(sys.argv) > 8 else 2 ** 15   # (2**16 with ~44 k-row windows: n_list 1,024 -- SURVEY 8d's C4 row)
 ctx = dv.Context(0); pipe = ClusterPipeline(ctx)
 t = time.time(); data = synth.generate_device(N, ctx.tdev, mz_lo=mz_lo, mz_hi=mz_hi); print(f"generated {N} in {time.time()-t:.1f}s", flush=True)
 p = AnnParams(scan=scan, n_probe=n_probe, dtype=dtype, low_dim=low_dim)
@@ -22,7 +23,7 @@ for rep in range(REPS):
     if rep == REPS - 1: ctx.enable_timing(True)
     tot = 0; st = {}
     for ds in parts:
-        labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, 2**15, p)
+        labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, batch_size, p)
         tot += int(medoids.numel())
         if rep == REPS - 1:
             for k in ("vectorize", "build", "coarse", "scan", "select", "filter", "dbscan", "tail"):
@@ -30,4 +31,4 @@ for rep in range(REPS):
             st["pairs"] = st.get("pairs", 0) + ctx.counter(0); st["coarse_pairs"] = st.get("coarse_pairs", 0) + ctx.counter(1)
     torch.cuda.synchronize(); dt = time.time() - t
     print(f"rep {rep}: {N} spectra in {dt*1e3:.1f} ms -> {N/dt/1e6:.1f} M spectra/s, {tot} clusters, mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB torch", flush=True)
-print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()})
+print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}, "n_list max", int(np.max(pipe.last["n_list"])))
