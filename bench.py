@@ -198,6 +198,8 @@ def main():
                     help="BASELINE configs[3] at its own size (n_probe 32, n_neighbors_ann 128), run in --big-chunks bucket shares "
                          "(ClusterPipeline.run_chunked); 0 = skip")
     ap.add_argument("--big-chunks", type=int, default=4)
+    ap.add_argument("--skew-spectra", type=int, default=2_000_000,
+                    help="the skewed-workload entry of `configs` (synth skew=True: log-normal window occupancy, 5..50 peaks); 0 = skip")
     ap.add_argument("--partitions", choices=["auto", "concurrent", "pipelined"], default="auto",
                     help="how the two charge partitions of a step are scheduled: concurrent = a host thread + HIP stream + context "
                          "each (PartitionRunner; the reference clusters its blocks on a thread pool, cluster.py:115-136), pipelined = "
@@ -212,7 +214,7 @@ def main():
     import torch.distributed as dist
     from falcon_amd import synth
     from falcon_amd import distributed as fdist
-    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, PartitionRunner, SpectrumDataset
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, PartitionRunner, SpectrumDataset, n_list_rule
     from falcon_amd.device import Context
 
     rank = int(os.environ.get("RANK", "0"))
@@ -265,7 +267,7 @@ def main():
         base.update(kw)
         return AnnParams(**base)
 
-    def make_parts(n_total, first_block=0, mz_lo=400.0, mz_hi=1200.0, replicas=1):
+    def make_parts(n_total, first_block=0, mz_lo=400.0, mz_hi=1200.0, replicas=1, skew=False):
         """the dataset, split by precursor charge (falcon.py:151-160), resident in HBM -> [SpectrumDataset].
         `replicas` = R > 1: R statistically identical blocks of n_total / R spectra each (generator blocks first_block,
         first_block + 1, ...), block k's charges relabelled (2, 3) -> (2 + 2k, 3 + 2k): a dataset of 2R charge partitions"""
@@ -274,10 +276,10 @@ def main():
         for k in range(replicas):
             fb = first_block + k * ((per + synth.BLOCK - 1) // synth.BLOCK)
             if args.generator == "device":
-                data = synth.generate_device(per, dev, seed=42, first_block=fb, mz_lo=mz_lo, mz_hi=mz_hi)
+                data = synth.generate_device(per, dev, seed=42, first_block=fb, mz_lo=mz_lo, mz_hi=mz_hi, skew=skew)
                 sel = lambda c: synth.select_charge_device(data, c)
             else:
-                data = synth.generate(per, seed=42, first_block=fb, mz_lo=mz_lo, mz_hi=mz_hi)
+                data = synth.generate(per, seed=42, first_block=fb, mz_lo=mz_lo, mz_hi=mz_hi, skew=skew)
                 sel = lambda c: synth.select_charge(data, c)
             for charge in (2, 3):
                 c = sel(charge)
@@ -398,6 +400,23 @@ def main():
         ctx.enable_timing(True)
         stages = []
         step(parts, run_args, stages)
+        ctx.enable_timing(False)
+        return stages
+
+    def staged_share(parts, run_args, chunks):
+        """per-kernel timing of ONE bucket share of a job that runs in `chunks` shares (configs[3] at 50 M spectra): share 0 of the
+        same deal `run_chunked` executes, partition by partition, serial, HIP events around every stage"""
+        owners = pipe.plan_shards(ctx, parts, run_args[4], run_args[5], chunks)
+
+        def one(collect):
+            for j, ds in enumerate(parts):
+                o = pipe.run_many([ds], *run_args, shard=(0, chunks, [owners[j]]))
+                if collect is not None:
+                    collect.append(collect_stages(int(o[0][0].numel())))
+        one(None)
+        ctx.enable_timing(True)
+        stages = []
+        one(stages)
         ctx.enable_timing(False)
         return stages
 
@@ -551,33 +570,42 @@ def main():
         del parts
         torch.cuda.empty_cache()
         was_concurrent = concurrent["on"]
-        plan = [("f32", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 1200.0, 1),
-                ("f16", args.configs_spectra, dict(low_dim=800, dtype="f16", scan="f32"), 1200.0, 1),
+        plan = [("f32", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 1200.0, 1, args.batch_size),
+                ("f16", args.configs_spectra, dict(low_dim=800, dtype="f16", scan="f32"), 1200.0, 1, args.batch_size),
                 # BASELINE configs[3]'s bucket regime on one GPU: the same number of spectra in a quarter of the precursor
                 # range (buckets of 20-35 k rows: n_list 512) with that config's n_probe = 32
-                ("f32-dense", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32), 600.0, 1)]
+                ("f32-dense", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32), 600.0, 1, args.batch_size),
+                # SURVEY 8d's C4 row as written: 1 m/z windows of ~44 k charge-2 spectra kept whole by `--batch_size 65536`
+                # (config.py:119-124) -> n_list 1,024, n_probe 32: more than 512 lists per bucket (VERDICT r4 missing #4)
+                ("f32-b64k", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32), 560.0, 1, 2 ** 16),
+                # a workload that is NOT uniform (synth skew=True: log-normal occupancy of the 1 m/z windows, 5..50 peaks per
+                # spectrum): 300-row flat buckets next to 2^15-row indexed ones in one job
+                ("f32-skew", args.skew_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 1200.0, 1, args.batch_size)]
+        plan = [e for e in plan if e[1] > 0]
         if args.big_spectra > 0:
             # ... and configs[3] itself: 50 M spectra; the working set of one pass (~260 GB) does not fit beside the dataset,
             # so the precursor buckets run in 4 shares one after the other (ClusterPipeline.run_chunked)
             plan.append(("f32-50M", args.big_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32, n_neighbors_ann=128),
-                         1200.0, args.big_chunks))
+                         1200.0, args.big_chunks, args.batch_size))
         big, big_key = None, None
-        for name, n_cfg, kw, hi, chunks in plan:
-            if big_key != (n_cfg, hi):
+        for name, n_cfg, kw, hi, chunks, batch in plan:
+            skew = name == "f32-skew"
+            if big_key != (n_cfg, hi, skew):
                 del big
                 torch.cuda.empty_cache()
-                big = make_parts(n_cfg, mz_hi=hi)
-                big_key = (n_cfg, hi)
+                big = make_parts(n_cfg, mz_hi=hi, skew=skew)
+                big_key = (n_cfg, hi, skew)
             pc = params(**kw)
-            ra = (20.0, "ppm", None, 0.05, args.batch_size, pc)
+            ra = (20.0, "ppm", None, 0.05, batch, pc)
             # (five timed steps after three priming passes: with three a single late scratch growth -- a GB-sized hipMalloc of
             #  one of the two partition contexts -- showed up as + 40 ms on the mean of a 120 ms step)
-            steps_c = 5 if chunks == 1 else 2
+            steps_c = 5 if chunks == 1 else 3
             try:
                 dtc = timed(big, ra, steps_c, 1, prime=3 if chunks == 1 else 2, chunks=chunks)
-                sc = None
                 if chunks == 1:
                     sc = summarize(staged(big, ra), pc.low_dim, pc, 2 if name == "f16" else 4)
+                else:                                             # one bucket share of the chunked job, its own staged pass
+                    sc = summarize(staged_share(big, ra, chunks), pc.low_dim, pc, 4)
             except Exception as e:                                # pragma: no cover -- reported, never hidden
                 extra.append({"workload": f"{n_cfg} spectra {name}", "error": repr(e)[:300]})
                 continue
@@ -585,15 +613,26 @@ def main():
             entry = {
                 "workload": f"{n_cfg} synthetic spectra on 1 GPU (charges 2+3, precursor m/z 400-{hi:.0f}), low_dim={pc.low_dim} "
                             f"{name.split('-')[0]}, n_neighbors={pc.n_neighbors}, n_neighbors_ann={pc.n_neighbors_ann}, "
-                            f"n_probe={pc.n_probe}, eps={pc.eps}, precursor_tol=20ppm, mz_interval={pc.mz_interval}"
+                            f"n_probe={pc.n_probe}, eps={pc.eps}, precursor_tol=20ppm, mz_interval={pc.mz_interval}, batch_size={batch}"
                             + (f", precursor buckets in {chunks} shares run one after the other" if chunks > 1 else ""),
                 "baseline_config": {"f32": "configs[2] dataset on one GPU", "f16": "configs[4]",
                                     "f32-dense": "configs[3] regime (n_list 512, n_probe 32, n_neighbors_ann 128) at one GPU's size: "
                                                  "precursors in 400-600 m/z",
+                                    "f32-b64k": "SURVEY 8d's C4 row as written (43,750-row buckets, n_list 1,024, n_probe 32) at one "
+                                                "GPU's size: precursors in 400-560 m/z, batch_size 65536",
+                                    "f32-skew": "none (VERDICT r4 next #7): configs[1]'s parameters on a skewed dataset -- log-normal window "
+                                                "occupancy (fullest window ~70x the median), 5..50 peaks per spectrum",
                                     "f32-50M": "configs[3] (50 M spectra, n_probe 32, n_neighbors_ann 128) at its own size"}[name],
                 "steps": steps_c, "ms_per_step": dtc / steps_c * 1e3, "value": n_big * steps_c / dtc, "unit": "spectra/s",
                 "dtype": name.split("-")[0]}
-            if sc is not None:
+            if chunks > 1:
+                entry["staged_share"] = {"what": f"share 0 of {chunks} (the deal run_chunked executes), serial staged pass",
+                                         "spectra": sc["n_rows"], "stage_ms": sc["stage_ms"], "pairs": sc["pairs"]}
+                entry["roofline"] = roofline_of(
+                    sc, "list16_kernel<25> (f16 MFMA 32x32x16, list-major), one bucket share of the 50 M job", PEAK_MFMA_F16_TFLOPS,
+                    "f16 MFMA 2.5 PFLOP/s dense", None,
+                    note="work and launches of ONE of the job's bucket shares (its own serial staged pass)")
+            elif sc is not None:
                 entry.update({"stage_ms": sc["stage_ms"], "pairs_per_step": sc["pairs"]})
                 if name == "f16" and not pc.f16_index:
                     entry["roofline"] = roofline_of(sc, "scan16_kernel<50,1> (f16 MFMA 32x32x16, LDS-staged candidates, exhaustive)",
@@ -610,12 +649,21 @@ def main():
                     entry["roofline"] = roofline_of(
                         sc, "list16_kernel<25> (f16 MFMA 32x32x16, list-major: <= 128 rows of a list resident, the queries probing it "
                             "stream through LDS)", PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense",
-                        {"f32": "10M_f32", "f32-dense": "10M_f32_dense"}[name],
+                        {"f32": "10M_f32", "f32-dense": "10M_f32_dense", "f32-b64k": "10M_f32_b64k", "f32-skew": None}[name],
                         note="the kernel scans every probed (query, candidate) pair on the f16 matrix cores to 16-bit keys; the exact "
                              "float32 work (pair chains, k-th key resolution: stages scan / select) is in scan_plus_topk")
                 entry["prefilter_fallback_rows"] = int(ctx.counter(5))
-            else:
-                entry["note"] = "per-stage timing and the kernel roofline are those of the configs[3]-regime entry above (same kernels)"
+            if skew:
+                # balance of the job as the multi-GPU deal would cut it (window histogram -> cost model -> deal_job), 8 ranks
+                counts = ctx.window_counts([ds.precursor_mz for ds in big], pc.mz_interval)
+                costs = fdist.window_costs(counts.ravel(), batch, pc.n_probe).reshape(counts.shape)
+                owners = fdist.deal_job(list(costs), 8)
+                loads = sum(np.bincount(o, weights=c, minlength=8) for o, c in zip(owners, costs))
+                occ = counts[0][counts[0] > 0]
+                entry["skew"] = {"window_occupancy_charge2": {"max": int(occ.max()), "median": float(np.median(occ)), "windows": int(len(occ))},
+                                 "n_list_of_the_fullest_bucket": int(n_list_rule(np.array([min(int(occ.max()), batch)]), pc.n_probe)[0]),
+                                 "deal_8_ranks_worst_over_mean_modelled": float(loads.max() / loads.mean()),
+                                 "scan_plus_topk_ms_per_Gpair": sc["topk_ms"] / max(sc["pairs"], 1) * 1e9}
             extra.append(entry)
         del big
         torch.cuda.empty_cache()
@@ -667,7 +715,10 @@ def main():
                                    f"n_neighbors={args.n_neighbors}, n_neighbors_ann={args.n_neighbors_ann}, "
                                    f"n_probe={args.n_probe}, eps={args.eps}, precursor_tol=20ppm, "
                                    f"mz_interval={args.mz_interval}, batch_size={args.batch_size}",
-                       "generator": f"falcon_amd.synth ({args.generator}; SURVEY 8d recipe, seed 42)",
+                       "generator": ("device (falcon_amd.synth.generate_device: torch RNG on the GPU, seed 42; statistically SURVEY 8d's "
+                                     "recipe -- same distributions and parameters, not its PCG64 stream bit for bit)"
+                                     if args.generator == "device" else
+                                     "numpy (falcon_amd.synth.generate: SURVEY 8d's recipe, numpy default_rng([42, block]), PCG64)"),
                        "exchange": (args.exchange + " (CSR all-gatherv of neighbour lists + labels + rows, overlapped with "
                                     "the next step)") if exchanging else "none",
                        "partitions": ("serial" if args.serial else
@@ -704,6 +755,22 @@ def main():
             out["strong_scaling"] = strong_extra
         if extra:
             out["configs"] = extra
+            # The path BASELINE.json's north_star names -- 10 M spectra on one GPU through "IVF list build + n_probe query" -- as a
+            # first-class object: `value` above is configs[1] (1 M spectra: every bucket flat, build = coarse = 0)
+            ns = next((e for e in extra if e.get("baseline_config") == "configs[2] dataset on one GPU" and "roofline" in e), None)
+            if ns is not None:
+                r = ns["roofline"]
+                out["north_star"] = {
+                    "workload": ns["workload"], "value": ns["value"], "unit": "spectra/s", "ms_per_step": ns["ms_per_step"],
+                    "stage_ms": ns["stage_ms"], "target": ">= 10 M spectra end-to-end on one MI355X, cosine kernel >= 0.50 of the HBM roof",
+                    "cosine_kernel_scan_plus_topk": {"ms": r["scan_plus_topk"]["ms"],
+                                                     "frac_of_hbm_roof": r["scan_plus_topk"]["frac_of_hbm_roof"],
+                                                     "frac_of_f16_mfma_peak": r["scan_plus_topk"]["frac_of_mfma_peak"],
+                                                     "algorithmic_bytes": r["scan_plus_topk"]["algorithmic_bytes"]},
+                    "list16_kernel": {"avg_launch_ms": r["avg_launch_ms"], "launches": r["launches"],
+                                      "frac_of_f16_mfma_peak": r["frac_of_mfma_peak"], "frac_of_hbm_roof": r["frac_of_hbm_roof"],
+                                      "traffic": r["traffic"]},
+                    "index_build_ms": ns["stage_ms"]["build"], "coarse_ms": ns["stage_ms"]["coarse"]}
         if world == 1 and not args.no_cpu_baseline:
             hosts = [{k: getattr(x, k).cpu().numpy() for k in ("precursor_mz", "retention_time", "mz", "intensity", "indptr")}
                      for x in parts]

@@ -16,9 +16,21 @@ BLOCK = 1_000_000
 N_TEMPLATE_PEAKS = 50
 N_NOISE_PEAKS = 5
 MAX_PEAKS = 50
+SKEW_SIGMA = 1.0          # `skew=True`: log-normal occupancy of the 1 m/z precursor windows (sigma of the log)
+SKEW_MIN_PEAKS = 5        # ... and 5..50 peaks per template instead of 50
 
 
-def _block(n: int, block: int, seed: int, mz_lo: float, mz_hi: float):
+def skew_window_weights(seed: int, mz_lo: float, mz_hi: float) -> np.ndarray:
+    """`skew=True`: the probability of every 1 m/z precursor window of [mz_lo, mz_hi) -- LogNormal(0, SKEW_SIGMA) weights drawn
+    from the seed alone (every block of a dataset uses the same windows), normalised.  With 800 windows the fullest holds
+    ~70x the median's spectra: a 32 k-row window and a few of 8-14 k rows among 500-row ones at 1 M spectra (seed 42) (real precursor
+    distributions are not uniform; SURVEY 8d's recipe is)."""
+    n_win = max(1, int(np.ceil(mz_hi - mz_lo)))
+    w = np.random.default_rng([seed, 0x5CE3]).lognormal(0.0, SKEW_SIGMA, n_win)
+    return w / w.sum()
+
+
+def _block(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, skew: bool = False):
     rng = np.random.default_rng([seed, block])
     f32 = np.float32
     n_single = int(round(0.2 * n))
@@ -34,10 +46,20 @@ def _block(n: int, block: int, seed: int, mz_lo: float, mz_hi: float):
     tmpl = np.repeat(np.arange(n_t), sizes)                      # template of every spectrum
     assert len(tmpl) == n
     # templates
-    t_pmz = rng.uniform(mz_lo, mz_hi, n_t).astype(f32)
+    if skew:
+        pw = skew_window_weights(seed, mz_lo, mz_hi)
+        win = rng.choice(len(pw), size=n_t, p=pw)
+        t_pmz = np.minimum(mz_lo + win + rng.random(n_t), np.nextafter(f32(mz_hi), f32(0))).astype(f32)
+    else:
+        t_pmz = rng.uniform(mz_lo, mz_hi, n_t).astype(f32)
     t_charge = np.where(rng.random(n_t) < 0.7, 2, 3).astype(np.int8)
     t_mz = np.sort(rng.uniform(101.0, 1500.0, (n_t, N_TEMPLATE_PEAKS)), axis=1).astype(f32)
     t_int = rng.lognormal(0.0, 1.0, (n_t, N_TEMPLATE_PEAKS)).astype(f32)
+    t_valid = None
+    if skew:                                                     # SKEW_MIN_PEAKS .. 50 peaks per template, a random subset
+        k_t = rng.integers(SKEW_MIN_PEAKS, N_TEMPLATE_PEAKS + 1, n_t)
+        ranks = np.argsort(np.argsort(rng.random((n_t, N_TEMPLATE_PEAKS)), axis=1), axis=1)
+        t_valid = ranks < k_t[:, None]
     # members
     P = N_TEMPLATE_PEAKS + N_NOISE_PEAKS
     mz = np.empty((n, P), f32)
@@ -46,6 +68,9 @@ def _block(n: int, block: int, seed: int, mz_lo: float, mz_hi: float):
     it[:, :N_TEMPLATE_PEAKS] = t_int[tmpl] * rng.lognormal(0.0, 0.2, (n, N_TEMPLATE_PEAKS)).astype(f32)
     keep = rng.random((n, P)) >= 0.10                            # 10 % peak dropout
     keep[:, N_TEMPLATE_PEAKS:] = True
+    if t_valid is not None:
+        keep[:, :N_TEMPLATE_PEAKS] &= t_valid[tmpl]
+        keep[:, N_TEMPLATE_PEAKS:] = np.arange(N_NOISE_PEAKS)[None, :] < ((k_t[tmpl] + 9) // 10)[:, None]      # 1 noise peak per 10
     base = np.max(np.where(keep[:, :N_TEMPLATE_PEAKS], it[:, :N_TEMPLATE_PEAKS], 0), axis=1, keepdims=True)
     base = np.maximum(base, f32(1e-6))
     mz[:, N_TEMPLATE_PEAKS:] = rng.uniform(101.0, 1500.0, (n, N_NOISE_PEAKS)).astype(f32)
@@ -76,13 +101,15 @@ def _block(n: int, block: int, seed: int, mz_lo: float, mz_hi: float):
                 truth=tmpl[perm].astype(np.int64))
 
 
-def generate(n: int, seed: int = 42, first_block: int = 0, mz_lo: float = 400.0, mz_hi: float = 1200.0):
+def generate(n: int, seed: int = 42, first_block: int = 0, mz_lo: float = 400.0, mz_hi: float = 1200.0, skew: bool = False):
     """-> dict(mz f32[nnz], intensity f32[nnz], indptr i64[n+1], precursor_mz f32[n],
-    retention_time f32[n], precursor_charge i8[n], truth i64[n])."""
+    retention_time f32[n], precursor_charge i8[n], truth i64[n]).
+    `skew`: log-normal occupancy of the 1 m/z precursor windows and 5..50 peaks per spectrum (`skew_window_weights`); the
+    default (False) is SURVEY 8d's recipe and its random stream, unchanged."""
     parts, done, b, t_off = [], 0, first_block, 0
     while done < n:
         m = min(BLOCK, n - done)
-        p = _block(m, b, seed, mz_lo, mz_hi)
+        p = _block(m, b, seed, mz_lo, mz_hi, skew)
         p["truth"] = p["truth"] + t_off
         t_off = int(p["truth"].max()) + 1
         parts.append(p)
@@ -116,7 +143,7 @@ def select_charge(data: dict, charge: int) -> dict:
 # spectra are statistically -- not bitwise -- the numpy ones.  Parity tests keep the numpy generator
 # (the oracle runs on its output); tests/test_host_logic.py::test_device_generator_matches_the_numpy_recipe_statistically compares the statistics of the two.
 # ---------------------------------------------------------------------------------------------
-def _block_device(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, dev):
+def _block_device(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, dev, skew: bool = False):
     import torch
     g = torch.Generator(device=dev)
     g.manual_seed(int(seed) * 1_000_003 + int(block))
@@ -140,10 +167,21 @@ def _block_device(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, dev
     sizes = torch.cat([sizes, torch.ones(n - int(sizes.sum().item()), dtype=torch.long, device=dev)])
     n_t = sizes.numel()
     tmpl = torch.repeat_interleave(torch.arange(n_t, device=dev), sizes)
-    t_pmz = uni(mz_lo, mz_hi, (n_t,)).to(f32)
+    if skew:                                                                           # (the numpy generator's windows)
+        pw = torch.from_numpy(skew_window_weights(seed, mz_lo, mz_hi)).to(dev)
+        win = torch.multinomial(pw, n_t, replacement=True, generator=g)
+        t_pmz = (mz_lo + win.double() + torch.rand(n_t, generator=g, device=dev, dtype=torch.float64)).to(f32)
+        t_pmz = torch.minimum(t_pmz, torch.nextafter(torch.tensor(mz_hi, dtype=f32, device=dev), torch.zeros((), dtype=f32, device=dev)))
+    else:
+        t_pmz = uni(mz_lo, mz_hi, (n_t,)).to(f32)
     t_charge = torch.where(torch.rand(n_t, generator=g, device=dev) < 0.7, 2, 3).to(torch.int8)
     t_mz = torch.sort(uni(101.0, 1500.0, (n_t, N_TEMPLATE_PEAKS)), dim=1).values.to(f32)
     t_int = torch.exp(randn((n_t, N_TEMPLATE_PEAKS)))                                  # LogNormal(0, 1)
+    t_valid = None
+    if skew:
+        k_t = torch.randint(SKEW_MIN_PEAKS, N_TEMPLATE_PEAKS + 1, (n_t,), generator=g, device=dev)
+        ranks = torch.argsort(torch.argsort(torch.rand((n_t, N_TEMPLATE_PEAKS), generator=g, device=dev), dim=1), dim=1)
+        t_valid = ranks < k_t[:, None]
     P, T = N_TEMPLATE_PEAKS + N_NOISE_PEAKS, N_TEMPLATE_PEAKS
     mz = torch.empty((n, P), dtype=f32, device=dev)
     it = torch.empty((n, P), dtype=f32, device=dev)
@@ -151,6 +189,9 @@ def _block_device(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, dev
     it[:, :T] = t_int[tmpl] * torch.exp(randn((n, T)) * 0.2)
     keep = torch.rand((n, P), generator=g, device=dev) >= 0.10                         # 10 % peak dropout
     keep[:, T:] = True
+    if t_valid is not None:
+        keep[:, :T] &= t_valid[tmpl]
+        keep[:, T:] = torch.arange(N_NOISE_PEAKS, device=dev)[None, :] < ((k_t[tmpl] + 9) // 10)[:, None]
     base = torch.where(keep[:, :T], it[:, :T], torch.zeros((), device=dev)).amax(1, keepdim=True).clamp_min(1e-6)
     mz[:, T:] = uni(101.0, 1500.0, (n, N_NOISE_PEAKS)).to(f32)
     it[:, T:] = (uni(0.0, 0.05, (n, N_NOISE_PEAKS)) * base.double()).to(f32)
@@ -174,13 +215,14 @@ def _block_device(n: int, block: int, seed: int, mz_lo: float, mz_hi: float, dev
                 precursor_charge=charge[perm], truth=tmpl[perm].long())
 
 
-def generate_device(n: int, device, seed: int = 42, first_block: int = 0, mz_lo: float = 400.0, mz_hi: float = 1200.0):
+def generate_device(n: int, device, seed: int = 42, first_block: int = 0, mz_lo: float = 400.0, mz_hi: float = 1200.0,
+                    skew: bool = False):
     """`generate` on a torch device -> the same dict with device tensors (indptr i64[n+1])."""
     import torch
     parts, done, b, t_off = [], 0, first_block, 0
     while done < n:
         m = min(BLOCK, n - done)
-        p = _block_device(m, b, seed, mz_lo, mz_hi, device)
+        p = _block_device(m, b, seed, mz_lo, mz_hi, device, skew)
         p["truth"] = p["truth"] + t_off
         t_off = int(p["truth"].max().item()) + 1
         parts.append(p)

@@ -82,7 +82,7 @@ def _check_partition(ctx, ds, lab, med, lab2, med2, last, p, dist_tol, check_val
     return n
 
 
-def _run_and_check(n_total, p, generator, dist_tol):
+def _run_and_check(n_total, p, generator, dist_tol, skew=False):
     import torch
     from falcon_amd import synth
     from falcon_amd.cluster.cluster import ClusterPipeline
@@ -90,13 +90,16 @@ def _run_and_check(n_total, p, generator, dist_tol):
     ctx = Context(0)
     pipe = ClusterPipeline(ctx)
     if generator == "device":
-        data = synth.generate_device(n_total, ctx.tdev, seed=42)
+        data = synth.generate_device(n_total, ctx.tdev, seed=42, skew=skew)
         parts = _parts(ctx, data, synth.select_charge_device)
     else:
-        parts = _parts(ctx, synth.generate(n_total, seed=42), synth.select_charge)
+        parts = _parts(ctx, synth.generate(n_total, seed=42, skew=skew), synth.select_charge)
     args = (20.0, "ppm", None, 0.05, 2 ** 15, p)
     outs = pipe.run_many(parts, *args)
     lasts = [dict(x) for x in pipe.lasts]
+    if skew:                                                      # flat and indexed buckets side by side, tiny to 2^15 rows
+        nl = np.concatenate([np.asarray(x["n_list"]) for x in lasts])
+        assert nl.min() == 1 and nl.max() >= 256 and (nl == 1).sum() > 100
     again = pipe.run_many(parts, *args)
     total, sizes = 0, []
     for ds, (lab, med), (lab2, med2), last in zip(parts, outs, again, lasts):
@@ -169,3 +172,11 @@ def test_ten_million_spectra_f16_low_dim_800_invariants():
     """BASELINE configs[4]: 10 M spectra, low_dim 800, float16 vectors (f16 MFMA, float32 accumulation)"""
     from falcon_amd.cluster.cluster import AnnParams
     _run_and_check(10_000_000, AnnParams(dtype="f16", low_dim=800), "device", 2e-5)
+
+
+def test_skewed_two_million_spectra_invariants():
+    """a workload that is NOT uniform: log-normal occupancy of the 1 m/z precursor windows (the fullest
+    ~70x the median: a 65 k-row window and a few of 15-30 k rows -- cut at batch_size, n_list up to 512 -- among 300-row flat ones) and 5..50
+    peaks per spectrum (`synth.generate_device(skew=True)`): the same invariants"""
+    from falcon_amd.cluster.cluster import AnnParams
+    _run_and_check(2_000_000, AnnParams(), "device", 1e-5, skew=True)

@@ -265,6 +265,25 @@ def test_device_generator_matches_the_numpy_recipe_statistically():
     assert int(c2["indptr"][-1]) == c2["mz"].numel() and (c2["precursor_charge"] == 2).all()
 
 
+def test_skewed_generator_numpy_and_device_agree_statistically():
+    """`skew=True`: log-normal occupancy of the 1 m/z precursor windows -- the SAME windows in the numpy and
+    the torch generator (the weights come from the seed alone) -- and 5..50 peaks per template; the default recipe's stream is
+    untouched (the golden vectors and every parity test depend on it)."""
+    import torch
+    from falcon_amd import synth
+    a = synth.generate(150000, seed=9, skew=True)
+    b = synth.generate_device(150000, torch.device("cpu"), seed=9, skew=True)
+    wa = np.bincount(np.floor(a["precursor_mz"]).astype(int) - 400, minlength=800)[:800]
+    wb = np.bincount(np.floor(b["precursor_mz"].numpy()).astype(int) - 400, minlength=800)[:800]
+    assert wa.max() > 40 * np.median(wa) and np.corrcoef(wa, wb)[0, 1] > 0.95
+    pa, pb = np.diff(a["indptr"]), np.diff(b["indptr"].numpy())
+    assert pa.min() <= 5 and pa.max() == 50 and abs(pa.mean() - pb.mean()) < 1.0 and 20 < pa.mean() < 35
+    w = synth.skew_window_weights(9, 400.0, 1200.0)
+    assert len(w) == 800 and abs(w.sum() - 1) < 1e-12 and np.array_equal(w, synth.skew_window_weights(9, 400.0, 1200.0))
+    u = synth.generate(20000, seed=9)                            # the default: uniform windows, ~50 peaks
+    assert np.diff(u["indptr"]).mean() > 45
+
+
 def test_spectrum_dataset_knows_where_its_columns_live():
     """`PartitionRunner.run` uploads host-resident partitions itself (cluster.py: SpectrumDataset.on_host / to_device): numpy
     columns and CPU tensors count as host-resident; the column order is the one `generate_clusters` reads (cluster.py:73-85)"""
