@@ -79,7 +79,8 @@ def deal_job(costs_list, world_size: int, tol: float = 0.03):
       * whole partitions, by longest-processing-time, when that balances within `tol` of the mean load: a rank then runs its
         partitions exactly as one GPU would, with no per-partition work for the others (many similar partitions);
       * otherwise every window of every partition is dealt on its own (`deal_units` over all of them): every rank gets a
-        like mix of windows of every partition.
+        like mix of windows of every partition -- unless that deal is itself off by more than `tol` (heavy-tailed window
+        sizes): then by longest-processing-time (`shard_units`) over all windows.
     Deterministic: every rank derives the same deal from the same counts.  -> [owner int32[n_windows_j] per partition]"""
     sizes = [len(c) for c in costs_list]
     totals = np.array([float(np.sum(c)) for c in costs_list], np.float64)
@@ -89,7 +90,15 @@ def deal_job(costs_list, world_size: int, tol: float = 0.03):
     loads = np.bincount(whole, weights=totals, minlength=world_size)
     if loads.max() <= (1.0 + tol) * loads.mean():
         return [np.full(n, whole[j], np.int32) for j, n in enumerate(sizes)]
-    owner = deal_units(np.concatenate([np.asarray(c, np.float64) for c in costs_list]), world_size)
+    allc = np.concatenate([np.asarray(c, np.float64) for c in costs_list])
+    owner = deal_units(allc, world_size)
+    # a heavy-tailed job (a few windows tens of times the median: real precursor distributions, synth skew=True) leaves the
+    # boustrophedon deal unbalanced -- its first `world_size` units go one to each rank whatever they cost (10 M skewed
+    # spectra, 8 ranks: worst / mean 1.29 modelled, 1.18 measured, profiles/NOTES.md r5): then longest-processing-time over
+    # all units (0.6 ms of heap for 1,600 windows; modelled 1.00)
+    loads = np.bincount(owner, weights=allc, minlength=world_size)
+    if loads.max() > (1.0 + tol) * loads.mean():
+        owner = shard_units(allc, world_size).astype(np.int32)
     out, at = [], 0
     for n in sizes:
         out.append(owner[at:at + n].copy())
@@ -261,6 +270,29 @@ class SparseGraphExchange:
         return out
 
 
+# xGMI on one MI355X node: 7 links x ~153 GB/s per GPU, point to point
+XGMI_LINKS, XGMI_LINK_GBS = 7, 153.0
+
+
+def expected_exchange_bytes(n_total: int, world_size: int, nnz_per_row: float, with_rows: bool = True, imbalance: float = 1.0):
+    """What ONE exchange step of a job of `n_total` spectra dealt to `world_size` GPUs moves, from the layout of
+    `SparseGraphExchange.start` alone -- a number to hold the first real multi-GPU run against.  Every
+    rank sends one int32 block [counts n_max | labels n_max | (rows n_max) | idx nnz_max | dist nnz_max] padded to the largest
+    rank's sizes (`imbalance` = largest share / mean share) and receives `world_size` of them.  `nnz_per_row`: stored
+    neighbours per spectrum after the precursor filter (CSR, not the [n, n_neighbors] ELL: 9.94 on the synthetic 10 M job,
+    measured by tools/shard_share.py).  Times: the payload over all 7 xGMI links at once (direct fan-out) and over one link
+    (what a ring all-gather is bound by) -- lower bounds, no latency terms."""
+    ws = max(1, int(world_size))
+    n_max = int(np.ceil(n_total / ws * imbalance))
+    nnz_max = int(np.ceil(n_max * nnz_per_row))
+    width = 4 * ((3 if with_rows else 2) * n_max + 2 * nnz_max)
+    recv = (ws - 1) * width                                       # from the other ranks
+    return {"world_size": ws, "rows_per_rank": n_max, "nnz_per_rank": nnz_max, "block_bytes_per_rank": width,
+            "received_bytes_per_rank": recv, "gathered_bytes_total": ws * width,
+            "ms_fan_out_7_links": recv / (XGMI_LINKS * XGMI_LINK_GBS * 1e9) * 1e3 if ws > 1 else 0.0,
+            "ms_ring_one_link": recv / (XGMI_LINK_GBS * 1e9) * 1e3 if ws > 1 else 0.0}
+
+
 def _self_check_payload(r: int, n_neighbors: int, scale: int):
     """rank r's synthetic ragged payload (numpy, a function of r alone: every rank can rebuild every other rank's)"""
     rng = np.random.default_rng([2026, r])
@@ -323,8 +355,14 @@ def exchange_self_check(device, n_neighbors: int = 64, scale: int = 20000, round
         d.all_gather_into_tensor(all_seen, seen)
         seen = all_seen
     payload = sum(int(a.nbytes) for a in (np.diff(mine[0]).astype(np.int32), mine[1], mine[2], mine[3], mine[5]))
+    # what the collective itself moved here (padded blocks), and what the real strong-scaling job is expected to move
+    sizes = [(lambda e: (len(e[3]), int(e[0][-1])))(_self_check_payload(r, n_neighbors, scale)) for r in range(ws)]
+    width = 4 * (3 * max(s[0] for s in sizes) + 2 * max(max(s[1] for s in sizes), 1))
     return {"ok": bool(int(ok.item()) == 1), "world_size": ws, "ranks_seen": [int(x) for x in seen.cpu().tolist()],
-            "local_errors": bad[:5], "payload_bytes_this_rank": payload, "ms_per_exchange": [round(x, 3) for x in ms]}
+            "local_errors": bad[:5], "payload_bytes_this_rank": payload, "block_bytes_per_rank": width,
+            "gathered_bytes_total": ws * width, "ms_per_exchange": [round(x, 3) for x in ms],
+            "gbs_per_rank_received": [round((ws - 1) * width / (x * 1e-3) / 1e9, 2) for x in ms] if ws > 1 else None,
+            "expected_strong_10M_job": expected_exchange_bytes(10_000_000, ws, 9.94)}
 
 
 def start_graph_exchange(ctx, exchange: "SparseGraphExchange", outs, lasts, part_off, n_neighbors: int, sharded: bool,

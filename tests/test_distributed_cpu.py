@@ -339,5 +339,41 @@ def test_exchange_self_check_world3_gloo(corrupt):
         assert res[r]["world_size"] == 3 and res[r]["ranks_seen"] == [0, 1, 2]
         assert res[r]["ok"] == (not corrupt)
     assert len({res[r]["payload_bytes_this_rank"] for r in range(3)}) == 3          # ragged: every rank sends a different size
+    # the padded block every rank ships is the largest rank's, and the line carries what the real 10 M job should move
+    assert len({res[r]["block_bytes_per_rank"] for r in range(3)}) == 1
+    assert res[0]["block_bytes_per_rank"] >= max(res[r]["payload_bytes_this_rank"] for r in range(3))
+    e = res[0]["expected_strong_10M_job"]
+    assert e["world_size"] == 3 and e["rows_per_rank"] == 3333334 and e["received_bytes_per_rank"] == 2 * e["block_bytes_per_rank"]
     if corrupt:
         assert res[1]["local_errors"] and not res[0]["local_errors"]
+
+
+def test_deal_of_a_heavy_tailed_job_falls_back_to_longest_processing_time():
+    """windows with log-normal occupancy (synth skew=True at 10 M spectra): the boustrophedon deal hands the eight most
+    expensive windows one to each rank whatever they cost (worst / mean 1.29 by the cost model) -- `deal_job` then deals by
+    longest-processing-time and balances within a per cent; a uniform job keeps the boustrophedon deal"""
+    from falcon_amd import distributed as fd, synth
+    w = synth.skew_window_weights(42, 400.0, 1200.0)
+    counts = [np.round(w * 7e6).astype(np.int64), np.round(w * 3e6).astype(np.int64)]
+    costs = [fd.window_costs(c, 2 ** 15, 16) for c in counts]
+    allc = np.concatenate(costs)
+    b = np.bincount(fd.deal_units(allc, 8), weights=allc, minlength=8)
+    assert b.max() / b.mean() > 1.15
+    owners = fd.deal_job(costs, 8)
+    loads = sum(np.bincount(o, weights=c, minlength=8) for o, c in zip(owners, costs))
+    assert loads.max() / loads.mean() < 1.01
+    assert all(np.array_equal(o, o2) for o, o2 in zip(owners, fd.deal_job(costs, 8)))          # deterministic
+    uni = [fd.window_costs(np.full(800, 8750), 2 ** 15, 16), fd.window_costs(np.full(800, 3750), 2 ** 15, 16)]
+    assert np.array_equal(np.concatenate(fd.deal_job(uni, 8)), fd.deal_units(np.concatenate(uni), 8))
+
+
+def test_expected_exchange_bytes_formula():
+    """`distributed.expected_exchange_bytes`: the padded int32 block of `SparseGraphExchange.start`, priced over xGMI"""
+    from falcon_amd import distributed as fd
+    e = fd.expected_exchange_bytes(10_000_000, 8, 3.2)
+    assert e["rows_per_rank"] == 1_250_000 and e["nnz_per_rank"] == 4_000_000
+    assert e["block_bytes_per_rank"] == 4 * (3 * 1_250_000 + 2 * 4_000_000) == 47_000_000
+    assert e["received_bytes_per_rank"] == 7 * 47_000_000 and e["gathered_bytes_total"] == 8 * 47_000_000
+    assert abs(e["ms_fan_out_7_links"] - 7 * 47e6 / (7 * 153e9) * 1e3) < 1e-9 and abs(e["ms_ring_one_link"] - 7 * e["ms_fan_out_7_links"]) < 1e-9
+    one = fd.expected_exchange_bytes(1_000_000, 1, 3.2)
+    assert one["received_bytes_per_rank"] == 0 and one["ms_ring_one_link"] == 0.0

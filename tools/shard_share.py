@@ -4,7 +4,9 @@ exchange, no concurrency between ranks: a PROJECTION of the compute side of the 
 
 python tools/shard_share.py [world] [weak|strong] [ranks, comma separated]
   weak:   N blocks of the 1 M workload as 2 N charge partitions (bench.py --scaling weak)
-  strong: the fixed 10 M dataset (bench.py --scaling strong)"""
+  strong: the fixed 10 M dataset (bench.py --scaling strong)
+  skew:   the fixed 10 M dataset with synth skew=True (log-normal window occupancy, 5..50 peaks per spectrum)
+Every rank also reports the exchange payload it would contribute (rows, stored neighbours -> bytes of its CSR block)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +20,7 @@ ctx = Context(0)
 pipe = ClusterPipeline(ctx)
 parts = []
 for k in range(world if mode == "weak" else 1):
-    data = synth.generate_device(1_000_000 if mode == "weak" else 10_000_000, ctx.tdev, first_block=k)
+    data = synth.generate_device(1_000_000 if mode == "weak" else 10_000_000, ctx.tdev, first_block=k, skew=(mode == "skew"))
     for ch in (2, 3):
         c = synth.select_charge_device(data, ch)
         parts.append(SpectrumDataset(c["precursor_mz"], c["retention_time"], c["mz"], c["intensity"], c["indptr"]))
@@ -48,11 +50,21 @@ only = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else list(r
 for rank in only:
     ms, outs = timed(lambda: runner.run(parts, *args, shard=(rank, world)))
     rows = sum(int(o[0].numel()) for o in outs)
+    nnz = sum(int(l["nb_count"].sum().item()) for l in runner.lasts if l.get("nb_count") is not None)
     ms_p, _ = timed(lambda: pipe.run_many(parts, *args, shard=(rank, world)))
-    out["ranks"].append({"rank": rank, "rows": rows, "ms_concurrent_partitions": round(ms, 2), "ms_pipelined": round(ms_p, 2)})
-    print(f"rank {rank}: {rows} rows in {ms:.2f} ms (concurrent partitions), {ms_p:.2f} ms (software-pipelined)", flush=True)
+    out["ranks"].append({"rank": rank, "rows": rows, "stored_neighbours": nnz, "csr_block_bytes": 4 * (3 * rows + 2 * nnz),
+                         "ms_concurrent_partitions": round(ms, 2), "ms_pipelined": round(ms_p, 2)})
+    print(f"rank {rank}: {rows} rows, {nnz} stored neighbours in {ms:.2f} ms (concurrent partitions), {ms_p:.2f} ms (software-pipelined)", flush=True)
 worst = max(r["ms_concurrent_partitions"] for r in out["ranks"])
 out["slowest_rank_ms"] = worst
+out["mean_rank_ms"] = sum(r["ms_concurrent_partitions"] for r in out["ranks"]) / len(out["ranks"])
+out["worst_over_mean"] = worst / out["mean_rank_ms"]
+from falcon_amd import distributed as fdist
+rows_all, nnz_all = sum(r["rows"] for r in out["ranks"]), sum(r["stored_neighbours"] for r in out["ranks"])
+if len(only) == world and rows_all:
+    out["nnz_per_row"] = nnz_all / rows_all
+    out["exchange_expected"] = fdist.expected_exchange_bytes(rows_all, world, nnz_all / rows_all,
+                                                             imbalance=max(r["rows"] for r in out["ranks"]) * world / rows_all)
 out["projected_spectra_per_s"] = n_total / (worst * 1e-3)
 out["note"] = ("one GPU running every rank's share in turn: the compute side of the sharded job, every phase of the rank included "
                "(window histograms of all partitions, the deal, its own sort, the path); the all-gatherv of the neighbour lists "
