@@ -130,9 +130,9 @@ def cpu_baseline(hosts, params, budget_s=75.0):
 def pmc_traffic(workload):
     """HBM bytes per launch of a workload's dominant cosine kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so
-    the figure is only reported for the workloads it was measured on (profiles/r4_pmc_traffic.json -- r3 as the fallback --, written by
+    the figure is only reported for the workloads it was measured on (profiles/r5_pmc_traffic.json -- r4 / r3 as the fallback --, written by
     tools/pmc_traffic.sh on the GPU box).  -> (bytes per launch or None, source file or None)"""
-    for fn in ("r4_pmc_traffic.json", "r3_pmc_traffic.json"):
+    for fn in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if os.path.isfile(path):
             try:
