@@ -26,6 +26,7 @@ namespace fal {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr float kA16EpsRel = 1.3e-3f, kA16EpsAbs = 2e-6f;
+constexpr uint32_t kAmbMerged = 0x80000000u;          // amb_list entry [4]: a row of a merged (> 128-list) bucket, see assign_exact_rows_kernel
 
 __global__ void cvt_f16_kernel(const float* __restrict__ in, __half* __restrict__ out, int64_t n4) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -299,7 +300,43 @@ __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, c
                 bid = c;
             }
         };
-        if (fg == 0u) {
+        if (fg == kAmbMerged) {
+            // a row of a bucket with more than 128 lists that the merge could not decide (round 5; before: every centroid of the
+            // bucket, 1,024 chains per row): the row's subgroup summaries are still in the partial arrays -- thr from the best
+            // of them (the merge kernel's own formula), then only the subgroups whose RUNNER-UP reaches thr are evaluated in
+            // full (their other members are unknown), the others contribute their best if it reaches thr.  Any centroid left
+            // out has an approximate value below thr and cannot be the exact arg-max.
+            const int nsg = (job.ncent + 31) >> 5;
+            float pb = -INFINITY, ps = -INFINITY;
+            int pid = 0;
+            if (lane < nsg) {
+                const int64_t at = (int64_t)lane * a.n + row;
+                pb = a.part_b[at];
+                ps = a.part_s[at];
+                pid = a.part_id[at];
+            }
+            float top = pb;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) top = fmaxf(top, __shfl_xor(top, off, 64));
+            const float thr = top - 2.2f * (kA16EpsRel * top + kA16EpsAbs);
+            unsigned long long fm = __ballot(lane < nsg && ps >= thr);
+            const unsigned long long sm = __ballot(lane < nsg && pb >= thr && !(ps >= thr));
+            while (fm) {                                                 // two full subgroups per round: lanes 0-31 / 32-63
+                const int g0 = __ffsll((long long)fm) - 1;
+                fm &= fm - 1;
+                const int g1 = fm ? __ffsll((long long)fm) - 1 : -1;
+                fm &= fm ? fm - 1 : 0ull;
+                const int g = lane < 32 ? g0 : g1;
+                const int c = g >= 0 ? 32 * g + (lane & 31) : -1;
+                eval(c, c >= 0 && c < job.ncent);
+            }
+            const int n_single = __popcll(sm);                           // (<= 64: one lane each)
+            if (n_single > 0) {
+                const int src = __fns64(sm, 0, lane + 1);               // the lane of the (lane + 1)-th single subgroup, or -1
+                const int c = __shfl(pid, src < 0 ? 0 : src, 64) - job.id_base;
+                eval(c, src >= 0 && c >= 0 && c < job.ncent);
+            }
+        } else if (fg == 0u) {
             for (int c0 = 0; c0 < job.ncent; c0 += 64) eval(c0 + lane, c0 + lane < job.ncent);
         } else {
             const int nfull = 32 * __popc(fg);
@@ -427,7 +464,7 @@ __global__ __launch_bounds__(256) void assign16_merge_kernel(Assign16Args a, int
             if (at < a.amb_cap) {
                 a.amb_list[5 * at] = (int32_t)row;
                 a.amb_list[5 * at + 1] = (int32_t)(job_index0 + ji);
-                a.amb_list[5 * at + 4] = 0;
+                a.amb_list[5 * at + 4] = (int32_t)kAmbMerged;         // (assign_exact_rows_kernel: consult the partial arrays)
             }
         }
     }
