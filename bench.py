@@ -29,9 +29,11 @@ Inputs are resident in HBM before the timed region (`value`); `value_host_to_hos
 with the peak arrays starting in pinned host memory: the upload of step i + 1 travels on a copy stream under
 the kernels of step i (`ms_per_step_host_to_host_latency` = one step alone, upload then compute).  Rank 0 prints ONE JSON
 line; at N = 1 it also carries `configs`: the 10 M-spectra float32 run (BASELINE configs[2]'s dataset on one GPU = the
-north star's target size), the 10 M / low_dim 800 / float16 run (configs[4]), the configs[3] bucket regime at 10 M and
-configs[3] itself (50 M spectra, n_probe 32, in 4 bucket shares), each with its own `roofline`, and `cpu_baseline` (the
-oracle on all host cores).
+north star's target size; repeated as the top-level `north_star` object), the 10 M / low_dim 800 / float16 run
+(configs[4]), the configs[3] bucket regime at 10 M, SURVEY 8d's C4 row as written (batch_size 65536: n_list 1,024), a
+skewed 2 M workload (log-normal window occupancy, 5..50 peaks per spectrum) and configs[3] itself (50 M spectra, n_probe
+32, in 4 bucket shares; its roofline from a staged pass over one share), each with its own `roofline`, and
+`cpu_baseline` (the oracle on all host cores).
 """
 import argparse
 import json

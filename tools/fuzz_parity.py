@@ -17,24 +17,33 @@ pipe = ClusterPipeline(ctx)
 bad = 0
 for case in range(n_cases):
     n = int(rng.choice([3000, 9000, 20000]))
-    d = synth.select_charge(synth.generate(n, seed=int(rng.integers(1, 10 ** 6))), int(rng.choice([2, 3])))
+    skew = bool(rng.random() < 0.25)                          # log-normal window occupancy, 5..50 peaks per spectrum
+    big = bool(rng.random() < 0.06)                           # one window of ~45 k rows kept whole: n_list 1,024 (batch_size 2^16)
+    if big:
+        n, skew = 65000, False
+    d = synth.select_charge(synth.generate(n, seed=int(rng.integers(1, 10 ** 6)), skew=skew), 2 if big else int(rng.choice([2, 3])))
+    batch_size = 2 ** 16 if big else 2 ** 15
     opts = dict(eps=float(rng.choice([0.05, 0.1, 0.3])), low_dim=int(rng.choice([64, 128, 256, 400])),
                 n_probe=int(rng.choice([2, 5, 16, 32])), n_neighbors=int(rng.choice([8, 64])),
                 n_neighbors_ann=int(rng.choice([16, 128, 200])), mz_interval=float(rng.choice([0.0, 1.0])),
                 kmeans_iters=int(rng.choice([2, 10])))
     tol = (20.0, "ppm") if rng.random() < 0.6 else (0.02, "Da")
     rt_tol = None if rng.random() < 0.6 else float(rng.choice([5.0, 30.0]))
-    if rng.random() < 0.3:                                   # squeeze the precursors: large (IVF) buckets
+    if big:
+        pm = d["precursor_mz"]
+        d["precursor_mz"] = (600.02 + (pm - pm.min()) / np.ptp(pm) * 0.96).astype(np.float32)
+        opts.update(low_dim=int(rng.choice([128, 400])), n_probe=32, kmeans_iters=int(rng.choice([2, 10])), mz_interval=1.0)
+    elif rng.random() < 0.3:                                 # squeeze the precursors: large (IVF) buckets
         pm = d["precursor_mz"]
         d["precursor_mz"] = (600.0 + (pm - pm.min()) / np.ptp(pm) * float(rng.choice([2.0, 20.0]))).astype(np.float32)
     ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
     t = time.time()
     ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"],
-                                     precursor_tol=tol, rt_tol=rt_tol, **opts)
+                                     precursor_tol=tol, rt_tol=rt_tol, batch_size=batch_size, n_jobs=8, **opts)
     t_or = time.time() - t
     scan = str(rng.choice(["f32", "f32", "f16x3"])) if opts["low_dim"] in (64, 128, 256, 400) else "f32"
     p = AnnParams(scan=scan, **opts)
-    lab, med = pipe.run(ds, tol[0], tol[1], rt_tol, 0.05, 2 ** 15, p)
+    lab, med = pipe.run(ds, tol[0], tol[1], rt_tol, 0.05, batch_size, p)
     lab, med = lab.cpu().numpy(), med.cpu().numpy()
     same_lab, same_med = np.array_equal(lab, ref), np.array_equal(med, rmed)
     # medoids: the oracle's similarities come from BLAS (last-bit differences, not exactly symmetric), so exact score
@@ -44,11 +53,11 @@ for case in range(n_cases):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ari = adjusted_rand_score(ref, lab)
-    many = pipe.run_many([ds], tol[0], tol[1], rt_tol, 0.05, 2 ** 15, p)[0]
+    many = pipe.run_many([ds], tol[0], tol[1], rt_tol, 0.05, batch_size, p)[0]
     same_many = np.array_equal(many[0].cpu().numpy(), lab)
     flag = "OK " if (same or ari >= 0.99) and same_many and med_ok else "BAD"
     bad += flag == "BAD"
-    print(f"{flag} case {case}: n={len(ds)} scan={scan} {opts} tol={tol} rt={rt_tol} labels_identical={same_lab} medoids_identical={same_med} (differing: {int((med != rmed).sum()) if len(med) == len(rmed) else -1}) ari={ari:.5f} clusters={len(med)} "
+    print(f"{flag} case {case}: n={len(ds)} skew={skew} batch={batch_size} n_list_max={int(np.max(pipe.last['n_list']))} scan={scan} {opts} tol={tol} rt={rt_tol} labels_identical={same_lab} medoids_identical={same_med} (differing: {int((med != rmed).sum()) if len(med) == len(rmed) else -1}) ari={ari:.5f} clusters={len(med)} "
           f"run_many_same={same_many} oracle {t_or:.1f}s", flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)
