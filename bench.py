@@ -694,9 +694,9 @@ def main():
             # `issued` = machine flops actually run through the matrix pipe, tile padding included
             roof.update({"issued_tflops": s["issued_tflops"], "issued_frac": s["issued_tflops"] / PEAK_MFMA_F32_TFLOPS})
         roof["profile"] = ("avg_launch_ms comes from a serial per-stage pass (HIP events); it agrees with the kernel's average in "
-                           "profiles/r4_bench_1M_pipelined_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py "
+                           "profiles/r5_bench_1M_pipelined_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py "
                            "--partitions pipelined --no-configs --no-cpu-baseline`: one stream); in the default two-stream run "
-                           "(profiles/r4_bench_1M_kernel_stats.csv) the two partitions' kernels overlap and stretch each other")
+                           "(profiles/r5_bench_1M_kernel_stats.csv) the two partitions' kernels overlap and stretch each other")
         out = {
             "metric": "spectra clustered/sec @1/2/4/8 GPU; cosine-kernel HBM GB/s vs roofline",
             "value": n_total * args.steps / dt,

@@ -213,6 +213,25 @@ def test_float16_assignment_and_keyed_quantiser_with_1024_and_2048_lists(ctx):
     assert torch.equal(n0[0], n1[0]) and torch.equal(n0[1].view(torch.int32), n1[1].view(torch.int32))
 
 
+def test_float16_assignment_with_list_counts_that_are_not_powers_of_two(ctx):
+    """the C ABI takes any list count per bucket: 600 lists (eight-wave group jobs of 256 + 256 + 88 centroids, keys of 640
+    columns) and 1,500 (5 x 256 + 220; 32 keys per lane in the quantiser, the last 548 of them padding), low_dim 64 and 400 --
+    keyed build and search == the exact build's, bit for bit"""
+    import torch
+    for d, iters in ((64, 3), (400, 2)):
+        sizes = [14000, 31000]
+        nl = np.array([600, 1500], np.int32)
+        off, X, mz, rt = _buckets(sizes, d, 71)
+        Xd = torch.from_numpy(X).to(ctx.tdev)
+        plain = ctx.ivf_build(Xd, off, nl, kmeans_iters=iters)
+        keyed = ctx.ivf_build(Xd, off, nl, kmeans_iters=iters, Xkm=Xd.to(torch.float16).contiguous())
+        for a, b in zip(plain.export(), keyed.export()):
+            assert torch.equal(a, b)
+        s0, i0 = plain.search(32, 64)
+        s1, i1 = keyed.search(32, 64)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
 @pytest.mark.parametrize("d,n_probe", [(400, 16), (400, 3), (128, 8), (64, 1)])
 def test_coarse_quantiser_from_the_build_keys_gives_the_same_search(ctx, d, n_probe):
     """an index built with the float16 k-means prefilter keeps the final pass's (row, centroid) similarities as 16-bit keys and
