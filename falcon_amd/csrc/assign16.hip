@@ -67,24 +67,19 @@ struct Assign16Args {
 
 __device__ __forceinline__ int a16_rowoff(int i) { return (i & 3) + 8 * (i >> 2); }
 
-// NW = 8 (round 5, PARTIAL jobs of buckets with more than 128 lists, low_dim <= 400): eight waves -- 256 resident centroids --
-// share one row stream, so a 32-row chunk is staged (global -> registers -> LDS, one barrier) once per 256 centroids instead of
-// once per 128; one 512-thread workgroup per CU = the same two waves per SIMD as two 4-wave workgroups.
-template <int STEPS, bool KEYS, bool PARTIAL, int NW = 4>
-__global__ __launch_bounds__(64 * NW, (STEPS > 32 || NW == 8) ? 1 : 2) void assign16_kernel(Assign16Args a) {
+template <int STEPS, bool KEYS, bool PARTIAL>
+__global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void assign16_kernel(Assign16Args a) {
     constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int RB16 = D / 8;
     constexpr int RS = D * 2 + 16;
     constexpr int PIECES = 32 * RB16;
-    constexpr int kThreads = 64 * NW;
-    constexpr int kStage = (PIECES + kThreads - 1) / kThreads;
+    constexpr int kStage = (PIECES + 255) / 256;
     constexpr int NB = STEPS < 4 ? STEPS : 4;
     static_assert(kStage <= 13, "staging registers");      // (low_dim 800: 13 x 16 bytes per thread and chunk, one workgroup per CU)
-    static_assert(NW == 4 || (NW == 8 && PARTIAL && STEPS <= 25), "eight waves: merged buckets at low_dim <= 400 only");
     __shared__ __align__(16) unsigned char stage[2 * 32 * RS];
-    __shared__ float r_best[2][NW][32];      // per chunk parity, wave, row: best / runner-up value and best id
-    __shared__ float r_second[2][NW][32];
-    __shared__ int r_id[2][NW][32];
+    __shared__ float r_best[2][4][32];       // per chunk parity, wave, row: best / runner-up value and best id
+    __shared__ float r_second[2][4][32];
+    __shared__ int r_id[2][4][32];
     const int64_t per_xcd = (a.n_jobs + 7) / 8;
     const int64_t ji = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= per_xcd || ji >= a.n_jobs) return;
@@ -105,13 +100,13 @@ __global__ __launch_bounds__(64 * NW, (STEPS > 32 || NW == 8) ? 1 : 2) void assi
     M(10, sa10) M(11, sa11) M(12, sa12)
 #define FAL_LOAD_ONE(I, R)                                                                             \
     if constexpr (I < kStage) {                                                                        \
-        const int idx = min((int)threadIdx.x + kThreads * I, PIECES - 1);                              \
+        const int idx = min((int)threadIdx.x + 256 * I, PIECES - 1);                                   \
         const int row = idx / RB16, col = idx - row * RB16;                                            \
         R = reinterpret_cast<const uint4*>(rbase + (int64_t)min(stage_c0 + row, nr - 1) * D)[col];     \
     }
 #define FAL_STORE_ONE(I, R)                                                                            \
     if constexpr (I < kStage) {                                                                        \
-        const int idx = min((int)threadIdx.x + kThreads * I, PIECES - 1);                              \
+        const int idx = min((int)threadIdx.x + 256 * I, PIECES - 1);                                   \
         const int row = idx / RB16, col = idx - row * RB16;                                            \
         *reinterpret_cast<uint4*>(stage + (size_t)stage_buf * 32 * RS + row * RS + col * 16) = R;      \
     }
@@ -120,12 +115,12 @@ __global__ __launch_bounds__(64 * NW, (STEPS > 32 || NW == 8) ? 1 : 2) void assi
     // decision for the 32 rows of a finished chunk: lanes 0..31 of the duty wave combine the four waves' results
     auto decide = [&](int par, int c0) {
         if (lane >= 32 || c0 + lane >= nr) return;
-        if constexpr (PARTIAL) {                                     // this group's NW subgroup summaries of the row
+        if constexpr (PARTIAL) {                                     // this group's four subgroup summaries of the row
             const int64_t row = job.row0 + c0 + lane;
-            const int sg0 = job.id_base >> 5;                        // (groups start at multiples of 32 NW lists)
+            const int g = job.id_base >> 7;
 #pragma unroll
-            for (int ww = 0; ww < NW; ++ww) {
-                const int64_t at = (int64_t)(sg0 + ww) * a.n + row;
+            for (int ww = 0; ww < 4; ++ww) {
+                const int64_t at = (int64_t)(4 * g + ww) * a.n + row;
                 a.part_b[at] = r_best[par][ww][lane];
                 a.part_s[at] = r_second[par][ww][lane];
                 a.part_id[at] = job.id_base + r_id[par][ww][lane];
@@ -135,7 +130,7 @@ __global__ __launch_bounds__(64 * NW, (STEPS > 32 || NW == 8) ? 1 : 2) void assi
         float best = -INFINITY, second = -INFINITY;
         int bid = 0x7fffffff;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {                             // (the undivided form has four waves: static_assert above)
+        for (int ww = 0; ww < 4; ++ww) {
             const float b = r_best[par][ww][lane], s2 = r_second[par][ww][lane];
             const int id = r_id[par][ww][lane];
             if (b > best || (b == best && id < bid)) {
@@ -262,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, (STEPS > 32 || NW == 8) ? 1 : 2) void assi
         FAL_STORE(buf ^ 1)                       // chunk c0 + 32
         FAL_LOAD(c0 + 64)
         __syncthreads();
-        if (w == ((c0 >> 5) & (NW - 1))) decide(par, c0);            // (the duty rotates over the waves)
+        if (w == ((c0 >> 5) & 3)) decide(par, c0);                   // (the duty rotates over the waves)
         buf ^= 1;
     }
 #undef FAL_LOAD
@@ -492,8 +487,7 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
 // to each other]
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
-                    uint16_t* ckeys, int ckeys_stride, const uint16_t* sp_cols, const float* sp_vals, int merge_max_lists,
-                    int merge_group) {
+                    uint16_t* ckeys, int ckeys_stride, const uint16_t* sp_cols, const float* sp_vals, int merge_max_lists) {
     if (n_single + n_merge <= 0) return FAL_OK;
     // work lists of the exact kernels: a row enters at most one of them once per pass, so n_rows entries never overflow
     int32_t* amb = nullptr;
@@ -507,15 +501,8 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     a.sp_cols = sp_cols; a.sp_vals = sp_vals;
     StageScope ts(ctx, stage);
     const dim3 block(256);
-    const bool wide = merge_group == 2 * kAssignGroup;       // merged buckets in groups of 256 lists: the eight-wave form
-    FAL_REQUIRE(merge_group == kAssignGroup || (wide && d <= 400), FAL_EINTERNAL, "assign16: merge groups of %d lists at low_dim %d",
-                merge_group, d);
 #define FAL_LAUNCH_A16(S)                                                                                  \
     do {                                                                                                   \
-        if constexpr (S <= 25) {                                                                           \
-            if (partial && wide && ckeys) { hipLaunchKernelGGL((assign16_kernel<S, true, true, 8>), grid, dim3(512), 0, ctx->stream, a); break; } \
-            if (partial && wide) { hipLaunchKernelGGL((assign16_kernel<S, false, true, 8>), grid, dim3(512), 0, ctx->stream, a); break; } \
-        }                                                                                                  \
         if (partial && ckeys) hipLaunchKernelGGL((assign16_kernel<S, true, true>), grid, block, 0, ctx->stream, a); \
         else if (partial) hipLaunchKernelGGL((assign16_kernel<S, false, true>), grid, block, 0, ctx->stream, a); \
         else if (ckeys) hipLaunchKernelGGL((assign16_kernel<S, true, false>), grid, block, 0, ctx->stream, a); \
@@ -536,7 +523,7 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     if (n_single > 0) FAL_TRY(run(false));
     if (n_merge > 0) {
         float* part = nullptr;
-        const size_t n_sub = (size_t)(merge_group / 32) * (size_t)std::max(1, (merge_max_lists + merge_group - 1) / merge_group);   // whole groups
+        const size_t n_sub = 4 * (size_t)std::max(1, (merge_max_lists + kAssignGroup - 1) / kAssignGroup);      // four per group job, whole groups
         FAL_REQUIRE(merge_max_lists <= kAssignMergeLists, FAL_EINTERNAL, "assign16: a merge job with %d lists", merge_max_lists);
         FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * 3 * n_sub * (size_t)n_rows, (void**)&part));
         a.part_b = part; a.part_s = part + n_sub * (size_t)n_rows; a.part_id = reinterpret_cast<int32_t*>(part + 2 * n_sub * (size_t)n_rows);

@@ -656,9 +656,6 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         const bool use16 = X16 != nullptr && assign16_supports(low_dim) && ivf->rows_signed == 0;
         std::vector<AssignJob> hjobs, mjobs, gjobs;    // single-group jobs; merge jobs and their group jobs (129..kAssignMergeLists lists)
         int merge_max_lists = 0;
-        // group jobs of merged buckets: 256 centroids on eight waves up to low_dim 400 (a chunk of rows is staged once per 256
-        // centroids), 128 on four at low_dim 800 (the resident tile is 200 registers per wave there)
-        const int merge_group = low_dim <= 400 ? 2 * kAssignGroup : kAssignGroup;
         for (const BucketDev& b : bk) {
             if (use16 && b.n_list <= kAssignGroup) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg)
@@ -668,8 +665,8 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg) {
                     const int32_t nr = (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0);
                     mjobs.push_back({b.row0 + s0, b.list0, nr, b.n_list, 0, 0});
-                    for (int t0 = 0; t0 < b.n_list; t0 += merge_group)       // the groups of a segment next to each other: they
-                        gjobs.push_back({b.row0 + s0, b.list0 + t0, nr, std::min(merge_group, b.n_list - t0), t0, 0});    // share its rows in L2
+                    for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)      // the groups of a segment next to each other: they
+                        gjobs.push_back({b.row0 + s0, b.list0 + t0, nr, std::min(kAssignGroup, b.n_list - t0), t0, 0});   // share its rows in L2
                 }
             } else if (b.n_list <= 64) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += wseg)
@@ -749,7 +746,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 }
                 B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, n_single, n_merge, n_group, n,
                                       ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr, ivf->ckeys_stride, sp_cols, sp_vals,
-                                      merge_max_lists, merge_group));
+                                      merge_max_lists));
             }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,

@@ -65,7 +65,7 @@ struct AssignJob {
     int64_t row0;        // first row of the segment (sorted rows = rows of X)
     int64_t cent0;       // global row of the group's first centroid
     int32_t nrows;       // rows in the segment (<= kAssignSeg)
-    int32_t ncent;       // centroids in the group (1..kAssignGroup; the group jobs of merged buckets at low_dim <= 400: 1..2 kAssignGroup)
+    int32_t ncent;       // centroids in the group (1..kAssignGroup)
     int32_t id_base;     // bucket-local list id of the group's first centroid
     int32_t pad;
 };
@@ -80,7 +80,7 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count);
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
                     uint16_t* ckeys = nullptr, int ckeys_stride = 0, const uint16_t* sp_cols = nullptr,
-                    const float* sp_vals = nullptr, int merge_max_lists = 4 * kAssignGroup, int merge_group = kAssignGroup);
+                    const float* sp_vals = nullptr, int merge_max_lists = 4 * kAssignGroup);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order

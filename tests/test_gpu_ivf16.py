@@ -214,8 +214,8 @@ def test_float16_assignment_and_keyed_quantiser_with_1024_and_2048_lists(ctx):
 
 
 def test_float16_assignment_with_list_counts_that_are_not_powers_of_two(ctx):
-    """the C ABI takes any list count per bucket: 600 lists (eight-wave group jobs of 256 + 256 + 88 centroids, keys of 640
-    columns) and 1,500 (5 x 256 + 220; 32 keys per lane in the quantiser, the last 548 of them padding), low_dim 64 and 400 --
+    """the C ABI takes any list count per bucket: 600 lists (group jobs of 4 x 128 + 88 centroids, keys of 640 columns) and
+    1,500 (11 x 128 + 92; 32 keys per lane in the quantiser, the last 548 of them padding), low_dim 64 and 400 --
     keyed build and search == the exact build's, bit for bit"""
     import torch
     for d, iters in ((64, 3), (400, 2)):
