@@ -49,6 +49,8 @@ bool dense4_supports(int d);
 int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, const DenseJob* jobs_host, int n_jobs, float* sims,
                   int64_t sims_base);
 int launch_dense_tiny4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base);
+// flat buckets of fewer than 64 rows at low_dim > 512: exact fmaf chains on the vector ALU (scan.hip)
+int launch_flat_exact_small(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base);
 // xcd_list_tiles > 0 selects XCD-list mode (simtile.h): `jobs` = the launch's jobs sorted by
 // decreasing size with xtile0 filled in, xcd_list_tiles = tiles of the longest of the 8 lists.
 int launch_dense(fal_ctx* ctx, int stage, int epi, const float* Q, const float* Cm, int d, const DenseJob* jobs,

@@ -5,6 +5,7 @@
 // snapshot).  See simtile.h for the tile algorithm, DESIGN.md for the roofline.
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "simtile.h"
 #include "scan.h"
@@ -487,6 +488,33 @@ int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, con
         return FAL_EUNSUPPORTED;
     }
 #undef FAL_LAUNCH_DENSE4
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
+}
+
+// Flat buckets of fewer than 64 rows beyond the fp32 matrix kernels' low_dim (512): the exact k-ordered fmaf chain on the vector
+// ALU, one wave per bucket, a lane per candidate -- the oracle's bits (simtile.h: exact_dot) where the f16 matrix cores are
+// within 2e-6 only.  Round 5: the two-or-three-row buckets at the ends of a float16 / low_dim 800 job's precursor range
+// (BASELINE configs[4]) were the one place where the neighbour distances were not bit-identical.  Same block layout as the
+// other flat kernels: one [32, ceil32(nc)] block per 32-query tile.
+__global__ __launch_bounds__(64) void flat_exact_small_kernel(const float* __restrict__ X, int d, const DenseJob* __restrict__ jobs,
+                                                              int n_jobs, float* __restrict__ sims, int64_t sims_base) {
+    const int lane = threadIdx.x;
+    for (int j = blockIdx.x; j < n_jobs; j += gridDim.x) {
+        const DenseJob job = jobs[j];
+        const int nc = job.nc, W = (nc + 31) & ~31;
+        float* const out = sims + (job.obase - sims_base);
+        for (int i = 0; i < job.nq; ++i)
+            for (int c = lane; c < nc; c += 64)
+                out[(int64_t)(i >> 5) * 32 * W + (i & 31) * W + c] = exact_dot(X + (job.q_row0 + i) * (int64_t)d, X + (job.c_row0 + c) * (int64_t)d, d);
+    }
+}
+
+int launch_flat_exact_small(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base) {
+    if (n_jobs <= 0) return FAL_OK;
+    StageScope ts(ctx, ST_SCAN);
+    hipLaunchKernelGGL(flat_exact_small_kernel, dim3((unsigned)std::min<int64_t>(n_jobs, (int64_t)ctx->num_cus * 16)), dim3(64), 0,
+                       ctx->stream, X, d, jobs, n_jobs, sims, sims_base);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;
 }

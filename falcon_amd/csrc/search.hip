@@ -341,7 +341,8 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     size_t need_flat = 0;
     const bool have16 = ivf->X16 != nullptr;
     const bool have4 = ivf->X && dense4_supports(d);       // the shared-stream fp32 kernels (scan.hip)
-    const int64_t thr16 = (ivf->X && d <= 512) ? 64 : 0;   // without float32 rows (or beyond the fp32 kernel's low_dim) everything takes the f16 kernel
+    const int64_t thr16 = ivf->X ? 64 : 0;                 // without float32 rows everything takes the f16 kernel; buckets below it: the fp32
+                                                           // matrix kernels up to low_dim 512, exact chains on the vector ALU beyond
     FAL_REQUIRE(have16 || ivf->X || border.empty(), FAL_EINVAL, "fal_ivf_search_topk: the index has no vectors to scan");
     {
         FlatBatch cur{0, 0, 0, 0, 0, 0, 0, 0};
@@ -457,7 +458,9 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         // (flat buckets keep their rows' positions in list order: the sorted rows serve)
         if (fb.jk > fb.jm)
             FAL_TRY(launch_dense4(ctx, ivf->X, d, flat_dev + fb.jm, flat.data() + fb.jm, (int)(fb.jk - fb.jm), buf, 0));
-        if (fb.j1 > fb.jk && have4)
+        if (fb.j1 > fb.jk && d > 512)
+            FAL_TRY(launch_flat_exact_small(ctx, ivf->X, d, flat_dev + fb.jk, (int)(fb.j1 - fb.jk), buf, 0));
+        else if (fb.j1 > fb.jk && have4)
             FAL_TRY(launch_dense_tiny4(ctx, ivf->X, d, flat_dev + fb.jk, (int)(fb.j1 - fb.jk), buf, 0));
         else if (fb.j1 > fb.jk)
             FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->X, ivf->X, d, flat_dev + fb.jk, (int)(fb.j1 - fb.jk), 0,

@@ -140,10 +140,9 @@ def test_config5_float16_vectors_low_dim_800_through_the_index(ctx):
     """BASELINE configs[4] (low_dim 800, float16 vectors) in the bucket regime of the 10 M run: windows of ~9 k spectra get
     their k-means index (n_list 128, n_probe 16) instead of the exhaustive scan of rounds 1-2 (VERDICT r2 missing #1).  The
     similarity of float16 vectors is the float32 chain over their images, the float16 rows are the prefilter copies: labels,
-    medoids and neighbour ids equal the oracle's run (`dtype=float16`: round, then the float32 path with the same index rule);
-    the distances are bit-identical for every row of an indexed bucket and within 2e-6 in the two-or-three-row flat buckets at
-    the ends of the precursor range (low_dim 800 is beyond the exact fp32 flat kernel: those are scanned on the f16 matrix
-    cores, float32 accumulation in the pipe's own order)."""
+    medoids, neighbour ids AND distances equal the oracle's run bit for bit (`dtype=float16`: round, then the float32 path with
+    the same index rule) -- the indexed buckets through the exact chains of the kept pairs, the two-or-three-row flat buckets at
+    the ends of the precursor range through flat_exact_small_kernel (low_dim 800 is beyond the fp32 matrix kernels)."""
     from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
     d, ds = _dense_dataset(39000, 600.0, 603.0, seed=73)
     p = AnnParams(dtype="f16", low_dim=800)
@@ -158,8 +157,10 @@ def test_config5_float16_vectors_low_dim_800_through_the_index(ctx):
     indexed = np.repeat(n_list > 1, np.diff(splits))
     assert indexed.sum() > 0.99 * len(ds)
     assert np.array_equal(gd[indexed], im["nb_dist"][indexed])
-    fin = np.isfinite(im["nb_dist"])
-    assert np.array_equal(np.isfinite(gd), fin) and np.abs(gd[fin] - im["nb_dist"][fin]).max() <= 2e-6
+    # (round 5) the flat buckets at the ends of the range hold fewer than 64 rows: exact chains on the vector ALU
+    # (flat_exact_small_kernel) -- the distances are the oracle's bits EVERYWHERE (round 4: within 2e-6 there)
+    assert np.diff(splits)[n_list == 1].max() < 64
+    assert np.array_equal(gd.view(np.uint32), im["nb_dist"].view(np.uint32))
     assert np.array_equal(labels.cpu().numpy(), ref) and np.array_equal(medoids.cpu().numpy(), rmed)
     assert ctx.counter(6) == 0
     pairs = ctx.counter(0)

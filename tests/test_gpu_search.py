@@ -47,6 +47,30 @@ def test_flat_exhaustive_topk(ctx, d, k):
     assert np.array_equal(idx[a, :5], np.arange(a, a + 5))
 
 
+def test_small_flat_buckets_beyond_low_dim_512_are_exact(ctx):
+    """float16 vectors at low_dim 800 (BASELINE configs[4]): flat buckets of fewer than 64 rows are scanned by exact fmaf chains on
+    the vector ALU (flat_exact_small_kernel) -- similarities bit-identical to the oracle's chain over the float32 images of the
+    float16 rows, tie order included; larger flat buckets stay on the f16 matrix cores (within 2e-6)."""
+    import torch
+    sizes = [3, 40, 63, 1, 33, 200, 17]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    X = unit_vectors(off[-1], 800, 29).astype(np.float16)
+    X[off[1] + 2:off[1] + 6] = X[off[1] + 2]                  # exact ties
+    Ximg = X.astype(np.float32)                               # the float32 image of the float16 rows (fal_vectorize_f16_image)
+    idxr = ctx.ivf_build(torch.from_numpy(Ximg).to(ctx.tdev), off, np.ones(len(sizes), np.int32),
+                         X16=torch.from_numpy(X).to(ctx.tdev))
+    k = 32
+    sim, idx = idxr.search(16, k)
+    sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
+    for b, (a, e) in enumerate(zip(off[:-1], off[1:])):
+        rs, ri = fo.exhaustive_topk(Ximg[a:e], k, base=a)
+        if e - a < 64:
+            assert_topk_exact(sim[a:e], idx[a:e], rs, ri, what=f"bucket {b} ({e - a} rows)")
+        else:                                                 # the f16-MFMA scan: float32 accumulation in the pipe's own order
+            fin = np.isfinite(rs)
+            assert np.array_equal(np.isfinite(sim[a:e]), fin) and np.abs(sim[a:e][fin] - rs[fin]).max() <= 2e-6
+
+
 def test_flat_many_small_batches(ctx, monkeypatch):
     """forces several scan/select batches through a tiny sims buffer."""
     import torch
