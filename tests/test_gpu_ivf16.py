@@ -232,6 +232,30 @@ def test_float16_assignment_with_list_counts_that_are_not_powers_of_two(ctx):
         assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
 
 
+def test_a_bucket_beyond_2048_lists_next_to_prefiltered_ones(ctx):
+    """more than 2,048 lists in one bucket (a window of > 80 k spectra kept whole by `--batch_size` >= 2^17): that bucket takes
+    the exact fp32 assignment while its neighbours keep the float16 one, no keys are left for the quantiser (the staged coarse
+    scan serves every bucket) -- index and search still equal the all-exact build's"""
+    import torch
+    sizes = [90000, 9000, 2500]
+    nl = np.array([4096, 128, 32], np.int32)
+    off, X, mz, rt = _buckets(sizes, 64, 73)
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    plain = ctx.ivf_build(Xd, off, nl, kmeans_iters=2)
+    keyed = ctx.ivf_build(Xd, off, nl, kmeans_iters=2, Xkm=Xd.to(torch.float16).contiguous())
+    for a, b in zip(plain.export(), keyed.export()):
+        assert torch.equal(a, b)
+    s0, i0 = plain.search(16, 32)
+    s1, i1 = keyed.search(16, 32)
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    mz_d = torch.from_numpy(mz).to(ctx.tdev)
+    n0 = plain.search_neighbors(16, 32, mz_d, None, 20.0, "ppm", None, 16)
+    pre = ctx.ivf_build(Xd, off, nl, kmeans_iters=2, Xkm=Xd.to(torch.float16).contiguous(), Xpre=Xd.to(torch.float16).contiguous(),
+                        prefilter_which=2)
+    n1 = pre.search_neighbors(16, 32, mz_d, None, 20.0, "ppm", None, 16)
+    assert torch.equal(n0[0], n1[0]) and torch.equal(n0[1].view(torch.int32), n1[1].view(torch.int32))
+
+
 @pytest.mark.parametrize("d,n_probe", [(400, 16), (400, 3), (128, 8), (64, 1)])
 def test_coarse_quantiser_from_the_build_keys_gives_the_same_search(ctx, d, n_probe):
     """an index built with the float16 k-means prefilter keeps the final pass's (row, centroid) similarities as 16-bit keys and
