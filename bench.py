@@ -199,7 +199,10 @@ def main():
     ap.add_argument("--big-spectra", type=int, default=50_000_000,
                     help="BASELINE configs[3] at its own size (n_probe 32, n_neighbors_ann 128), run in --big-chunks bucket shares "
                          "(ClusterPipeline.run_chunked); 0 = skip")
-    ap.add_argument("--big-chunks", type=int, default=4)
+    ap.add_argument("--big-chunks", type=int, default=4,
+                    help="bucket shares of the 50 M configuration (measured alone in a process: 2 shares 962 ms, 3 shares 978, 4 shares "
+                         "992 per pass; behind the other configurations of a default run -- whose scratch pools stay with their "
+                         "contexts -- 2 shares run out of device memory, so the default stays 4)")
     ap.add_argument("--skew-spectra", type=int, default=2_000_000,
                     help="the skewed-workload entry of `configs` (synth skew=True: log-normal window occupancy, 5..50 peaks); 0 = skip")
     ap.add_argument("--partitions", choices=["auto", "concurrent", "pipelined"], default="auto",
@@ -586,7 +589,7 @@ def main():
         plan = [e for e in plan if e[1] > 0]
         if args.big_spectra > 0:
             # ... and configs[3] itself: 50 M spectra; the working set of one pass (~260 GB) does not fit beside the dataset,
-            # so the precursor buckets run in 4 shares one after the other (ClusterPipeline.run_chunked)
+            # so the precursor buckets run in 4 shares one after the other (ClusterPipeline.run_chunked; --big-chunks)
             plan.append(("f32-50M", args.big_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32, n_neighbors_ann=128),
                          1200.0, args.big_chunks, args.batch_size))
         big, big_key = None, None
