@@ -328,7 +328,10 @@ def main():
 
     def step(parts, run_args, collect=None, chunks=1):
         """one pass of the hot path over the dataset; `collect` != None: serial, per-stage timing, no exchange"""
-        if chunks > 1:                                                            # (configs[3] at its own size, one GPU)
+        if chunks > 1 and collect is None and not args.serial and concurrent["on"] and os.environ.get("FALCON_BENCH_CHUNKED") != "pipelined":
+            outs = runner.run_chunked(parts, *run_args, n_chunks=chunks)          # (configs[3] at its own size, one GPU:
+            lasts = []                                                            #  every share's partitions on concurrent slots)
+        elif chunks > 1:
             outs = pipe.run_chunked(parts, *run_args, n_chunks=chunks)
             lasts = []
         elif collect is None and not args.serial and concurrent["on"]:

@@ -507,6 +507,33 @@ class PartitionRunner:
         self.lasts = [r[1] for r in res]                           # every partition's `last`, in the order of `datasets`
         return [r[0] for r in res]
 
+    def run_chunked(self, datasets, *args, n_chunks: int, on_chunk=None, **kwargs):
+        """`ClusterPipeline.run_chunked` with the partitions of every bucket share on concurrent slots: the precursor windows of the
+        job are dealt into `n_chunks` shares exactly as they are dealt to GPUs, the shares run one after the other, each
+        through `run(shard=(c, n_chunks))`.  Same partition as one pass; cluster ids are share-major.
+        -> [(labels i32[N_j] by dataset row, medoids i32[n_labels_j] dataset rows)] per dataset."""
+        import torch
+        if n_chunks <= 1:
+            return self.run(datasets, *args, **kwargs)
+        dev = torch.device("cuda", self.device)
+        labels = [torch.full((len(ds),), -1, dtype=torch.int32, device=dev) for ds in datasets]
+        medoids = [[] for _ in datasets]
+        off = [0] * len(datasets)
+        for ch in range(n_chunks):
+            outs = self.run(datasets, *args, shard=(ch, n_chunks), **kwargs)
+            for j, ((lab, med), last) in enumerate(zip(outs, self.lasts)):
+                rows = last["rows"]
+                if rows.numel() == 0:
+                    continue
+                labels[j][rows] = lab + off[j]
+                medoids[j].append(rows[med.long()].to(torch.int32))
+                off[j] += int(med.numel())
+            if on_chunk is not None:
+                on_chunk(ch, outs, self.lasts)
+            del outs
+        return [(labels[j], torch.cat(medoids[j]) if medoids[j] else torch.empty(0, dtype=torch.int32, device=dev))
+                for j in range(len(datasets))]
+
     def close(self):
         self._pool.shutdown(wait=True)
 

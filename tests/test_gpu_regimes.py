@@ -211,6 +211,35 @@ def test_many_partition_job_equals_single_gpu(ctx):
         runner.close()
 
 
+def test_chunked_runs_pipelined_and_on_concurrent_slots_give_the_same_partition(ctx):
+    """a job run in bucket shares (BASELINE configs[3] at 50 M spectra on one GPU): `ClusterPipeline.run_chunked` (a share's
+    partitions software-pipelined) and `PartitionRunner.run_chunked` (on concurrent slots, what bench.py times) return the same
+    labels and medoids, and the partition of the single pass"""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, PartitionRunner, SpectrumDataset
+    data = synth.generate(30000, seed=31, mz_lo=600.0, mz_hi=612.0)          # flat and indexed buckets
+    parts = []
+    for ch in (2, 3):
+        c = synth.select_charge(data, ch)
+        parts.append(SpectrumDataset(c["precursor_mz"], c["retention_time"], c["mz"], c["intensity"], c["indptr"]))
+    args = (20.0, "ppm", None, 0.05, 2 ** 15, AnnParams())
+    pipe = ClusterPipeline(ctx)
+    single = [lab.cpu().numpy() for lab, _ in pipe.run_many(parts, *args)]
+    a = pipe.run_chunked(parts, *args, n_chunks=3)
+    runner = PartitionRunner(ctx.device, 2)
+    try:
+        b = runner.run_chunked(parts, *args, n_chunks=3)
+    finally:
+        runner.close()
+    for j, ((la, ma), (lb, mb)) in enumerate(zip(a, b)):
+        assert torch.equal(la, lb) and torch.equal(ma, mb)
+        la = la.cpu().numpy()
+        assert la.min() == 0 and np.array_equal(la[ma.cpu().numpy()], np.arange(len(ma)))
+        pairs = np.unique(np.stack([single[j], la]), axis=1)                   # the same partition, share-major ids
+        assert pairs.shape[1] == len(np.unique(single[j])) == len(np.unique(la))
+
+
 def test_bucket_sharded_run_many_equals_single_gpu(ctx):
     """bench.py's multi-GPU step on one device: `run_many(shard=(r, 3))` for r = 0, 1, 2 (the same buckets -> ranks
     assignment every rank derives) and `SparseGraphExchange.assemble_labels`-style merging give the single-GPU
