@@ -131,6 +131,54 @@ __global__ __launch_bounds__(1024) void probe_hist_bucket_kernel(const int32_t* 
     for (int i = threadIdx.x; i < nl; i += blockDim.x) cnt[job.c_row0 + i] = hist[i];
 }
 
+// probe_hist_bucket_kernel + probe_totals_kernel in one pass over the probes (round 5; buckets of up to 4,096 lists): a thread per
+// query, the bucket's list sizes and the histogram in LDS -- a query's candidate total is the sum of its probed lists' sizes
+// (16 LDS reads instead of 32 dependent 8-byte gathers from global memory), stored at its tile-order slot; the launch's largest
+// total behind the padded slots as probe_totals_kernel leaves it.
+template <int NPV>
+__global__ __launch_bounds__(1024) void probe_hist_totals_bucket_kernel(const int32_t* __restrict__ probes, int np,
+                                                                        const DenseJob* __restrict__ jobs,
+                                                                        const int64_t* __restrict__ list_off, int64_t n_tiles,
+                                                                        int32_t* __restrict__ cnt, int64_t* __restrict__ totals) {
+    extern __shared__ int32_t lds32[];
+    const DenseJob job = jobs[blockIdx.x];
+    const int nl = job.nc;
+    int32_t* hist = lds32;                // [nl]
+    int32_t* len = lds32 + nl;            // [nl] rows of every list
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) {
+        hist[i] = 0;
+        len[i] = (int32_t)(list_off[job.c_row0 + i + 1] - list_off[job.c_row0 + i]);
+    }
+    __syncthreads();
+    int64_t mx = 0;
+    for (int ql = threadIdx.x; ql < job.nq; ql += blockDim.x) {
+        const int64_t p = job.q_row0 + ql;
+        int64_t tot = 0;
+        auto take = [&](int l) {
+            if (l < 0) return;
+            atomicAdd(&hist[l], 1);
+            tot += len[l];
+        };
+        if (NPV > 0) {
+            int4 pr[NPV > 0 ? NPV : 1];
+            const int4* src = reinterpret_cast<const int4*>(probes + p * np);
+#pragma unroll
+            for (int v = 0; v < NPV; ++v) pr[v] = src[v];
+#pragma unroll
+            for (int v = 0; v < NPV; ++v) { take(pr[v].x); take(pr[v].y); take(pr[v].z); take(pr[v].w); }
+        } else {
+            for (int j = 0; j < np; ++j) take(probes[p * np + j]);
+        }
+        totals[32 * (job.tile0 + (ql >> 5)) + (ql & 31)] = tot;
+        mx = max(mx, tot);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = max(mx, (int64_t)__shfl_xor((long long)mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(reinterpret_cast<unsigned long long*>(totals + 32 * n_tiles + 1), (unsigned long long)mx);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nl; i += blockDim.x) cnt[job.c_row0 + i] = hist[i];
+}
+
 // The same table with every list's entries in ASCENDING QUERY ORDER (to within one chunk of 1,024 queries): one workgroup per
 // bucket walks the bucket's queries chunk by chunk, cursors in LDS.  The fine-scan kernels stream a list's queries in table
 // order; the ~64 lists of a bucket that run concurrently on an XCD then sweep the bucket's rows together and share them in L2
@@ -529,7 +577,9 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size(); sa.tile_begin = t0; sa.ids_are_rows = 0;
         FAL_TRY(launch_select(ctx, ST_COARSE, MODE_DENSE, sa, (t1 - t0) * 32));
     }
-    {
+    // (buckets of up to 4,096 lists: the candidate totals come out of the probe histogram's pass below, one kernel for both)
+    const bool fused_totals = max_n_list <= 4096;
+    if (!fused_totals) {
         StageScope ts(ctx, ST_COARSE);
         const dim3 tg((unsigned)ceil_div(n_slots, 256));
         if (np == 16)
@@ -564,7 +614,20 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     {
         StageScope ts(ctx, ST_COARSE);
         const unsigned pg = (unsigned)ceil_div(n_slots, 256);
-        if (max_n_list <= 16384)
+        if (fused_totals) {
+            const dim3 hg((unsigned)coarse.size());
+            const size_t hl = 2 * sizeof(int32_t) * (size_t)max_n_list;
+            if (np == 16)
+                hipLaunchKernelGGL(probe_hist_totals_bucket_kernel<4>, hg, dim3(1024), hl, st, probes, np, coarse_dev, ivf->list_off,
+                                   ivf_tiles, cnt, totals);
+            else if (np == 32)
+                hipLaunchKernelGGL(probe_hist_totals_bucket_kernel<8>, hg, dim3(1024), hl, st, probes, np, coarse_dev, ivf->list_off,
+                                   ivf_tiles, cnt, totals);
+            else
+                hipLaunchKernelGGL(probe_hist_totals_bucket_kernel<0>, hg, dim3(1024), hl, st, probes, np, coarse_dev, ivf->list_off,
+                                   ivf_tiles, cnt, totals);
+            FAL_TRY(device_scan_i64(ctx, totals, n_slots, q_sim_off, SLOT_MISC2));
+        } else if (max_n_list <= 16384)
             hipLaunchKernelGGL(probe_hist_bucket_kernel, dim3((unsigned)coarse.size()), dim3(1024), sizeof(int32_t) * (size_t)max_n_list,
                                st, probes, np, coarse_dev, cnt);
         else
