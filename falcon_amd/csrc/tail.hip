@@ -235,6 +235,43 @@ __global__ __launch_bounds__(64) void refine_kernel(int32_t* __restrict__ rows, 
             if (lane == 0) n_sub[c] = 0;
             continue;
         }
+        // Round 5: the common case first -- every member within the tolerance of every other.  The root of the 1-D complete-
+        // linkage dendrogram is the pair (largest, smallest value) and its height link_dist(max, min) bounds every other
+        // merge (float32 difference and division are monotone), so fcluster(Z, t, "distance") returns ONE flat cluster
+        // exactly when link_dist(max, min) <= t (cluster.py:433-435: every member keeps the DBSCAN cluster) -- the same
+        // arithmetic, no margin.  Two loads per member, two wave reductions; the sort, the dendrogram and the numbering
+        // (~1,500 instructions per cluster: the kernel was instruction-bound) run only for clusters that do split.
+        {
+            float vmin = INFINITY, vmax = -INFINITY, rmin = INFINITY, rmax = -INFINITY;
+            bool bad = false;
+            for (int e = lane; e < m; e += 64) {
+                const int32_t rr = rows[o + e];
+                const float v = mz[rr];
+                bad = bad || !(v == v);
+                vmin = fminf(vmin, v);
+                vmax = fmaxf(vmax, v);
+                if (use_rt) {
+                    const float u = rt[rr];
+                    bad = bad || !(u == u);
+                    rmin = fminf(rmin, u);
+                    rmax = fmaxf(rmax, u);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                vmin = fminf(vmin, __shfl_xor(vmin, off, 64));
+                vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+                rmin = fminf(rmin, __shfl_xor(rmin, off, 64));
+                rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
+            }
+            bool one = !__any(bad) && link_dist(vmax, vmin, !is_da) <= tol;
+            if (use_rt) one = one && link_dist(rmax, rmin, false) <= rt_tol;
+            if (one) {                                 // (uniform over the wave)
+                for (int e = lane; e < m; e += 64) out[e] = 0;
+                if (lane == 0) n_sub[c] = 1;
+                continue;
+            }
+        }
         const bool small = m <= kLdsMembers;
         const RefineScratch& W = small ? L : S;        // work arrays of this cluster ...
         const int64_t wo = small ? 0 : o;              // ... and where they start
