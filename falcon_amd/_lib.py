@@ -12,7 +12,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfalcon_hip.so")
 
-FAL_DTYPE_F32, FAL_DTYPE_F16, FAL_DTYPE_SPLIT16 = 0, 1, 2
+FAL_DTYPE_F32, FAL_DTYPE_F16, FAL_DTYPE_SPLIT16, FAL_OUT_F32_F16, FAL_OUT_F16_IMAGE = 0, 1, 2, 3, 4
 STAGES = {"vectorize": 0, "build": 1, "coarse": 2, "scan": 3, "select": 4, "filter": 5, "dbscan": 6, "tail": 7,
           "kernel": 8}     # the cosine kernel's own launches (subset of "scan")
 
@@ -45,6 +45,9 @@ _SIGNATURES = {
                             c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p], c_int),
     "fal_vectorize_f16_image": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
                                  c_uint32, c_uint32, c_uint32, c_int, c_void_p, c_void_p], c_int),
+    "fal_row_width": ([c_uint32, P(c_uint32)], c_int),
+    "fal_vectorize_rows": ([c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double,
+                            c_uint32, c_uint32, c_uint32, c_uint32, c_int, c_int, c_void_p, c_void_p], c_int),
     "fal_window_counts": ([c_void_p, c_void_p, c_void_p, c_int, c_double, c_int64, c_void_p, c_void_p], c_int),
     "fal_window_select": ([c_void_p, c_void_p, c_int64, c_double, c_int64, c_void_p, c_int, c_void_p, c_void_p, P(c_int64)], c_int),
     "fal_precursor_splits": ([c_void_p, c_void_p, c_int64, c_double, c_int, c_int64, c_double, c_int,

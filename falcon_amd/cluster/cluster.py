@@ -19,7 +19,9 @@ from .. import device as _device
 
 logger = logging.getLogger("falcon")
 
-F16_INDEX_DIMS = (64, 128, 256, 400, 800)   # low_dim values the float16 index kernels (assign16 / list16) are instantiated for
+F16_INDEX_DIMS = (64, 128, 256, 400, 800)   # row widths the float16 index kernels (assign16 / list16) are instantiated for =
+                                            # the widths `device.row_width(low_dim)` pads the rows to
+F16_FLAT_DIMS = (64, 128, 256, 400)         # ... the on-chip top-k of flat buckets (fused.hip) and the hi/lo split scan
 FLAT_MAX = 100           # buckets up to this size use a flat (single list) index
 MIN_PTS_PER_LIST = 39    # [SURVEY App. A] Faiss' minimum points per centroid
 MAX_N_LIST = 1 << 17
@@ -29,7 +31,8 @@ MAX_N_LIST = 1 << 17
 class AnnParams:
     """The README's nearest-neighbour options (README.md:73-79, 107-117) plus the build's."""
     eps: float = 0.1
-    low_dim: int = 400
+    low_dim: int = 400            # any integer in [1, 800] (README.md:114-117): the hash modulus; rows are stored
+                                  # `device.row_width(low_dim)` columns wide (64 / 128 / 256 / 400 / 800), zero behind low_dim
     n_probe: int = 16
     n_neighbors: int = 64
     n_neighbors_ann: int = 128
@@ -149,9 +152,9 @@ class ClusterPipeline:
         rts = c.gather_f32(ds.retention_time, order) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
         n_list = n_list_rule(np.diff(splits), p.n_probe)
-        if p.dtype == "f16" and not (p.f16_index and p.low_dim in F16_INDEX_DIMS):
-            # float16 vectors without an index (AnnParams.f16_index off, or a low_dim the index kernels are not instantiated
-            # for): every bucket is searched exhaustively on the f16 matrix cores -- a superset of what n_probe lists find
+        if p.dtype == "f16" and not p.f16_index:
+            # float16 vectors without an index (AnnParams.f16_index off): every bucket is searched exhaustively on the f16
+            # matrix cores -- a superset of what n_probe lists find
             n_list[:] = 1
         return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list)
 
@@ -198,7 +201,7 @@ class ClusterPipeline:
         rts = c.gather_f32(ds.retention_time, rows_sorted) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
         n_list = n_list_rule(np.diff(splits), p.n_probe)
-        if p.dtype == "f16" and not (p.f16_index and p.low_dim in F16_INDEX_DIMS):
+        if p.dtype == "f16" and not p.f16_index:
             n_list[:] = 1
         return dict(order=rows_sorted, mzs=mzs, rts=rts, splits=splits, n_list=n_list, rows=rows_sorted, n_total=n)
 
@@ -232,10 +235,16 @@ class ClusterPipeline:
         order, mzs, rts, splits, n_list = st["order"], st["mzs"], st["rts"], st["splits"], st["n_list"]
         n_bins, start, _ = _device.get_dim(p.min_mz, p.max_mz, fragment_tol)      # falcon.py:124-126
         all_flat = bool((n_list == 1).all())
+        # `--low_dim` is a free integer (README.md:114-117): the hash runs modulo low_dim, the rows are stored W columns wide
+        # (the next width the kernels are instantiated for) with zeros behind -- every kernel below sees d = W
+        W = _device.row_width(p.low_dim)
+        assert W in F16_INDEX_DIMS
         vec = lambda dt: c.vectorize(ds.mz, ds.intensity, ds.indptr, order, start, fragment_tol, n_bins, p.low_dim,
-                                     p.hash_seed, True, dt)
+                                     p.hash_seed, True, dt, width=W)
         X = X16 = Xpre = Xkm = None
         which = 0
+        if p.dtype not in ("f32", "f16"):
+            raise ValueError(f"unknown dtype {p.dtype!r} (f32 or f16)")
         if p.dtype == "f16" and not all_flat:
             # float16 vectors with an index: the exact kernels (k-means close calls, coarse quantiser, pair chains) work on the
             # float32 image of the rounded rows, the float16 rows themselves are every prefilter copy AND the flat buckets' scan
@@ -246,16 +255,17 @@ class ClusterPipeline:
         elif p.dtype == "f16":
             X16 = vec("f16")
         elif p.scan == "f16x3":
+            if W not in F16_FLAT_DIMS:
+                raise ValueError(f"scan='f16x3' needs low_dim <= {F16_FLAT_DIMS[-1]} (got {p.low_dim})")
             X16 = vec("split16")
             if not all_flat:
                 X = vec("f32")              # k-means, coarse quantiser and IVF fine scan stay exact fp32
         else:
-            ok16 = p.low_dim in (64, 128, 256, 400)
-            if p.prefilter and not keep_intermediates and ok16 and bool((n_list == 1).any()):
+            if p.prefilter and not keep_intermediates and W in F16_FLAT_DIMS and bool((n_list == 1).any()):
                 which |= 1
-            if p.ivf_prefilter and not keep_intermediates and ok16 and bool((n_list > 1).any()):
+            if p.ivf_prefilter and not keep_intermediates and bool((n_list > 1).any()):
                 which |= 2
-            want_km = p.kmeans_prefilter and ok16 and bool(((n_list > 1) & (n_list <= 2048)).any())      # (scan.h kAssignMergeLists)
+            want_km = p.kmeans_prefilter and bool(((n_list > 1) & (n_list <= 2048)).any())      # (scan.h kAssignMergeLists)
             if want_km or which:
                 X, x16 = vec("f32+f16")            # the float16 rounding of the same rows, from the same pass over the peaks
                 Xkm = x16 if want_km else None

@@ -4,7 +4,7 @@ Mirrors reference falcon/config.py:24-212 (names, defaults, nargs, choices, `con
 default file, `-c/--config`, attribute access, RuntimeError before `parse`) and ADDS the
 nearest-neighbour options the README documents but the snapshot's parser lacks
 (`--eps` README.md:49,73-79; `--n_probe`, `--n_neighbors`, `--n_neighbors_ann`
-README.md:107-113; `--low_dim` README.md:114-117).  configargparse is not available, so
+README.md:107-113; `--low_dim` README.md:114-117) plus the build's `--dtype`.  configargparse is not available, so
 the INI layer is stdlib configparser: values from the file become defaults, the command
 line overrides them (the precedence configargparse implements).
 """
@@ -59,7 +59,12 @@ class Config:
         p.add_argument("--n_probe", type=int, default=16, help="Maximum number of inverted lists to inspect.")
         p.add_argument("--n_neighbors", type=int, default=64, help="Final number of neighbours per spectrum.")
         p.add_argument("--n_neighbors_ann", type=int, default=128, help="Neighbours retrieved by the ANN search.")
-        p.add_argument("--low_dim", type=int, default=400, help="Length of the hashed vectors.")
+        p.add_argument("--low_dim", type=int, default=400,
+                       help="Low-dimensional vector length (README.md:114-117): any integer in [1, 800]. The vectors are "
+                            "stored in rows of the next instantiated width (64 / 128 / 256 / 400 / 800), zero behind low_dim.")
+        p.add_argument("--dtype", type=str, default="f32", choices=["f32", "f16"],
+                       help="Element type of the hashed vectors: f32 (default) or f16 (half the bytes per vector; the "
+                            "similarity of two float16 vectors is the float32 chain over their exact float32 images).")
         p.add_argument("--mz_interval", type=float, default=1.0,
                        help="Width in m/z of the precursor windows that bound an index (0 = off).")
         p.add_argument("--rescore", action="store_true",
@@ -142,6 +147,8 @@ class Config:
             self._parser.error(f"--linkage {ns['linkage']} needs --clustering hierarchical (DBSCAN has no linkage)")
         if ns["clustering"] == "hierarchical":
             ns["rescore"] = True
+        if not 1 <= ns["low_dim"] <= 800:
+            raise ValueError("low_dim must be an integer in [1, 800] (README.md:114-117; the widest rows the kernels hold)")
         if ns["n_neighbors_ann"] < ns["n_neighbors"]:
             raise ValueError("n_neighbors_ann should be equal or greater than n_neighbors (README.md:110-113)")
         self._namespace = ns

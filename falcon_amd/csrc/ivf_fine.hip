@@ -21,8 +21,11 @@ namespace fal {
 // Tiles of this kernel = groups of 4 slices (ListScanArgs::group_shift = 7).
 // ------------------------------------------------------------------------------------------------
 
-template <int DH4>
-__global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
+// MODE 1 / 2 (rows of 513..800 columns, `--low_dim` 401..800 in float32): one launch per K-HALF, as in dense4_kernel (scan.hip)
+// -- a.d = the columns one pass sees (half the row), the physical rows are 2 a.d floats wide, pass k_off = 0 takes the columns
+// [0, d/2) + [d, 3d/2), pass k_off = d/2 the rest and (MODE 2) starts every block from the sums the first pass stored.
+template <int DH4, int MODE>
+__global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a, int k_off) {
     __shared__ float4 sbuf0[DH4 * 64];       // separate objects, named per phase of the 2x-unrolled loop (assign.hip)
     __shared__ float4 sbuf1[DH4 * 64];
     const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
@@ -39,6 +42,8 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int slice = 4 * (int)(t - a.ltile_off[L]) + w;  // this wave's 32-row slice of the list
     const int d = a.d, dh = d >> 1, dh4 = dh >> 2;
+    const int rstride = MODE == 0 ? d : 2 * d;            // floats between two rows of Xl
+    const int hoff = (MODE == 0 ? dh : d) * h + k_off;    // where this lane's k-half of a row starts
     const int64_t l_row0 = a.list_off[L];
     const int l_rows = (int)(a.list_off[L + 1] - l_row0);
     const int nrow = min(32, l_rows - 32 * slice);        // rows of this slice (<= 0: the wave only helps loading)
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
     const bool active = nrow > 0;
 
     float q[DH4 * 4];                                      // the resident operand: list row 32*slice + r
-    load_half_row<DH4>(q, a.Xl + (l_row0 + min(32 * slice + min(r, max(nrow, 1) - 1), l_rows - 1)) * d + (int64_t)h * dh, dh4);
+    load_half_row<DH4>(q, a.Xl + (l_row0 + min(32 * slice + min(r, max(nrow, 1) - 1), l_rows - 1)) * rstride + hoff, dh4);
     const int pos = 32 * slice + r;                        // position inside the list = offset inside a query's segment
     const bool rvalid = active && r < nrow;
 
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
     // touched earlier, hipcc waits vmcnt(0) on the spot and the LDS-DMA just issued drains with it
     auto pin = [](int32_t& x, int64_t& y) { asm volatile("" : "+v"(x), "+v"(y)); };
     auto issue = [&](int32_t row, float4* buf) {
-        const float4* rowp = reinterpret_cast<const float4*>(a.Xl + (int64_t)row * d + (int64_t)h * dh);
+        const float4* rowp = reinterpret_cast<const float4*>(a.Xl + (int64_t)row * rstride + hoff);
 #pragma unroll
         for (int jj = 0; jj < (DH4 + 3) / 4; ++jj) {
             const int j = 4 * jj + w;
@@ -95,6 +100,17 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        if (MODE == 2) {
+            // the sums of the first K-half: this chunk's own slots (read before the previous chunk's epilogue below stores
+            // anything; the staged path is not the timed one -- the wait for these loads drains the row DMA just issued)
+            const uint32_t dcur = (uint32_t)(q_dest(c0) - a.sims_base);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qr = mfma32_row(i, h);
+                const uint32_t dest = (uint32_t)__shfl((int)dcur, qr, 64);
+                if (rvalid && c0 + qr < nq) acc[i] = a.sims[dest + pos];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < DH4; ++j) {
             const float4 s = ring[j % kRing];
@@ -142,24 +158,30 @@ __global__ __launch_bounds__(256, 1) void ivf_list4_kernel(ListScanArgs a) {
     }
 }
 
-int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a) {
-    if (a.n_tiles_max <= 0) return FAL_OK;
+int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a_in) {
+    if (a_in.n_tiles_max <= 0) return FAL_OK;
+    ListScanArgs a = a_in;
+    const bool split = a.d > 512;
+    if (split) a.d /= 2;                                   // (the columns one K-half pass sees)
     const int dh4 = a.d / 8;
     const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
     FAL_REQUIRE(per_xcd * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     dim3 grid((unsigned)(per_xcd * 8)), block(256);
     StageScope ts(ctx, ST_SCAN);
     StageScope tk(ctx, ST_KERNEL);
-#define FAL_LAUNCH_LIST(DH4) hipLaunchKernelGGL(ivf_list4_kernel<DH4>, grid, block, 0, ctx->stream, a)
-    if (dh4 <= 8) FAL_LAUNCH_LIST(8);
+#define FAL_LAUNCH_LIST(DH4) hipLaunchKernelGGL((ivf_list4_kernel<DH4, 0>), grid, block, 0, ctx->stream, a, 0)
+    if (split) {
+        if (a_in.d > 800 || a_in.d % 16 != 0) {
+            set_error("float32 scan supports low_dim <= 512 and 513..800 in steps of 16 (got %d)", a_in.d);
+            return FAL_EUNSUPPORTED;
+        }
+        hipLaunchKernelGGL((ivf_list4_kernel<50, 1>), grid, block, 0, ctx->stream, a, 0);
+        hipLaunchKernelGGL((ivf_list4_kernel<50, 2>), grid, block, 0, ctx->stream, a, a.d / 2);
+    } else if (dh4 <= 8) FAL_LAUNCH_LIST(8);
     else if (dh4 <= 16) FAL_LAUNCH_LIST(16);
     else if (dh4 <= 32) FAL_LAUNCH_LIST(32);
     else if (dh4 <= 50) FAL_LAUNCH_LIST(50);
-    else if (dh4 <= 64) FAL_LAUNCH_LIST(64);
-    else {
-        set_error("float32 scan supports low_dim <= 512 (got %d)", a.d);
-        return FAL_EUNSUPPORTED;
-    }
+    else FAL_LAUNCH_LIST(64);
 #undef FAL_LAUNCH_LIST
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;

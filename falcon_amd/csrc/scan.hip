@@ -145,8 +145,16 @@ __global__ __launch_bounds__(64, 1) void dense_kernel(
 // are bit-identical.  A wave idles until the stream reaches its diagonal (the 4 x 4 corner of blocks costs 16 slots for 10
 // blocks).  Measured (s_memtime per workgroup): 16.6 k cycles per chunk against 12.8 k of MFMA issue.
 // ---------------------------------------------------------------------------------------------
-template <int DH4>
-__global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict__ X, int d, const DenseJob* __restrict__ jobs,
+//
+// MODE 1 / 2 (rows of more than 400 columns: `--low_dim` 401..800 in float32): one launch per K-HALF of rows that are 2 d floats
+// wide.  A pass sees the "virtual" row [k_off, k_off + d/2) ++ [d + k_off, d + k_off + d/2) of every physical row (k_off = 0, then
+// d/2) -- two contiguous segments, fetched by the same row DMAs -- so its MFMA step kk multiplies the columns (k_off + kk,
+// d + k_off + kk): pass 0 then pass 1 walk the k-ordered chain of the 2 d-wide row (simtile.h) front to back.  MODE 2 starts
+// every block's accumulators from what pass 0 stored (the block's own [32, 32] slots: loaded one chunk ahead, before the next
+// chunk's row DMAs are issued, so the hand-counted waits see them complete) instead of zero: the same chain, bit for bit,
+// with the query tile still in registers (200 of them; 400 do not exist).
+template <int DH4, int MODE>
+__global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict__ X, int d, int k_off, const DenseJob* __restrict__ jobs,
                                                         float* __restrict__ sims, int64_t sims_base,
                                                         int32_t* __restrict__ cursors, const int32_t* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char stream_lds[];
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int dh = d >> 1, dh4 = dh >> 2;
     const int row_bytes = d * 4, rs = row_bytes + 16;
+    const int rstride = MODE == 0 ? d : 2 * d;               // floats between two rows of X
     unsigned char* const buf0 = stream_lds;
     unsigned char* const buf1 = stream_lds + 32 * rs;
     const unsigned char* const my0 = buf0 + r * rs + h * (dh * 4);      // this lane's operand row in either buffer
@@ -174,8 +183,11 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
     auto issue_piece = [&](int k, const Target& t) {
         const int p = k / 8, row = 8 * w + (k & 7);
         if (p * 1024 + lane * 16 < row_bytes) {
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(t.rows + (int64_t)min(t.c0 + row, t.nc - 1) * d) +
-                                       p * 1024 + lane * 16;
+            const int vb = p * 1024 + lane * 16;             // byte of the (virtual) row this lane brings
+            const float* rowp = t.rows + (int64_t)min(t.c0 + row, t.nc - 1) * rstride;
+            const unsigned char* src = MODE == 0 ? reinterpret_cast<const unsigned char*>(rowp) + vb
+                                                 : reinterpret_cast<const unsigned char*>(rowp + k_off + (vb >= 2 * d ? d : 0)) +
+                                                       (vb >= 2 * d ? vb - 2 * d : vb);
             const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)((uint32_t)(size_t)(__attribute__((address_space(3))) const void*)t.buf + (uint32_t)(row * rs + p * 1024)));
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory", "m0");
@@ -227,9 +239,9 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
     Target first_of_next{X, 1, 0, nullptr, false};
     if (have_next) {
         const int nj = items[2 * nxt], ng = items[2 * nxt + 1];
-        first_of_next = Target{X + jobs[nj].c_row0 * d, jobs[nj].nc, 128 * ng, nullptr, true};
+        first_of_next = Target{X + jobs[nj].c_row0 * rstride, jobs[nj].nc, 128 * ng, nullptr, true};
     }
-    const float* const rows = X + job.c_row0 * d;
+    const float* const rows = X + job.c_row0 * rstride;
     const int lt = 4 * g + w;                                // this wave's 32-query tile of the bucket
     const int nc = job.nc, ncp = (nc + 31) & ~31;
     const bool active = 32 * lt < job.nq;
@@ -246,6 +258,12 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 16; ++i) prev[i] = 0.f;
     int prev_c0 = min(c_stop, c_last);
+    // MODE 2: the accumulators the NEXT block starts from = what the first K-half's pass stored in the block's slots
+    f32x16 init;
+    auto load_init = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) init[i] = out[mfma32_row(i, h) * ncp + min(c0, c_last)];
+    };
     // the 20 stores of a finished block (first call: zeros into the diagonal chunk's slots, overwritten by the real
     // epilogue later in program order): 16 rows of the block, then the transposed block in four 16-byte columns
     auto store_piece = [&](int k) {
@@ -272,7 +290,8 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
         for (int j = 0; j < kRing; ++j) ring[j] = ld(j);
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 16; ++i) acc[i] = MODE == 2 ? init[i] : 0.f;
+        if (MODE == 2) load_init(c0 + 32);                   // (VM loads in front of this chunk's row DMAs and stores)
 #pragma unroll
         for (int j = 0; j < DH4; ++j) {
             const float4 s = ring[j % kRing];
@@ -325,7 +344,10 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
             chunk_barrier(after);                            // chunk ci has landed in buf0, buf1 is free again
             Target next = ci + 1 < n_chunks ? Target{rows, nc, c0 + 32, buf1, true} : first_of_next;
             next.buf = buf1;
-            if (active && c0 == c_stop) take_queries(my0);
+            if (active && c0 == c_stop) {
+                if (MODE == 2) load_init(c0);
+                take_queries(my0);
+            }
             if (active && c0 >= c_stop) {
                 compute(my0, c0, next);
                 after = kStores;
@@ -341,7 +363,10 @@ __global__ __launch_bounds__(256, 1) void dense4_kernel(const float* __restrict_
         chunk_barrier(after);                                // chunk ci has landed in buf1, buf0 is free again
         Target next = ci + 1 < n_chunks ? Target{rows, nc, c0 + 32, buf0, true} : first_of_next;
         next.buf = buf0;
-        if (active && c0 == c_stop) take_queries(my1);
+        if (active && c0 == c_stop) {
+            if (MODE == 2) load_init(c0);
+            take_queries(my1);
+        }
         if (active && c0 >= c_stop) {
             compute(my1, c0, next);
             after = kStores;
@@ -444,13 +469,16 @@ __global__ __launch_bounds__(256, 1) void dense_tiny4_kernel(const float* __rest
 }
 
 
-bool dense4_supports(int d) { return d % 8 == 0 && d >= 32 && d <= 400; }   // (low_dim 512: the 64-step form needs scratch)
+bool dense4_supports(int d) { return d % 8 == 0 && d >= 32 && (d <= 400 || (d > 512 && d <= 800 && d % 16 == 0)); }
+// (low_dim 512: the 64-step form needs scratch -> dense_kernel; 513..800: two K-half passes of the 50-step form, MODE 1 / 2)
 
 // jobs_host = the host copy of `jobs` (sorted by decreasing size: job j belongs to XCD list j % 8)
 int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, const DenseJob* jobs_host, int n_jobs, float* sims,
                   int64_t sims_base) {
     if (n_jobs <= 0) return FAL_OK;
-    const int dh4 = d / 8;
+    const bool split = d > 512;
+    const int dv = split ? d / 2 : d;                        // columns one pass sees
+    const int dh4 = dv / 8;
     // the item table: 9 offsets (in items), then the (job, 128-row group) pairs of XCD list 0, 1, ... from word 16
     std::vector<int32_t> table(16, 0);
     for (int x = 0; x < 8; ++x) {
@@ -465,26 +493,33 @@ int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, con
     int32_t* table_dev = nullptr;
     FAL_TRY(ctx->reserve(SLOT_ITEMS, sizeof(int32_t) * table.size(), (void**)&table_dev));
     FAL_TRY(ctx->upload(table_dev, table.data(), sizeof(int32_t) * table.size()));
-    const size_t lds = (size_t)2 * 32 * (d * 4 + 16);
+    const size_t lds = (size_t)2 * 32 * (dv * 4 + 16);
     int32_t* cursors = nullptr;
     FAL_TRY(ctx->reserve(SLOT_CURSORS, sizeof(int32_t) * 16, (void**)&cursors));
     dim3 grid((unsigned)std::min<int64_t>(n_items, ctx->persistent_wgs)), block(256);
     StageScope ts(ctx, ST_SCAN);
     StageScope tk(ctx, ST_KERNEL);
-    FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t) * 8, ctx->stream));
-#define FAL_LAUNCH_DENSE4(DH4)                                                                                      \
+#define FAL_LAUNCH_DENSE4(DH4, MODE, KOFF)                                                                          \
     do {                                                                                                            \
-        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)dense4_kernel<DH4>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t) * 8, ctx->stream));                                \
+        FAL_CHECK_HIP(hipFuncSetAttribute((const void*)dense4_kernel<DH4, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                           (int)lds));                                                               \
-        hipLaunchKernelGGL((dense4_kernel<DH4>), grid, block, lds, ctx->stream, X, d, jobs, sims, sims_base, cursors, \
+        hipLaunchKernelGGL((dense4_kernel<DH4, MODE>), grid, block, lds, ctx->stream, X, dv, KOFF, jobs, sims, sims_base, cursors, \
                            table_dev);                                                                              \
     } while (0)
-    if (dh4 <= 8) FAL_LAUNCH_DENSE4(8);
-    else if (dh4 <= 16) FAL_LAUNCH_DENSE4(16);
-    else if (dh4 <= 32) FAL_LAUNCH_DENSE4(32);
-    else if (dh4 <= 50) FAL_LAUNCH_DENSE4(50);
+    if (split) {
+        if (dh4 > 50 || d % 16 != 0) {
+            set_error("dense4 supports low_dim <= 400 and 513..800 in steps of 16 (got %d)", d);
+            return FAL_EUNSUPPORTED;
+        }
+        FAL_LAUNCH_DENSE4(50, 1, 0);                         // columns [0, d/4) + [d/2, 3d/4) ...
+        FAL_LAUNCH_DENSE4(50, 2, dv / 2);                    // ... then [d/4, d/2) + [3d/4, d), from the first pass's sums
+    } else if (dh4 <= 8) FAL_LAUNCH_DENSE4(8, 0, 0);
+    else if (dh4 <= 16) FAL_LAUNCH_DENSE4(16, 0, 0);
+    else if (dh4 <= 32) FAL_LAUNCH_DENSE4(32, 0, 0);
+    else if (dh4 <= 50) FAL_LAUNCH_DENSE4(50, 0, 0);
     else {
-        set_error("dense4 supports low_dim <= 400 (got %d)", d);
+        set_error("dense4 supports low_dim <= 400 and 513..800 in steps of 16 (got %d)", d);
         return FAL_EUNSUPPORTED;
     }
 #undef FAL_LAUNCH_DENSE4

@@ -45,7 +45,7 @@ template <int OUT_F16>
 __global__ __launch_bounds__(64) void vectorize_kernel(
     const float* __restrict__ mz, const float* __restrict__ inten, const int64_t* __restrict__ indptr,
     const int64_t* __restrict__ row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-    uint32_t d, uint32_t seed, int normalize, void* __restrict__ out, void* __restrict__ out2, int chunk) {
+    uint32_t d, uint32_t hash_mod, uint32_t seed, int normalize, void* __restrict__ out, void* __restrict__ out2, int chunk) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t passes = (d + 255) / 256;
     float* acc = reinterpret_cast<float*>(smem);                 // passes*256 floats
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void vectorize_kernel(
                 x = first ? x_c : inten[p];
                 if (bin_of(first ? mz_c : mz[p], min_mz, bin_size, n_bins, &b)) {
                     pending = true;
-                    h = fal::murmur3_32((uint32_t)b, seed) % d;
+                    h = fal::murmur3_32((uint32_t)b, seed) % hash_mod;      // (columns hash_mod .. d - 1 of a padded row stay zero)
                 }
             }
             while (__any(pending)) {
@@ -208,7 +208,7 @@ int fal_to_vector_indices(fal_ctx* ctx, const float* mz, int64_t nnz, double min
 
 static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                           const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2);
+                          uint32_t hash_mod, uint32_t row_width, uint32_t seed, int normalize, int out_dtype, void* out, void* out2);
 
 int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                   const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
@@ -216,8 +216,8 @@ int fal_vectorize(fal_ctx* ctx, const float* mz, const float* intensity, const i
     fal::CallScope _call(ctx);
     FAL_REQUIRE(out_dtype == FAL_DTYPE_F32 || out_dtype == FAL_DTYPE_F16 || out_dtype == FAL_DTYPE_SPLIT16, FAL_EINVAL,
                 "fal_vectorize: bad out_dtype");
-    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out_dtype, out,
-                          nullptr);
+    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, low_dim, seed, normalize, out_dtype,
+                          out, nullptr);
 }
 
 int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
@@ -225,8 +225,8 @@ int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, co
                        uint32_t low_dim, uint32_t seed, int normalize, float* out_f32, void* out_f16) {
     fal::CallScope _call(ctx);
     FAL_REQUIRE(n == 0 || out_f16, FAL_EINVAL, "fal_vectorize_pair: NULL array");
-    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, -3, out_f32,
-                          out_f16);
+    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, low_dim, seed, normalize, -3,
+                          out_f32, out_f16);
 }
 
 int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
@@ -234,22 +234,49 @@ int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensit
                             uint32_t low_dim, uint32_t seed, int normalize, float* out_f32_image, void* out_f16) {
     fal::CallScope _call(ctx);
     FAL_REQUIRE(n == 0 || (out_f16 && out_f32_image), FAL_EINVAL, "fal_vectorize_f16_image: NULL array");
-    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, -4,
+    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, low_dim, seed, normalize, -4,
                           out_f32_image, out_f16);
 }
 
+int fal_row_width(uint32_t low_dim, uint32_t* row_width) {
+    FAL_REQUIRE(row_width, FAL_EINVAL, "fal_row_width: NULL");
+    static const uint32_t widths[] = {64, 128, 256, 400, 800};
+    for (uint32_t w : widths)
+        if (low_dim >= 1 && low_dim <= w) {
+            *row_width = w;
+            return FAL_OK;
+        }
+    fal::set_error("low_dim must be in [1, 800] (got %u): the widest instantiation of the cosine kernels holds 800 columns", low_dim);
+    return FAL_EUNSUPPORTED;
+}
+
+int fal_vectorize_rows(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr, const int64_t* row_order,
+                       int64_t n, double min_mz, double bin_size, uint32_t n_bins, uint32_t low_dim, uint32_t row_width,
+                       uint32_t seed, int normalize, int out_mode, void* out, void* out2) {
+    fal::CallScope _call(ctx);
+    FAL_REQUIRE(out_mode >= FAL_DTYPE_F32 && out_mode <= FAL_OUT_F16_IMAGE, FAL_EINVAL, "fal_vectorize_rows: bad out_mode");
+    FAL_REQUIRE(n == 0 || out_mode < FAL_OUT_F32_F16 || out2, FAL_EINVAL, "fal_vectorize_rows: NULL second output");
+    const int code = out_mode == FAL_OUT_F32_F16 ? -3 : out_mode == FAL_OUT_F16_IMAGE ? -4 : out_mode;
+    return vectorize_impl(ctx, mz, intensity, indptr, row_order, n, min_mz, bin_size, n_bins, low_dim, row_width, seed, normalize, code,
+                          out, out2);
+}
+
+// low_dim = the hash modulus (README.md:114-117: any positive integer); row_width = columns of an output row, a multiple of 8
+// >= low_dim: the columns behind low_dim are zero
 static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                           const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
-                          uint32_t low_dim, uint32_t seed, int normalize, int out_dtype, void* out, void* out2) {
+                          uint32_t hash_mod, uint32_t row_width, uint32_t seed, int normalize, int out_dtype, void* out, void* out2) {
     FAL_REQUIRE(ctx, FAL_EINVAL, "fal_vectorize: NULL ctx");
     FAL_REQUIRE(n >= 0 && bin_size > 0 && n_bins > 0, FAL_EINVAL, "fal_vectorize: bad sizes");
-    FAL_REQUIRE(low_dim >= 8 && low_dim <= FAL_MAX_LOW_DIM && low_dim % 8 == 0, FAL_EUNSUPPORTED,
-                "fal_vectorize: low_dim must be a multiple of 8 in [8, %d] (got %u)", FAL_MAX_LOW_DIM, low_dim);
+    FAL_REQUIRE(row_width >= 8 && row_width <= FAL_MAX_LOW_DIM && row_width % 8 == 0, FAL_EUNSUPPORTED,
+                "fal_vectorize: the row width must be a multiple of 8 in [8, %d] (got %u)", FAL_MAX_LOW_DIM, row_width);
+    FAL_REQUIRE(hash_mod >= 1 && hash_mod <= row_width, FAL_EINVAL, "fal_vectorize: low_dim %u must be in [1, row width %u]", hash_mod,
+                row_width);
     if (n == 0) return FAL_OK;
     FAL_REQUIRE(indptr && out, FAL_EINVAL, "fal_vectorize: NULL array");
     ctx->stage_reset(fal::ST_VECTORIZE);
-    const uint32_t passes = (low_dim + 255) / 256;
-    const size_t lds = (size_t)(passes * 256 + low_dim) * 4;
+    const uint32_t passes = (row_width + 255) / 256;
+    const size_t lds = (size_t)(passes * 256 + row_width) * 4;
     // rows per wave and turn: 16 at most (measured: 4..16 equal, 64 loses the balance again), fewer while the waves (32 per CU)
     // would get less than four turns each
     int chunk = 16;
@@ -259,19 +286,19 @@ static int vectorize_impl(fal_ctx* ctx, const float* mz, const float* intensity,
         fal::StageScope t(ctx, fal::ST_VECTORIZE);
         if (out_dtype == -4)
             hipLaunchKernelGGL(vectorize_kernel<4>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
+                               row_order, n, min_mz, bin_size, n_bins, row_width, hash_mod, seed, normalize, out, out2, chunk);
         else if (out_dtype == -3)
             hipLaunchKernelGGL(vectorize_kernel<3>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
+                               row_order, n, min_mz, bin_size, n_bins, row_width, hash_mod, seed, normalize, out, out2, chunk);
         else if (out_dtype == FAL_DTYPE_SPLIT16)
             hipLaunchKernelGGL(vectorize_kernel<2>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
+                               row_order, n, min_mz, bin_size, n_bins, row_width, hash_mod, seed, normalize, out, out2, chunk);
         else if (out_dtype == FAL_DTYPE_F16)
             hipLaunchKernelGGL(vectorize_kernel<1>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
+                               row_order, n, min_mz, bin_size, n_bins, row_width, hash_mod, seed, normalize, out, out2, chunk);
         else
             hipLaunchKernelGGL(vectorize_kernel<0>, dim3(grid), dim3(64), lds, ctx->stream, mz, intensity, indptr,
-                               row_order, n, min_mz, bin_size, n_bins, low_dim, seed, normalize, out, out2, chunk);
+                               row_order, n, min_mz, bin_size, n_bins, row_width, hash_mod, seed, normalize, out, out2, chunk);
     }
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;

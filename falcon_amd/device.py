@@ -91,7 +91,10 @@ class Context:
         return out
 
     def vectorize(self, mz, intensity, indptr, row_order, min_mz: float, bin_size: float, n_bins: int,
-                  low_dim: int, seed: int = 0, normalize: bool = True, dtype: str = "f32"):
+                  low_dim: int, seed: int = 0, normalize: bool = True, dtype: str = "f32", width: Optional[int] = None):
+        """a2 + a3 (`fal_vectorize_rows`).  `low_dim` = the hash modulus (any integer >= 1, README.md:114-117); `width` =
+        columns of an output row (default: low_dim, which then has to be a multiple of 8; `row_width(low_dim)` = the width
+        the path uses): the columns behind low_dim are zero and change no similarity."""
         torch = _torch()
         mz = self.to_dev(mz, torch.float32)
         intensity = self.to_dev(intensity, torch.float32)
@@ -99,26 +102,23 @@ class Context:
         row_order = None if row_order is None else self.to_dev(row_order, torch.int64)
         # output row i is spectrum row_order[i] of the CSR: a subset / permutation of the dataset is fine
         n = indptr.numel() - 1 if row_order is None else row_order.numel()
-        f16 = dtype in ("f16", "float16")
-        split = dtype == "split16"
+        w = int(low_dim if width is None else width)
+        out2 = None
         if dtype in ("f32+f16", "f16+image"):
             # one pass over the peaks, two outputs: float32 rows and their float16 rounding ("f16+image": float16 VECTORS --
-            # the float32 output is the image of the rounded values, fal_vectorize_f16_image)
-            out, out16 = self.empty((n, low_dim), torch.float32), self.empty((n, low_dim), torch.float16)
-            fn = self.lib.fal_vectorize_pair if dtype == "f32+f16" else self.lib.fal_vectorize_f16_image
-            check(fn(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
-                                              n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
-                                              int(normalize), self._p(out), self._p(out16)), "fal_vectorize_pair")
-            return out, out16
-        if split:
-            out, code = self.empty((n, 2, low_dim), torch.float16), _lib.FAL_DTYPE_SPLIT16
+            # the float32 output is the image of the rounded values)
+            out, out2 = self.empty((n, w), torch.float32), self.empty((n, w), torch.float16)
+            code = _lib.FAL_OUT_F32_F16 if dtype == "f32+f16" else _lib.FAL_OUT_F16_IMAGE
+        elif dtype == "split16":
+            out, code = self.empty((n, 2, w), torch.float16), _lib.FAL_DTYPE_SPLIT16
+        elif dtype in ("f16", "float16"):
+            out, code = self.empty((n, w), torch.float16), _lib.FAL_DTYPE_F16
         else:
-            out = self.empty((n, low_dim), torch.float16 if f16 else torch.float32)
-            code = _lib.FAL_DTYPE_F16 if f16 else _lib.FAL_DTYPE_F32
-        check(self.lib.fal_vectorize(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
-                                     n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), int(seed),
-                                     int(normalize), code, self._p(out)), "fal_vectorize")
-        return out
+            out, code = self.empty((n, w), torch.float32), _lib.FAL_DTYPE_F32
+        check(self.lib.fal_vectorize_rows(self._h, self._p(mz), self._p(intensity), self._p(indptr), self._p(row_order),
+                                          n, float(min_mz), float(bin_size), int(n_bins), int(low_dim), w, int(seed),
+                                          int(normalize), code, self._p(out), self._p(out2)), "fal_vectorize_rows")
+        return out if out2 is None else (out, out2)
 
 
     # ------------------------------------------------------------------ a6 / a7
@@ -443,6 +443,17 @@ def get_dim(min_mz: float, max_mz: float, bin_size: float):
     dim, s, e = C.c_uint32(), C.c_float(), C.c_float()
     check(lib.fal_get_dim(min_mz, max_mz, bin_size, C.byref(dim), C.byref(s), C.byref(e)), "fal_get_dim")
     return int(dim.value), float(s.value), float(e.value)
+
+
+def row_width(low_dim: int) -> int:
+    """`fal_row_width`: columns of the rows the path stores `low_dim`-dimensional vectors in (64 / 128 / 256 / 400 / 800: the
+    widths the cosine kernels are instantiated for; zero columns behind low_dim).  Raises beyond 800."""
+    lib = _lib.load()
+    w = C.c_uint32()
+    if int(low_dim) < 1:
+        raise FalconHipError(f"low_dim must be a positive integer (got {low_dim})")
+    check(lib.fal_row_width(int(low_dim), C.byref(w)), "fal_row_width")
+    return int(w.value)
 
 
 def hash_lookup(n_bins: int, low_dim: int, seed: int = 0) -> np.ndarray:

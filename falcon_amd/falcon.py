@@ -71,7 +71,7 @@ def _option_lines() -> List[str]:
         # nearest-neighbour options (README.md:101-117)
         f"eps = {c.eps:.3f}", f"n_probe = {c.n_probe}", f"n_neighbors = {c.n_neighbors}",
         f"n_neighbors_ann = {c.n_neighbors_ann}", f"low_dim = {c.low_dim}", f"mz_interval = {c.mz_interval}",
-        f"rescore = {c.rescore}", f"clustering = {c.clustering}",
+        f"rescore = {c.rescore}", f"clustering = {c.clustering}", f"dtype = {c.dtype}",
     ]
 
 
@@ -122,7 +122,7 @@ def _run(args) -> int:
     ann = cluster.AnnParams(eps=config.eps, low_dim=config.low_dim, n_probe=config.n_probe,
                             n_neighbors=config.n_neighbors, n_neighbors_ann=config.n_neighbors_ann,
                             mz_interval=config.mz_interval, min_mz=config.min_mz, max_mz=config.max_mz,
-                            rescore=config.rescore, clustering=config.clustering)
+                            rescore=config.rescore, clustering=config.clustering, dtype=config.dtype)
     rows_all, current_label, representatives = [], 0, []
     for charge in charges:                                                                     # falcon.py:153
         part = np.load(os.path.join(spectra_dir, f"spectra_charge_{charge}.npz"))     # plain arrays: no pickle

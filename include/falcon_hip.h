@@ -40,6 +40,8 @@ extern "C" {
 #define FAL_DTYPE_F32 0
 #define FAL_DTYPE_F16 1
 #define FAL_DTYPE_SPLIT16 2   /* per row: low_dim f16 'hi' = f16(x), then low_dim f16 'lo' = f16((x - hi) * 2048) */
+#define FAL_OUT_F32_F16   3   /* fal_vectorize_rows: float32 rows to `out` + their float16 rounding to `out2` (= fal_vectorize_pair) */
+#define FAL_OUT_F16_IMAGE 4   /* fal_vectorize_rows: float16 VECTORS to `out2` + their float32 image to `out` (= fal_vectorize_f16_image) */
 
 #define FAL_MAX_LOW_DIM   1024     /* multiple of 8 */
 #define FAL_MAX_K_ANN      256
@@ -118,6 +120,20 @@ int fal_vectorize_pair(fal_ctx* ctx, const float* mz, const float* intensity, co
 int fal_vectorize_f16_image(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
                             const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
                             uint32_t low_dim, uint32_t seed, int normalize, float* out_f32_image, void* out_f16);
+
+/* `--low_dim` is a free integer in the reference (README.md:114-117, config.py: "low_dim" of the nearest-neighbour options);
+ * the cosine kernels are instantiated for rows of 64, 128, 256, 400 and 800 columns.  fal_row_width: the row width the path
+ * stores `low_dim`-dimensional vectors in = the smallest of those widths >= low_dim (FAL_EUNSUPPORTED beyond 800) -- [host].
+ * fal_vectorize_rows: fal_vectorize / _pair / _f16_image (out_mode = FAL_DTYPE_* / FAL_OUT_*) with the hash taken modulo
+ * `low_dim` (any integer in [1, row_width]) and rows of `row_width` columns (a multiple of 8) whose columns >= low_dim are
+ * zero.  A zero column adds fma(0 * 0, acc) = acc to every k-ordered inner-product chain, so every kernel downstream runs at
+ * d = row_width unchanged and the similarities are those of the low_dim-dimensional vectors summed in the order of the
+ * row_width-wide chain (the oracle pads the same way). ---------------------------------------- [dev] */
+int fal_row_width(uint32_t low_dim, uint32_t* row_width);
+int fal_vectorize_rows(fal_ctx* ctx, const float* mz, const float* intensity, const int64_t* indptr,
+                       const int64_t* row_order, int64_t n, double min_mz, double bin_size, uint32_t n_bins,
+                       uint32_t low_dim, uint32_t row_width, uint32_t seed, int normalize, int out_mode,
+                       void* out, void* out2 /*second output of FAL_OUT_*, else NULL*/);
 
 /* ---- a5  precursor-m/z bucket boundaries: reference cluster.py:159-209
  *          `_get_precursor_mz_splits` over the m/z-SORTED float32 precursor array,

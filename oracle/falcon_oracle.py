@@ -124,15 +124,32 @@ def l2_normalize_rows(V: np.ndarray) -> np.ndarray:
     return out
 
 
+ROW_WIDTHS = (64, 128, 256, 400, 800)
+
+
+def row_width(low_dim: int) -> int:
+    """[build rule] `--low_dim` is a free integer (README.md:114-117); the path stores the vectors in rows of the next of
+    these widths, zero behind column low_dim.  A zero column adds fma(0 * 0, acc) = acc to a chain, so the padding changes no
+    value of the low_dim-dimensional inner product -- only the ORDER of its terms, which is that of the row_width-wide chain
+    (`sims_f32` with d = row_width)."""
+    for w in ROW_WIDTHS:
+        if 1 <= low_dim <= w:
+            return w
+    raise ValueError(f"low_dim must be in [1, {ROW_WIDTHS[-1]}] (got {low_dim})")
+
+
 def vectorize(mz: np.ndarray, intensity: np.ndarray, indptr: np.ndarray,
               min_mz: float, bin_size: float, n_bins: int, low_dim: int,
               seed: int = 0, norm: bool = True, row_order: Optional[np.ndarray] = None,
-              dtype=np.float32) -> np.ndarray:
-    """a2+a3: CSR peaks -> dense [n, low_dim] vectors (spectrum.py:202-247 with the
-    projection realised as feature hashing, README.md:124-131).
+              dtype=np.float32, width: Optional[int] = None) -> np.ndarray:
+    """a2+a3: CSR peaks -> dense [n, width] vectors (spectrum.py:202-247 with the
+    projection realised as feature hashing, README.md:124-131); `width` (default low_dim) >= low_dim
+    columns per row, zero behind low_dim.
 
     Peaks are added in peak order with float32 adds; peaks whose bin falls outside
     [0, n_bins) are ignored.  `row_order[r]` = input spectrum that becomes row r."""
+    width = low_dim if width is None else int(width)
+    assert width >= low_dim
     n = len(indptr) - 1
     if row_order is None:
         row_order = np.arange(n)
@@ -144,7 +161,7 @@ def vectorize(mz: np.ndarray, intensity: np.ndarray, indptr: np.ndarray,
     b = bin_indices(np.asarray(mz)[pos], min_mz, bin_size)
     ok = (b >= 0) & (b < n_bins)
     h = (murmurhash3_32(b[ok], seed) % np.uint32(low_dim)).astype(np.int64)
-    V = np.zeros((n, low_dim), f32)
+    V = np.zeros((n, width), f32)
     np.add.at(V, (rows[ok], h), np.asarray(intensity, f32)[pos][ok])   # ordered, unbuffered f32 adds
     if norm:
         V = l2_normalize_rows(V)
@@ -790,7 +807,7 @@ def generate_clusters(mz, intensity, indptr, precursor_mz, rt, *, eps=0.1, precu
     rts = None if rt is None else np.asarray(rt, f32)[order]
     n_bins, start, _ = get_dim(min_mz, max_mz, fragment_tol)
     X = vectorize(mz, intensity, indptr, start, fragment_tol, n_bins, low_dim, hash_seed,
-                  True, order, dtype)
+                  True, order, dtype, width=row_width(low_dim))
     splits = bucket_splits(mzs, tol, mode, batch_size, mz_interval)
     sim = np.full((N, n_neighbors_ann), -np.inf, f32)
     idx = np.full((N, n_neighbors_ann), -1, np.int32)

@@ -195,3 +195,44 @@ def test_main_hierarchical_clustering_option(tmp_path):
         pairs = np.unique(np.stack([ref, got]), axis=1)
         assert pairs.shape[1] == len(np.unique(ref)) == len(np.unique(got))          # the same partition
     assert (np.bincount(lab) > 1).sum() > 30
+
+
+@pytest.mark.parametrize("extra", [["--low_dim", "200"], ["--low_dim", "504"], ["--low_dim", "800"],
+                                   ["--low_dim", "800", "--dtype", "f16"], ["--low_dim", "333", "--dtype", "f16"]])
+def test_main_at_any_low_dim_and_dtype_labels_equal_the_oracle(tmp_path, extra):
+    """`--low_dim` is a free integer in the reference (README.md:114-117) and `main()` is the drop-in: low_dim 200 (rows of 256
+    columns), 504 and 800 in float32 (rows of 800 columns: the two-K-half passes of the fp32 matrix kernels), and BASELINE
+    configs[4]'s low_dim 800 float16 through `--dtype f16` -- the CSV's cluster column EQUALS the oracle's labels."""
+    from falcon_amd import synth
+    from falcon_amd.falcon import main
+    from falcon_amd.ms_io import ms_io
+    # a dense stretch (flat buckets of ~150 rows: the matrix kernels) + a sparse one (buckets of a few rows: exact chains)
+    parts = [synth.generate(4000, seed=6, mz_lo=500.0, mz_hi=520.0), synth.generate(1500, seed=7, mz_lo=700.0, mz_hi=900.0)]
+    specs = []
+    for k, d in enumerate(parts):
+        for i in range(len(d["precursor_mz"])):
+            a, b = d["indptr"][i], d["indptr"][i + 1]
+            specs.append({"identifier": f"scan={len(specs)}", "precursor_mz": float(d["precursor_mz"][i]),
+                          "precursor_charge": int(d["precursor_charge"][i]), "retention_time": float(d["retention_time"][i]),
+                          "mz": d["mz"][a:b].astype(np.float64), "intensity": d["intensity"][a:b]})
+    mgf = str(tmp_path / "in.mgf")
+    ms_io.write_spectra(mgf, specs)
+    out, work = str(tmp_path / "res"), tmp_path / "work"
+    assert main([mgf, out, "--eps", "0.1", "--work_dir", str(work)] + extra) == 0
+    opts = dict(zip(extra[::2], extra[1::2]))
+    low_dim, f16 = int(opts["--low_dim"]), opts.get("--dtype") == "f16"
+    lines = open(out + ".csv").read().splitlines()
+    assert f"# low_dim = {low_dim}" in lines and f"# dtype = {'f16' if f16 else 'f32'}" in lines
+    body = [l for l in lines if not l.startswith("#")]
+    table = {r[1]: (int(r[2]), int(r[5])) for r in (l.split(",") for l in body[1:])}
+    offset, n_seen = 0, 0
+    for charge in (2, 3):
+        z = np.load(work / "spectra" / f"spectra_charge_{charge}.npz")
+        ref, rmed = fo.generate_clusters(z["mz"], z["intensity"], z["indptr"], z["precursor_mz"], z["retention_time"], eps=0.1,
+                                         low_dim=low_dim, dtype=np.float16 if f16 else np.float32)
+        got = np.array([table[str(i)][1] for i in z["identifier"]])
+        assert np.array_equal(got - offset, ref), (charge, int((got - offset != ref).sum()))
+        offset += len(rmed)
+        n_seen += len(ref)
+        assert (np.bincount(ref) > 1).sum() > 50
+    assert n_seen == len(table)

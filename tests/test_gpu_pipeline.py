@@ -45,7 +45,8 @@ def _check_stages(ctx, d, ds, tol, mode, rt_tol, batch_size, p, pipe=None):
     assert np.array_equal(L["splits"], fo.bucket_splits(mzs, tol, mode, batch_size, p.mz_interval))
     # a1-a3 vectors, bit-exact
     nb, start, _ = fo.get_dim(p.min_mz, p.max_mz, 0.05)
-    X = fo.vectorize(d["mz"], d["intensity"], d["indptr"], start, 0.05, nb, p.low_dim, p.hash_seed, True, order)
+    X = fo.vectorize(d["mz"], d["intensity"], d["indptr"], start, 0.05, nb, p.low_dim, p.hash_seed, True, order,
+                     width=fo.row_width(p.low_dim))           # (rows are stored row_width(low_dim) columns wide, zero behind low_dim)
     assert np.array_equal(L["X"], X)
     # a6/a7 on the GPU's own index
     cent, asg, perm, loff = [t.cpu().numpy() for t in pipe.last["index"].export()]

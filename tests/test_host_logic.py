@@ -306,3 +306,38 @@ def test_spectrum_dataset_knows_where_its_columns_live():
     assert up.retention_time is None
     assert [t.dtype for t in (up.precursor_mz, up.mz, up.intensity, up.indptr)] == [torch.float32] * 3 + [torch.int64]
     assert torch.equal(up.indptr, torch.from_numpy(cols[4])) and torch.equal(up.mz, torch.from_numpy(cols[2]))
+
+
+def test_low_dim_is_a_free_integer_rows_are_padded_to_an_instantiated_width(tmp_path):
+    """README.md:114-117: `--low_dim` is any integer; the path stores the rows `row_width(low_dim)` columns wide (64 / 128 / 256 /
+    400 / 800).  Oracle side of the rule: the padded columns are zero, the first low_dim columns are the unpadded vectors bit
+    for bit (same adds, same norm tree), and the k-ordered similarities of padded rows stay within 1e-6 of the unpadded ones
+    (same terms, another order).  `--dtype` reaches the parser, the INI layer and rejects unknown values."""
+    from falcon_amd import synth
+    from falcon_amd.config import Config
+    assert [fo.row_width(x) for x in (1, 64, 65, 200, 256, 257, 400, 401, 504, 800)] == [64, 64, 128, 256, 256, 400, 400, 800, 800, 800]
+    with pytest.raises(ValueError):
+        fo.row_width(801)
+    d = synth.generate(600, seed=3)
+    nb, start, _ = fo.get_dim(101.0, 1500.0, 0.05)
+    for low_dim in (7, 200, 504):
+        W = fo.row_width(low_dim)
+        plain = fo.vectorize(d["mz"], d["intensity"], d["indptr"], start, 0.05, nb, low_dim)
+        padded = fo.vectorize(d["mz"], d["intensity"], d["indptr"], start, 0.05, nb, low_dim, width=W)
+        assert padded.shape == (600, W) and not padded[:, low_dim:].any() and np.array_equal(padded[:, :low_dim], plain)
+        if low_dim % 2 == 0:
+            np.testing.assert_allclose(fo.sims_f32(padded[:50], padded[:200]), fo.sims_f32(plain[:50], plain[:200]), atol=1e-6, rtol=0)
+    c = Config()
+    c.parse("in.mgf out --low_dim 504 --dtype f16")
+    assert c.low_dim == 504 and c.dtype == "f16"
+    c.parse("in.mgf out")
+    assert c.low_dim == 400 and c.dtype == "f32"
+    ini = tmp_path / "c.ini"
+    ini.write_text("low_dim = 200\ndtype = f16\n")
+    c.parse(f"in.mgf out -c {ini}")
+    assert c.low_dim == 200 and c.dtype == "f16"
+    with pytest.raises(SystemExit):
+        c.parse("in.mgf out --dtype bf16")
+    for bad in ("0", "801"):
+        with pytest.raises(ValueError):
+            c.parse(f"in.mgf out --low_dim {bad}")
