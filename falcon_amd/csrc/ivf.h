@@ -58,6 +58,10 @@ struct fal_ivf {
     // column 0xFFFF = unused entry, 0xFFFE in entry 0 = more than 64 non-zeros, use the dense row); owned
     uint16_t* sp_cols = nullptr;
     float* sp_vals = nullptr;
+    // the same rows as the 256-byte query records of list16s_kernel: [n][64 x u16 column | 64 x f16 value] (made when the build was
+    // given float16 rows); owned.  rows_many = 1: some row has more than 64 non-zeros -- the dense-gather scan then serves the index
+    uint16_t* sq16 = nullptr;
+    int rows_many = 0;
     int64_t* list_off = nullptr;     // [total_lists + 1] list-order positions
     int64_t* counts = nullptr;       // [total_lists + 1] list sizes (flat buckets)
     void* bk_dev = nullptr;          // BucketDev[n_ivf_buckets]

@@ -66,7 +66,7 @@ __device__ __forceinline__ double wave_xor_sum_d(double v) {
 __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restrict__ X, int d, const BucketDev* __restrict__ bk,
                                                             const int64_t* __restrict__ seg_off, int nb,
                                                             uint16_t* __restrict__ cols, float* __restrict__ vals,
-                                                            int32_t* __restrict__ neg_flag) {
+                                                            uint16_t* __restrict__ sq16, int32_t* __restrict__ neg_flag) {
     __shared__ uint16_t sc[4][kSparseW];
     __shared__ float sv[4][kSparseW];
     int lo = 0, hi = nb - 1;
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
     const int r_first = (int)(blockIdx.x - seg_off[lo]) * 256;
     const int r_end = min(b.n, r_first + 256);
     bool neg = false;            // a component that is negative or not finite: the float16 prefilters' error bound needs rows >= 0
+    bool many = false;           // a row with more than kSparseW non-zero components (kept dense: list16s_kernel cannot take the index)
     bool wide = false;           // a component that is not a float16 value (float16 VECTORS, config 5: none -- pairs16.hip then keeps
                                  // its query tile in LDS as float16, exactly)
     for (int rl = r_first + w; rl < r_end; rl += 4) {
@@ -122,11 +123,19 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
             base += tot;
         }
         if (base > kSparseW && lane == 0) sc[w][0] = kColDense;
+        many |= base > kSparseW;
         cols[r * kSparseW + lane] = sc[w][lane];
         vals[r * kSparseW + lane] = sv[w][lane];
+        if (sq16) {
+            // the row as the query record of list16s_kernel: 64 columns, then the 64 values rounded to float16 (the float16 row's
+            // own components: vectorize.hip rounds the same float32 values the same way) -- 256 contiguous bytes
+            sq16[r * (2 * kSparseW) + lane] = sc[w][lane];
+            sq16[r * (2 * kSparseW) + kSparseW + lane] = __half_as_ushort(__float2half_rn(sv[w][lane]));
+        }
     }
     if (__ballot(neg) != 0ull && lane == 0) atomicOr(neg_flag, 1);
     if (__ballot(wide) != 0ull && lane == 0) atomicOr(neg_flag + 1, 1);
+    if (__ballot(many) != 0ull && lane == 0) atomicOr(neg_flag + 2, 1);
 }
 
 // global list of every sorted row (bucket by binary search on the bucket table) = the key of the stable sort by list
@@ -407,7 +416,7 @@ int fal_ivf_destroy(fal_ivf* ivf) {
     fal::CallScope _call(ivf ? ivf->ctx : nullptr);
     if (!ivf) return FAL_OK;
     void* ptrs[] = {ivf->Xl_owned, ivf->centroids, ivf->assign, ivf->perm, ivf->list_off, ivf->counts, ivf->bk_dev,
-                    ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals, ivf->neg_dev};
+                    ivf->pos_of_row, ivf->ckeys, ivf->sp_cols, ivf->sp_vals, ivf->sq16, ivf->neg_dev};
     for (void* p : ptrs)
         if (p && ivf->ctx) ivf->ctx->pool_free(p);     // recycled in stream order, no device sync
     delete ivf;
@@ -596,10 +605,10 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             }
             int64_t* seg_dev = nullptr;
             void* sortbuf = nullptr;
-            B_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (seg_off.size() + 1), (void**)&seg_dev));
+            B_TRY(ctx->reserve(SLOT_MISC, sizeof(int64_t) * (seg_off.size() + 2), (void**)&seg_dev));
             B_TRY(ctx->upload(seg_dev, seg_off.data(), sizeof(int64_t) * seg_off.size()));
             int32_t* neg_dev = reinterpret_cast<int32_t*>(seg_dev + seg_off.size());
-            B_HIP(hipMemsetAsync(neg_dev, 0, sizeof(int64_t), st));
+            B_HIP(hipMemsetAsync(neg_dev, 0, 2 * sizeof(int64_t), st));
             B_TRY(ctx->reserve(SLOT_MISC2, sizeof(int64_t) * tab.size(), (void**)&boff_dev));
             B_TRY(ctx->upload(boff_dev, tab.data(), sizeof(int64_t) * tab.size()));
             lbase_dev = boff_dev + n_buckets + 1;
@@ -607,6 +616,9 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             B_TRY(ctx->pool_alloc(sizeof(float) * (size_t)n * kSparseW, (void**)&ivf->sp_vals));
             sp_cols = ivf->sp_cols;
             sp_vals = ivf->sp_vals;
+            // (with float16 rows at hand the searches may run the float16 list scan: its queries arrive as 256-byte sparse records)
+            // (rows of up to 400 columns: at 800 the dense gather is the faster form, list16s.hip)
+            if (X16 != nullptr && low_dim <= 400) B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * 2 * kSparseW, (void**)&ivf->sq16));
             B_TRY(ctx->reserve(SLOT_SORT2, 3 * sizeof(uint32_t) * (size_t)n, &sortbuf));
             key_in = (uint32_t*)sortbuf;
             key_out = key_in + n;
@@ -614,7 +626,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             {
                 StageScope ts(ctx, ST_BUILD);
                 hipLaunchKernelGGL(sparsify_rows_kernel, dim3((unsigned)seg_off.back()), dim3(256), 0, st, X, low_dim, bkd, seg_dev,
-                                   nbk, sp_cols, sp_vals, neg_dev);
+                                   nbk, sp_cols, sp_vals, ivf->sq16, neg_dev);
                 B_HIP(hipGetLastError());
                 hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, st, iota, n);
                 B_HIP(hipGetLastError());
@@ -622,10 +634,11 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
             // the one synchronisation of the build (only when float16 rows were handed in: ~20 us of an empty queue against the
             // tens of ms of the k-means passes that follow)
             if (X16 != nullptr) {
-                B_HIP(hipMemcpyAsync(ctx->fb_host + 6, neg_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                B_HIP(hipMemcpyAsync(ctx->fb_host + 6, neg_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
                 B_HIP(hipStreamSynchronize(st));
                 ivf->rows_signed = ctx->fb_host[6] != 0 ? 1 : 0;
                 ivf->rows_f16 = ctx->fb_host[7] == 0 ? 1 : 0;
+                ivf->rows_many = ctx->fb_host[8] != 0 ? 1 : 0;
                 ctx->counters[6] |= ivf->rows_signed;
             } else {
                 ivf->rows_signed = -1;        // not known on the host yet: fal_ivf_attach_prefilter_ex reads it if it needs it

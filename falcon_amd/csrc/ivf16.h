@@ -10,6 +10,8 @@ namespace fal {
 
 struct List16Args {              // cf. ListScanArgs (scan.h); tiles = groups of four 32-row list slices
     const __half* X16;           // float16 rows in sorted-row order
+    const uint16_t* sq16;        // optional [n][64 x u16 column | 64 x f16 value]: the rows' sparse records (ivf.h) -- the queries are then
+                                 // gathered as these 256 bytes and expanded in LDS (list16s.hip) instead of as dense rows
     const int32_t* perm;         // [n] list-order position -> sorted row (the resident rows of a list)
     int d;
     const int64_t* list_off;
@@ -76,6 +78,7 @@ int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32
 int launch_pos_of_row(fal_ctx* ctx, const int32_t* perm, int64_t n, int32_t* pos_of_row);
 int launch_list16(fal_ctx* ctx, const List16Args& a);
 int launch_list16r(fal_ctx* ctx, const List16Args& a);      // list16r.hip (called by launch_list16)
+int launch_list16s(fal_ctx* ctx, const List16Args& a);      // list16s.hip (called by launch_list16)
 int launch_select16(fal_ctx* ctx, const Select16Args& a, int64_t n_tiles);
 
 }  // namespace fal

@@ -579,9 +579,10 @@ int launch_pos_of_row(fal_ctx* ctx, const int32_t* perm, int64_t n, int32_t* pos
 // (tests/test_gpu_ivf16.py); measured SLOWER (profiles/NOTES.md r5: both forms issue ~900 instructions per 32-query chunk
 // for its 65 MFMAs, and the lockstep form runs them on two waves per SIMD), so the lockstep form stays the default.  Read at
 // every launch: tests and tools/list16_ab.py switch it inside one process.
+// FALCON_LIST16 = "d": the dense-gather form even where the sparse records exist (list16s.hip is the default then: A/B switch)
 static int list16_form() {
     const char* e = getenv("FALCON_LIST16");
-    return (e && !strcmp(e, "r")) ? 1 : 0;
+    return (e && !strcmp(e, "r")) ? 1 : (e && !strcmp(e, "d")) ? 2 : 0;
 }
 
 int launch_list16(fal_ctx* ctx, const List16Args& a_in) {
@@ -593,6 +594,7 @@ int launch_list16(fal_ctx* ctx, const List16Args& a_in) {
     StageScope ts(ctx, ST_SCAN);
     StageScope tk(ctx, ST_KERNEL);
     if (a.d <= 400 && list16_form() == 1) return launch_list16r(ctx, a);
+    if (a.sq16 != nullptr && a.d <= 400 && list16_form() == 0) return launch_list16s(ctx, a);      // (measured slower at 800 columns)
     switch (a.d / 16) {
         case 4: hipLaunchKernelGGL((list16_kernel<4>), grid, block, 0, ctx->stream, a); break;
         case 8: hipLaunchKernelGGL((list16_kernel<8>), grid, block, 0, ctx->stream, a); break;

@@ -732,7 +732,9 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             const int64_t L0 = first.c_row0, L1 = last.c_row0 + last.nc;
             const int64_t base = qoff[(size_t)t0];
             List16Args la{};
-            la.X16 = reinterpret_cast<const __half*>(ivf->X16pre); la.perm = ivf->perm; la.d = d; la.list_off = ivf->list_off; la.inv_off = inv_off;
+            la.X16 = reinterpret_cast<const __half*>(ivf->X16pre); la.perm = ivf->perm;
+            la.sq16 = ivf->rows_many ? nullptr : ivf->sq16;      // (queries as 256-byte sparse records: list16s.hip)
+            la.d = d; la.list_off = ivf->list_off; la.inv_off = inv_off;
             la.ltile_off = ltile_off; la.inv_row = inv_row; la.inv_dest = inv_dest; la.list_begin = L0; la.list_end = L1;
             la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
             la.keys = keys; la.keys_base = base; la.sink = keys + need_fine; la.n_rows = ivf->n;

@@ -298,3 +298,88 @@ def test_pipeline_with_and_without_ivf_prefilter_is_identical(ctx):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
     assert outs[0][4] < 0.02 * len(ds)                        # few queries needed the exact fallback
+
+
+def _rows_of_at_most_64_nonzeros(n, d, seed, nnz_lo=5, nnz_hi=50):
+    """rows shaped like vectorised spectra, NONE with more than 64 non-zeros (the precondition of list16s_kernel: an index with a
+    wider row keeps the dense gather); near-duplicates in groups, rows with exactly 64 entries, all-zero rows"""
+    rng = np.random.default_rng(seed)
+    n_groups = max(1, n // 12)
+    proto = np.zeros((n_groups, d), np.float32)
+    for g in range(n_groups):
+        c = rng.choice(d, rng.integers(nnz_lo, min(nnz_hi, d // 2) + 1), replace=False)
+        proto[g, c] = rng.random(len(c)).astype(np.float32) + 0.05
+    X = proto[rng.integers(0, n_groups, n)].copy()
+    X *= np.abs(1.0 + 0.3 * rng.standard_normal(X.shape).astype(np.float32)) * (X != 0)
+    if d >= 64:
+        for r in rng.choice(n, max(4, n // 100), replace=False):       # rows that fill the record: exactly 64 entries
+            X[r] = 0
+            X[r, rng.choice(d, 64, replace=False)] = rng.random(64).astype(np.float32) + 0.01
+    nrm = np.sqrt((X.astype(np.float64) ** 2).sum(1))
+    X = (X / np.maximum(nrm, 1e-30)[:, None]).astype(np.float32)
+    X[rng.choice(n, 5, replace=False)] = 0
+    assert (X != 0).sum(1).max() <= 64
+    return X
+
+
+@pytest.mark.parametrize("d,n_probe,k_ann,keep,tol,mode,rt_tol", [
+    (400, 16, 128, 64, 20.0, "ppm", None), (400, 8, 32, 8, 0.05, "Da", 30.0), (800, 16, 128, 64, 20.0, "ppm", None),
+    (256, 12, 100, 50, 20.0, "ppm", None), (128, 16, 64, 16, 20.0, "ppm", None), (64, 4, 32, 16, 60.0, "ppm", None),
+])
+def test_list16s_sparse_query_records_give_the_staged_lists(ctx, monkeypatch, d, n_probe, k_ann, keep, tol, mode, rt_tol):
+    """list16s_kernel (list16s.hip): the probing queries gathered as their 256-byte sparse records and expanded in LDS -- the form
+    the production path takes whenever the build had float16 rows (the records are made beside the sparse rows) and no row holds
+    more than 64 non-zeros.  Neighbour lists == the staged path's, bit for bit, and == the dense-gather form's (FALCON_LIST16=d);
+    lists of 1 to 4 slices, lists of more than 128 rows, probe streams of one and two chunks, exact duplicates, all-zero rows."""
+    import torch
+    sizes = [6000, 300, 2500, 9000, 40, 1300, 5000, 150]
+    nl = np.array([64, 1, 32, 128, 1, 16, 32, 2], np.int32)
+    off, _, mz, rt = _buckets(sizes, d, 41)
+    X = _rows_of_at_most_64_nonzeros(int(off[-1]), d, 43)
+    X[off[3] + 10:off[3] + 16] = X[off[3] + 10]
+    rt_u = rt if rt_tol is not None else None
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    x16 = Xd.to(torch.float16).contiguous()
+    mz_d = torch.from_numpy(mz).to(ctx.tdev)
+    rt_d = None if rt_u is None else torch.from_numpy(rt_u).to(ctx.tdev)
+    # (the exact float32 assignment kernels end at 512 columns: at 800 the reference index is built with the float16 assignment
+    #  too -- the same index by construction, tests/test_gpu_search.py -- and searched with the staged float32 kernels)
+    plain = ctx.ivf_build(Xd, off, nl, Xkm=x16 if d > 512 else None)
+    sim, idx = plain.search(n_probe, k_ann)
+    e_idx, e_dist = ctx.filter_neighbors(sim, idx, mz_d, rt_d, tol, mode, rt_tol, keep)
+    out = {}
+    for form in ("s", "d"):
+        if form == "d":
+            monkeypatch.setenv("FALCON_LIST16", "d")
+        pre = ctx.ivf_build(Xd, off, nl, Xpre=x16, Xkm=x16, prefilter_which=2)       # (Xkm: the build sees float16 rows -> records)
+        g_idx, g_dist = pre.search_neighbors(n_probe, k_ann, mz_d, rt_d, tol, mode, rt_tol, keep)
+        ctx.sync()
+        assert ctx.counter(6) == 0
+        out[form] = (g_idx.cpu().numpy(), g_dist.cpu().numpy(), ctx.counter(5))
+    e_idx, e_dist = e_idx.cpu().numpy(), e_dist.cpu().numpy()
+    for form, (gi, gd, n_fb) in out.items():
+        bad = np.flatnonzero((gi != e_idx).any(1) | (gd.view(np.uint32) != e_dist.view(np.uint32)).any(1))
+        assert len(bad) == 0, (form, len(bad), bad[:10])
+        assert n_fb < 0.05 * off[-1], (form, n_fb)
+    assert out["s"][2] == out["d"][2]                 # the same keys -> the same queries took the exact fallback
+    assert (e_idx >= 0).sum() > off[-1] // 8
+
+
+def test_an_index_with_a_row_of_more_than_64_nonzeros_keeps_the_dense_gather(ctx):
+    """the sparse records hold 64 entries: one wider row in an indexed bucket and the searches of that index gather dense rows
+    (list16_kernel) -- same lists as the staged path"""
+    sizes = [6000, 2500]
+    nl = np.array([64, 32], np.int32)
+    off, _, mz, rt = _buckets(sizes, 400, 45)
+    X = sparse_unit_vectors(int(off[-1]), 400, 47)          # (holds rows of 65..160 non-zeros)
+    assert (X != 0).sum(1).max() > 64
+    import torch
+    Xd = torch.from_numpy(X).to(ctx.tdev)
+    x16 = Xd.to(torch.float16).contiguous()
+    mz_d = torch.from_numpy(mz).to(ctx.tdev)
+    plain = ctx.ivf_build(Xd, off, nl)
+    sim, idx = plain.search(16, 128)
+    e_idx, e_dist = ctx.filter_neighbors(sim, idx, mz_d, None, 20.0, "ppm", None, 64)
+    pre = ctx.ivf_build(Xd, off, nl, Xpre=x16, Xkm=x16, prefilter_which=2)
+    g_idx, g_dist = pre.search_neighbors(16, 128, mz_d, None, 20.0, "ppm", None, 64)
+    assert torch.equal(g_idx, e_idx) and torch.equal(g_dist.view(torch.int32), e_dist.view(torch.int32))

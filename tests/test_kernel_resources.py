@@ -31,6 +31,7 @@ def asm_dir(tmp_path_factory):
     ("scan16.hip", "scan16_kernel", 10),
     ("ivf_fine.hip", "ivf_list4_kernel", 7),   # DH4 in {8,16,32,50,64} + the two K-half passes
     ("ivf16.hip", "list16_kernel", 5),
+    ("list16s.hip", "list16s_kernel", 5),
     ("assign.hip", "assign_kernel", 5),
     ("assign.hip", "assign_wave_kernel", 5),
 ])
@@ -52,7 +53,7 @@ def _dma_sources():
 
 
 def test_dma_sources_are_the_known_ones():
-    assert _dma_sources() == ["assign.hip", "ivf16.hip", "ivf_fine.hip", "scan.hip"]
+    assert _dma_sources() == ["assign.hip", "ivf16.hip", "ivf_fine.hip", "list16s.hip", "scan.hip"]
 
 
 @pytest.mark.parametrize("src", _dma_sources())
@@ -130,4 +131,19 @@ def test_list16_vm_operation_counts_match_the_hand_counted_waits(asm_dir, steps,
     for dma, stores, mfma in runs:
         assert mfma == steps, (dma, stores, mfma)
         assert dma == row_ops + 1, f"DMAs per step changed (kRowOps + 1 = {row_ops + 1}): {(dma, stores, mfma)}"
+        assert stores in (16, 32), f"key stores per step changed: {(dma, stores, mfma)}"
+
+
+@pytest.mark.parametrize("steps", [4, 8, 16, 25, 50])
+def test_list16s_vm_operation_counts_match_the_hand_counted_waits(asm_dir, steps):
+    """list16s.hip: per step and wave 2 record DMAs + 1 metadata DMA and 16 key stores; the steps' vmcnt allowances are built from
+    exactly these"""
+    asm = L.compile_to_asm("list16s.hip", asm_dir)
+    name, body = next((k, b) for k, b in L.kernels(asm).items() if f"list16s_kernelILi{steps}E" in k)
+    assert L.kernel_meta(asm, "private_segment_fixed_size")[name] == 0
+    runs = [r for r in L.vm_ops_between_barriers(body) if r[2] > 0]
+    assert runs, "no MFMA stretch found"
+    for dma, stores, mfma in runs:
+        assert mfma == steps, (dma, stores, mfma)
+        assert dma == 3, f"DMAs per step changed (2 records + 1 metadata): {(dma, stores, mfma)}"
         assert stores in (16, 32), f"key stores per step changed: {(dma, stores, mfma)}"

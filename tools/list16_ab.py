@@ -1,4 +1,5 @@
-"""A/B of the two forms of the indexed fine scan (FALCON_LIST16 unset: list16_kernel, lockstep | "r": list16r_kernel) on one GPU: the same
+"""A/B of the forms of the indexed fine scan (FALCON_LIST16 unset: the default -- list16s_kernel, sparse query records, since round 6 | "d":
+list16_kernel, dense query rows | "r": list16r_kernel; FALCON_AB_FORMS=lockstep,d picks the forms, "lockstep" = unset) on one GPU: the same
 dataset, serial staged passes in turn (HIP events around every stage), labels compared.
 
     python tools/list16_ab.py [spectra] [mz_lo] [mz_hi] [n_probe] [rounds]
@@ -23,7 +24,8 @@ for ch in (2, 3):
     c = synth.select_charge_device(data, ch)
     parts.append(SpectrumDataset(c["precursor_mz"], c["retention_time"], c["mz"], c["intensity"], c["indptr"]))
 del data
-args = (20.0, "ppm", None, 0.05, 2 ** 15, AnnParams(n_probe=n_probe))
+args = (20.0, "ppm", None, 0.05, 2 ** 15, AnnParams(n_probe=n_probe, low_dim=int(os.environ.get("FALCON_AB_LOW_DIM", "400")),
+                                                    dtype=os.environ.get("FALCON_AB_DTYPE", "f32")))
 pipe = ClusterPipeline(ctx)
 STAGES = ("vectorize", "build", "coarse", "scan", "select", "filter", "dbscan", "tail", "kernel")
 
