@@ -194,15 +194,17 @@ def main():
                          "payload all-gather over RCCL) with synthetic ragged payloads on the N ranks, verify every rank's received "
                          "bytes, print one JSON line and exit (0 = ok)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true",
+                    help="skip the cold-pass measurement (tools/cold_pass.py in fresh child processes, before this process touches the GPU)")
     ap.add_argument("--no-configs", action="store_true", help="skip the 10 M / 50 M configurations of the `configs` array")
     ap.add_argument("--configs-spectra", type=int, default=10_000_000)
     ap.add_argument("--big-spectra", type=int, default=50_000_000,
                     help="BASELINE configs[3] at its own size (n_probe 32, n_neighbors_ann 128), run in --big-chunks bucket shares "
                          "(ClusterPipeline.run_chunked); 0 = skip")
-    ap.add_argument("--big-chunks", type=int, default=4,
+    ap.add_argument("--big-chunks", type=int, default=2,
                     help="bucket shares of the 50 M configuration (measured alone in a process: 2 shares 962 ms, 3 shares 978, 4 shares "
-                         "992 per pass; behind the other configurations of a default run -- whose scratch pools stay with their "
-                         "contexts -- 2 shares run out of device memory, so the default stays 4)")
+                         "992 per pass).  Round 6: the contexts' scratch pools are trimmed between the configurations (fal_ctx_trim), so the "
+                         "2 shares fit inside a default run too; if they do not, the entry falls back to 4 shares and says so")
     ap.add_argument("--skew-spectra", type=int, default=2_000_000,
                     help="the skewed-workload entry of `configs` (synth skew=True: log-normal window occupancy, 5..50 peaks); 0 = skip")
     ap.add_argument("--partitions", choices=["auto", "concurrent", "pipelined"], default="auto",
@@ -214,6 +216,21 @@ def main():
                     help="run the charge partitions strictly one after the other (default: software-pipelined, "
                          "ClusterPipeline.run_many)")
     args = ap.parse_args()
+
+    # ---- what falcon.main() pays: ONE pass per charge in a fresh process.  Measured in fresh child processes BEFORE this process
+    # touches the GPU (tools/cold_pass.py: library load, first pass incl. fal_ctx_plan, the following passes) -----------------
+    cold = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cold and not args.exchange_only:
+        import subprocess
+        cold = {}
+        for n_cold in (1_000_000, 10_000_000):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_pass.py"), str(n_cold), "--passes", "4"],
+                                   capture_output=True, text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                cold[str(n_cold)] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:                                # pragma: no cover -- reported, never hidden
+                cold[str(n_cold)] = {"error": repr(e)[:300]}
 
     import torch
     import torch.distributed as dist
@@ -522,6 +539,11 @@ def main():
         del slots
         del pinned, nxt, cur
 
+    def fo_steps(low_dim):
+        """MFMA steps of the float16 list scan = padded row width / 16"""
+        from falcon_amd.device import row_width
+        return row_width(low_dim) // 16
+
     def summarize(stages, d, p, elem):
         pairs = sum(s["pairs"] for s in stages)
         ms = {k: round(sum(s[k][0] for s in stages), 3) for k in STAGES + ("kernel",)}
@@ -579,6 +601,9 @@ def main():
         torch.cuda.empty_cache()
         was_concurrent = concurrent["on"]
         plan = [("f32", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 1200.0, 1, args.batch_size),
+                # `--low_dim` is a free integer (README.md:114-117): 200 runs on rows padded to 256 columns -- next to 256 itself
+                ("f32-d200", args.configs_spectra, dict(low_dim=200, dtype="f32", scan="f32"), 1200.0, 1, args.batch_size),
+                ("f32-d256", args.configs_spectra, dict(low_dim=256, dtype="f32", scan="f32"), 1200.0, 1, args.batch_size),
                 ("f16", args.configs_spectra, dict(low_dim=800, dtype="f16", scan="f32"), 1200.0, 1, args.batch_size),
                 # BASELINE configs[3]'s bucket regime on one GPU: the same number of spectra in a quarter of the precursor
                 # range (buckets of 20-35 k rows: n_list 512) with that config's n_probe = 32
@@ -598,6 +623,7 @@ def main():
         big, big_key = None, None
         for name, n_cfg, kw, hi, chunks, batch in plan:
             skew = name == "f32-skew"
+            chunks_note = None
             if big_key != (n_cfg, hi, skew):
                 del big
                 torch.cuda.empty_cache()
@@ -605,11 +631,25 @@ def main():
                 big_key = (n_cfg, hi, skew)
             pc = params(**kw)
             ra = (20.0, "ppm", None, 0.05, batch, pc)
+            # the scratch of the previous configuration goes back to the driver (fal_ctx_trim): every entry starts from the
+            # pools a fresh process would have, and the 50 M job has the device to itself
+            if runner is not None:
+                runner.trim()
+            pipe.trim()
             # (five timed steps after three priming passes: with three a single late scratch growth -- a GB-sized hipMalloc of
             #  one of the two partition contexts -- showed up as + 40 ms on the mean of a 120 ms step)
             steps_c = 5 if chunks == 1 else 3
             try:
-                dtc = timed(big, ra, steps_c, 1, prime=3 if chunks == 1 else 2, chunks=chunks)
+                try:
+                    dtc = timed(big, ra, steps_c, 1, prime=3 if chunks == 1 else 2, chunks=chunks)
+                except Exception as e:
+                    if chunks != 2 or "memory" not in repr(e).lower():
+                        raise
+                    chunks_note = f"2 shares ran out of device memory ({repr(e)[:120]}); ran in 4"
+                    runner.trim()
+                    pipe.trim()
+                    chunks = 4
+                    dtc = timed(big, ra, steps_c, 1, prime=2, chunks=chunks)
                 if chunks == 1:
                     sc = summarize(staged(big, ra), pc.low_dim, pc, 2 if name == "f16" else 4)
                 else:                                             # one bucket share of the chunked job, its own staged pass
@@ -624,6 +664,8 @@ def main():
                             f"n_probe={pc.n_probe}, eps={pc.eps}, precursor_tol=20ppm, mz_interval={pc.mz_interval}, batch_size={batch}"
                             + (f", precursor buckets in {chunks} shares run one after the other" if chunks > 1 else ""),
                 "baseline_config": {"f32": "configs[2] dataset on one GPU", "f16": "configs[4]",
+                                    "f32-d200": "configs[2] dataset on one GPU at --low_dim 200 (rows padded to 256 columns)",
+                                    "f32-d256": "configs[2] dataset on one GPU at --low_dim 256",
                                     "f32-dense": "configs[3] regime (n_list 512, n_probe 32, n_neighbors_ann 128) at one GPU's size: "
                                                  "precursors in 400-600 m/z",
                                     "f32-b64k": "SURVEY 8d's C4 row as written (43,750-row buckets, n_list 1,024, n_probe 32) at one "
@@ -633,11 +675,13 @@ def main():
                                     "f32-50M": "configs[3] (50 M spectra, n_probe 32, n_neighbors_ann 128) at its own size"}[name],
                 "steps": steps_c, "ms_per_step": dtc / steps_c * 1e3, "value": n_big * steps_c / dtc, "unit": "spectra/s",
                 "dtype": name.split("-")[0]}
+            if chunks_note:
+                entry["shares_note"] = chunks_note
             if chunks > 1:
                 entry["staged_share"] = {"what": f"share 0 of {chunks} (the deal run_chunked executes), serial staged pass",
                                          "spectra": sc["n_rows"], "stage_ms": sc["stage_ms"], "pairs": sc["pairs"]}
                 entry["roofline"] = roofline_of(
-                    sc, "list16_kernel<25> (f16 MFMA 32x32x16, list-major), one bucket share of the 50 M job", PEAK_MFMA_F16_TFLOPS,
+                    sc, "list16s_kernel<25> (f16 MFMA 32x32x16, list-major), one bucket share of the 50 M job", PEAK_MFMA_F16_TFLOPS,
                     "f16 MFMA 2.5 PFLOP/s dense", None,
                     note="work and launches of ONE of the job's bucket shares (its own serial staged pass)")
             elif sc is not None:
@@ -655,9 +699,10 @@ def main():
                                                     PEAK_MFMA_F32_TFLOPS, "fp32 MFMA 157.3 TFLOP/s", None)
                 else:
                     entry["roofline"] = roofline_of(
-                        sc, "list16_kernel<25> (f16 MFMA 32x32x16, list-major: <= 128 rows of a list resident, the queries probing it "
-                            "stream through LDS)", PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense",
-                        {"f32": "10M_f32", "f32-dense": "10M_f32_dense", "f32-b64k": "10M_f32_b64k", "f32-skew": None}[name],
+                        sc, f"list16s_kernel<{fo_steps(pc.low_dim)}> (f16 MFMA 32x32x16, list-major: <= 128 rows of a list resident, the queries "
+                            "probing it arrive as 256-byte sparse records and are expanded in LDS)", PEAK_MFMA_F16_TFLOPS,
+                        "f16 MFMA 2.5 PFLOP/s dense",
+                        {"f32": "10M_f32", "f32-dense": "10M_f32_dense", "f32-b64k": "10M_f32_b64k"}.get(name),
                         note="the kernel scans every probed (query, candidate) pair on the f16 matrix cores to 16-bit keys; the exact "
                              "float32 work (pair chains, k-th key resolution: stages scan / select) is in scan_plus_topk")
                 entry["prefilter_fallback_rows"] = int(ctx.counter(5))
@@ -688,7 +733,7 @@ def main():
                                PEAK_MFMA_F16_TFLOPS, "f16 MFMA 2.5 PFLOP/s dense", None,
                                issued_factor=3.0 if (args.scan == "f16x3" and args.dtype == "f32") else 1.0)
         elif ivf_regime and not args.no_ivf_prefilter:
-            roof = roofline_of(s, "list16_kernel<25> (f16 MFMA 32x32x16, list-major)", PEAK_MFMA_F16_TFLOPS,
+            roof = roofline_of(s, "list16s_kernel<25> (f16 MFMA 32x32x16, list-major)", PEAK_MFMA_F16_TFLOPS,
                                "f16 MFMA 2.5 PFLOP/s dense", "10M_f32" if n_total == 10_000_000 and world == 1 else None)
         else:
             default = (n_total == 1_000_000 and world == 1 and d == 400 and args.n_neighbors_ann == 128 and args.mz_interval == 1.0
@@ -759,6 +804,16 @@ def main():
                                  "partition's kernels start when its own bytes have arrived: PartitionRunner.run on host columns; one "
                                  "stream: upload, then compute); `value_host_to_host_pipelined` = a stream of datasets, the next upload under the current "
                                  "step's kernels")
+        if cold is not None:
+            # `cold_ms`: the first pass of a fresh process (what falcon.main() runs per charge: reference falcon.py:153-193) next to
+            # the steady-state `ms_per_step`; the child process's own later passes are its steady state (no priming beyond them)
+            out["cold_pass"] = {"what": "tools/cold_pass.py in a fresh child process per size: pass_ms[0] = the first pass of a fresh "
+                                        "process (kernels' code objects, scratch, torch's allocator all cold; it calls fal_ctx_plan "
+                                        "itself), pass_ms[1:] = the passes behind it; lib_load_ms = dlopen + symbol binding",
+                                **cold}
+            c1 = cold.get(str(n_total)) or {}
+            if "pass_ms" in c1:
+                out["cold_ms"] = c1["pass_ms"][0]
         if strong_extra is not None:
             out["strong_scaling"] = strong_extra
         if extra:

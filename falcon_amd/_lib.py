@@ -33,6 +33,8 @@ _SIGNATURES = {
     "fal_ctx_create": ([c_int, c_void_p, c_int, P(c_void_p)], c_int),
     "fal_ctx_destroy": ([c_void_p], c_int),
     "fal_ctx_sync": ([c_void_p], c_int),
+    "fal_ctx_plan": ([c_void_p, c_int64, c_int, c_int, c_int, c_int64], c_int),
+    "fal_ctx_trim": ([c_void_p], c_int),
     "fal_ctx_stage_ms": ([c_void_p, c_int, P(c_float), P(c_int64)], c_int),
     "fal_ctx_enable_timing": ([c_void_p, c_int], c_int),
     "fal_ctx_counter": ([c_void_p, c_int, P(c_int64)], c_int),

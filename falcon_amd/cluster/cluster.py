@@ -141,6 +141,25 @@ class ClusterPipeline:
         self.ctx = ctx or _device.Context(device)
         self.last = {}
 
+    def plan(self, n: int, batch_size: int, p: "AnnParams"):
+        """`fal_ctx_plan` for a pass over `n` spectra: the kernels' code objects loaded, the shape-dependent scratch sized.  The
+        reference calls generate_clusters ONCE per charge in a fresh process (falcon.py:153-193): the first pass is the only
+        one, so it should not stop for either between its kernels.  Cheap when there is nothing left to do (every `run` calls it)."""
+        key = (int(n), int(batch_size), p.low_dim, p.n_neighbors_ann, p.n_probe)
+        if getattr(self, "_planned", None) is not None and self._planned[0] >= key[0] and self._planned[1:] == key[1:]:
+            return
+        self.ctx.plan(n, _device.row_width(p.low_dim), p.n_neighbors_ann, p.n_probe, batch_size)
+        self._planned = key
+
+    def trim(self):
+        """`fal_ctx_trim` + torch's cache: give this pipeline's cached device memory back (between jobs of very different sizes)"""
+        import torch
+        for c in (self.ctx, getattr(self, "_front_ctx", None)):
+            if c is not None:
+                c.trim()
+        self._planned = None
+        torch.cuda.empty_cache()
+
     # The path in three phases, so that independent partitions (precursor charges, falcon.py:151-160) can be
     # pipelined: `_front` ends with the path's first host synchronisation (bucket boundaries), `_search` only
     # enqueues, `_graph` ends with the second (cluster counts).
@@ -320,6 +339,7 @@ class ClusterPipeline:
         c = self.ctx
         if len(ds) == 0:
             return c.empty((0,), torch.int32), c.empty((0,), torch.int32)
+        self.plan(len(ds), batch_size, p)
         st = self._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p)
         self._search(ds, st, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, p, keep_intermediates)
         labels, medoids, self.last = self._graph(st, precursor_tol_mass, precursor_tol_mode, rt_tol, p, keep_intermediates)
@@ -340,6 +360,8 @@ class ClusterPipeline:
         c = self.ctx
         args = (precursor_tol_mass, precursor_tol_mode, rt_tol)
         live = [i for i, ds in enumerate(datasets) if len(ds) > 0]
+        if live:
+            self.plan(max(len(datasets[i]) for i in live), batch_size, p)
         if len(live) > 1 and not hasattr(self, "_front_ctx"):
             self._front_stream = torch.cuda.Stream(device=c.tdev)
             with torch.cuda.stream(self._front_stream):
@@ -516,6 +538,30 @@ class PartitionRunner:
         res = [futs[i].result()[::2] if i in futs else nothing() for i in range(len(datasets))]
         self.lasts = [r[1] for r in res]                           # every partition's `last`, in the order of `datasets`
         return [r[0] for r in res]
+
+    def plan(self, datasets, *args, **kwargs):
+        """Before the first pass of a fresh process: create every slot's thread, stream and context and `fal_ctx_plan` each for the
+        job's largest partition (code objects loaded once per process, scratch sized).  Optional -- `run` does the same lazily."""
+        import threading
+        n = max((len(ds) for ds in datasets), default=0)
+        batch_size, p = args[4], args[5]
+        gate = threading.Barrier(self.n_slots)
+
+        def one():
+            pipe, stream = self._pipeline()
+            import torch
+            with torch.cuda.stream(stream):
+                pipe.plan(n, batch_size, p)
+            gate.wait()                                  # (every worker thread takes exactly one of the n_slots tasks)
+        for f in [self._pool.submit(one) for _ in range(self.n_slots)]:
+            f.result()
+
+    def trim(self):
+        """every slot's `ClusterPipeline.trim` (the slots are idle between two `run` calls)"""
+        with self._lock:
+            pipes = list(self.pipelines)
+        for pipe in pipes + ([self._planner] if hasattr(self, "_planner") else []):
+            pipe.trim()
 
     def run_chunked(self, datasets, *args, n_chunks: int, on_chunk=None, **kwargs):
         """`ClusterPipeline.run_chunked` with the partitions of every bucket share on concurrent slots: the precursor windows of the

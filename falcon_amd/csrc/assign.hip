@@ -228,3 +228,4 @@ int launch_assign(fal_ctx* ctx, int stage, const float* X, const float* centroid
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::assign_kernel<8>);      // (fal_ctx_plan: this unit's code object is loaded up front)

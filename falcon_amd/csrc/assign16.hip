@@ -543,3 +543,4 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::cvt_f16_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)

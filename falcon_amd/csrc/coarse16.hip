@@ -775,3 +775,4 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::coarse16x_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)

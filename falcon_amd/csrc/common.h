@@ -142,6 +142,14 @@ struct CallScope {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// One kernel of every translation unit, registered at load time: hipcc's runtime loads a translation unit's code object when one
+// of its kernels is first used on a device (a few ms each, ~20 units) -- fal_ctx_plan touches them all up front
+// (hipFuncGetAttributes) so that the first pass of a fresh process does not pay the loads between its kernels.
+struct WarmReg {
+    explicit WarmReg(const void* kernel);
+};
+#define FAL_WARM_KERNEL(...) static const ::fal::WarmReg _fal_warm_reg((const void*)(__VA_ARGS__))
+
 // LDS hand-off between the lanes of ONE wave: every lane's LDS writes in front, the reads of other lanes' data behind.
 // LDS operations of a wave execute in order, so no hardware wait is needed beyond the release fence's; what is also needed
 // is that hipcc keeps the reads behind the barrier.  Rounds 1-2 wrote `fence(release) + wave_barrier` only -- a release orders

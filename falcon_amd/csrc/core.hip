@@ -5,8 +5,35 @@
 #include <string.h>
 #include "common.h"
 #include "hash.h"
+#include "scan.h"
+#include "ivf.h"
+#include <algorithm>
 
+#include <chrono>
 namespace fal {
+// FALCON_TRACE_ALLOC=1: every device allocation of the library (scratch slots, pool blocks) with its size and duration on stderr
+// -- what a cold pass (falcon.main(): one pass per charge in a fresh process) pays before its first kernel
+static bool trace_alloc() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("FALCON_TRACE_ALLOC");
+        v = e && e[0] && e[0] != '0';
+    }
+    return v == 1;
+}
+static hipError_t traced_malloc(void** p, size_t bytes, const char* what, int id) {
+    if (!trace_alloc()) return hipMalloc(p, bytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, bytes);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[falcon alloc] %s %d: %.1f MB in %.2f ms\n", what, id, bytes / 1048576.0, ms);
+    return e;
+}
+static std::vector<const void*>& warm_kernels() {
+    static std::vector<const void*> v;        // (function-local: filled by other units' static initialisers)
+    return v;
+}
+WarmReg::WarmReg(const void* kernel) { warm_kernels().push_back(kernel); }
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -45,7 +72,7 @@ int fal_ctx::reserve(int slot, size_t bytes, void** out) {
             s.cap = 0;
         }
         const size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&s.ptr, want);
+        hipError_t e = fal::traced_malloc(&s.ptr, want, "slot", slot);
         if (e == hipErrorOutOfMemory && !retired.empty()) {
             // Out of memory with retired blocks around: the ones nobody can hold a pointer into any more (their slot had been
             // released, or was last reserved by an earlier call) go once the stream has drained; a block retired from a slot
@@ -94,7 +121,7 @@ int fal_ctx::pool_alloc(size_t bytes, void** out) {
     }
     void* p = nullptr;
     const size_t cap = bytes + bytes / 16 + 256;
-    FAL_CHECK_HIP(hipMalloc(&p, cap));
+    FAL_CHECK_HIP(fal::traced_malloc(&p, cap, "pool", (int)pool.size()));
     pool.push_back({p, cap, true});
     if (debug_poison) FAL_CHECK_HIP(hipMemsetAsync(p, 0xFF, cap, stream));
     *out = p;
@@ -245,6 +272,66 @@ int fal_ctx_destroy(fal_ctx* c) {
         }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return FAL_OK;
+}
+
+// Sizes the scratch a pass over n spectra will ask for and loads the kernels' code objects, so that the FIRST pass of a fresh
+// process -- the only pass falcon.main() makes per charge (reference falcon.py:153-193) -- does not stop between its kernels for
+// them.  What is sized: the slots whose size follows from n alone (sort buffers, the tail's and the graph's per-row arrays, the
+// flat scan's hand-off up to its cap); slots that depend on the bucket structure keep growing on demand (a device allocation
+// costs ~30 us on this driver: FALCON_TRACE_ALLOC=1).  Safe to call at any time; never shrinks anything.
+int fal_ctx_plan(fal_ctx* c, int64_t n, int low_dim, int k_ann, int n_probe, int64_t batch_size) {
+    fal::CallScope _call(c);
+    FAL_REQUIRE(c && n >= 0 && low_dim >= 1 && k_ann >= 1 && n_probe >= 1 && batch_size >= 1, FAL_EINVAL, "fal_ctx_plan: bad argument");
+    FAL_CHECK_HIP(hipSetDevice(c->device));
+    for (const void* k : fal::warm_kernels()) {
+        hipFuncAttributes attr;
+        FAL_CHECK_HIP(hipFuncGetAttributes(&attr, k));           // (loads the unit's code object on this device)
+    }
+    // the pinned upload ring of the job tables (32 MB of page-locked host memory: milliseconds to get)
+    if (!c->arena) FAL_CHECK_HIP(hipHostMalloc((void**)&c->arena, (size_t)32u << 20, hipHostMallocDefault));
+    if (n == 0) return FAL_OK;
+    void* p = nullptr;
+    using namespace fal;
+    const size_t nn = (size_t)n;
+    // sort by precursor / list sorts: keys + values, in and out (sortutil.hip, ivf.hip)
+    FAL_TRY(c->reserve(SLOT_SORT, 24 * nn + 4096, &p));
+    FAL_TRY(c->reserve(SLOT_SORT2, 12 * nn + 4096, &p));
+    // the flat scan's hand-off: one [32, ceil32(n_b)] block per query tile, batches of at most the cap (search.hip); a bucket holds
+    // at most batch_size rows -- the whole job's need is bounded by n * min(n, batch_size) floats, the cap (2 GiB) usually binds
+    {
+        const char* e = getenv("FALCON_SIMS_MB");
+        size_t cap = (e ? (size_t)atoll(e) : 2048) * 1024 * 1024;
+        const double need = 4.0 * (double)nn * (double)std::min<int64_t>(n, std::min<int64_t>(batch_size, 4096));
+        if (need < (double)cap) cap = (size_t)need;
+        FAL_TRY(c->reserve(SLOT_SIMS, cap + sizeof(float) * kSimsSlack, &p));
+    }
+    // per-row arrays of the graph stages (graph.hip, tail.hip): labels, parents, segment tables
+    for (int slot : {SLOT_DB, SLOT_DB2, SLOT_TAIL, SLOT_TAIL2, SLOT_FIN, SLOT_FIN2}) FAL_TRY(c->reserve(slot, 8 * nn + 4096, &p));
+    for (int slot = 0; slot < 32; ++slot) c->release(slot);      // (no pointer is held: the passes may still grow them)
+    return FAL_OK;
+}
+
+// Gives the context's cached device memory back to the driver: every scratch slot, every pool block no index holds, the retired
+// blocks.  For a process that runs jobs of very different sizes one after the other (bench.py between its configurations; a
+// falcon.main() that has finished a charge partition of 50 M spectra and goes on to one of 10 k).  The stream is drained first.
+int fal_ctx_trim(fal_ctx* c) {
+    fal::CallScope _call(c);
+    FAL_REQUIRE(c, FAL_EINVAL, "fal_ctx_trim: NULL ctx");
+    FAL_CHECK_HIP(hipStreamSynchronize(c->stream));
+    c->release_retired();
+    for (auto& s : c->scratch)
+        if (s.ptr) {
+            (void)hipFree(s.ptr);
+            s.ptr = nullptr;
+            s.cap = 0;
+        }
+    size_t kept = 0;
+    for (size_t i = 0; i < c->pool.size(); ++i) {
+        if (c->pool[i].used) c->pool[kept++] = c->pool[i];
+        else (void)hipFree(c->pool[i].ptr);
+    }
+    c->pool.resize(kept);
     return FAL_OK;
 }
 

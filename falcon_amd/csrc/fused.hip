@@ -937,3 +937,4 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
 bool fused_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::resolve_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void nb_pack_kernel(const int32_t* __restrict_
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::filter_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 using namespace fal;
 

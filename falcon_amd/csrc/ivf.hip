@@ -409,6 +409,7 @@ __global__ void rows_sign16_kernel(const uint4* __restrict__ x, int64_t n8, int3
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 }  // namespace fal
+FAL_WARM_KERNEL(fal::kmeans_init_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 extern "C" {
 

@@ -637,3 +637,4 @@ int launch_select16(fal_ctx* ctx, const Select16Args& a_in, int64_t n_tiles) {
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::list16_kernel<25>);      // (fal_ctx_plan: this unit's code object is loaded up front)

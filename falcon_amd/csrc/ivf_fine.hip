@@ -188,3 +188,4 @@ int launch_list_scan(fal_ctx* ctx, const ListScanArgs& a_in) {
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::ivf_list4_kernel<50, 0>);      // (fal_ctx_plan: this unit's code object is loaded up front)

@@ -487,6 +487,7 @@ int linkage_dev(fal_ctx* ctx, const int32_t* nb_idx, const float* nb_dist, int64
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::lk_init_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 using namespace fal;
 

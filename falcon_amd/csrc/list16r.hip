@@ -270,3 +270,4 @@ int launch_list16r(fal_ctx* ctx, const List16Args& a) {
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::list16r_kernel<25>);      // (fal_ctx_plan: this unit's code object is loaded up front)

@@ -469,3 +469,4 @@ int launch_pairs16(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::gather_pmz_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)

@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void prep_emit_kernel(const double* __restrict
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::prep_flags_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 using namespace fal;
 

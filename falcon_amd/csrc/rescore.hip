@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const int32_t* __restrict_
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::rescore_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 using namespace fal;
 

@@ -736,3 +736,4 @@ int launch_select(fal_ctx* ctx, int stage, int mode, const SelectArgs& a_in, int
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::dense4_kernel<50, 0>);      // (fal_ctx_plan: this unit's code object is loaded up front)

@@ -233,3 +233,4 @@ int launch_scan16(fal_ctx* ctx, int planes, const void* Xs, int d, const DenseJo
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::scan16_kernel<25, 1>);      // (fal_ctx_plan: this unit's code object is loaded up front)

@@ -272,6 +272,7 @@ static size_t sims_capacity_floats() {
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::probe_totals_kernel<4>);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 using namespace fal;
 

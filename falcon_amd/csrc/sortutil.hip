@@ -277,6 +277,7 @@ __global__ void nonzero_i32_kernel(const int32_t* __restrict__ in, int64_t n, in
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::iota_i64_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 using namespace fal;
 

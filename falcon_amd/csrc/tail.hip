@@ -477,6 +477,7 @@ __global__ void finalize_kernel(const int32_t* __restrict__ labels, int64_t n, c
 }
 
 }  // namespace fal
+FAL_WARM_KERNEL(fal::refine_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
 
 using namespace fal;
 

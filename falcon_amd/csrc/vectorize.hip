@@ -189,6 +189,7 @@ __global__ void to_vector_indices_kernel(const float* __restrict__ mz, int64_t n
         out[i] = (int32_t)floor(__ddiv_rn((double)mz[i] - min_mz, bin_size));
 }
 
+FAL_WARM_KERNEL(vectorize_kernel<0>);
 }  // namespace
 
 extern "C" {

@@ -68,6 +68,14 @@ class Context:
     def sync(self):
         check(self.lib.fal_ctx_sync(self._h), "fal_ctx_sync")
 
+    def plan(self, n: int, low_dim: int = 400, k_ann: int = 128, n_probe: int = 16, batch_size: int = 2 ** 15):
+        """`fal_ctx_plan`: load every kernel's code object and size the shape-dependent scratch before the first pass"""
+        check(self.lib.fal_ctx_plan(self._h, int(n), int(low_dim), int(k_ann), int(n_probe), int(batch_size)), "fal_ctx_plan")
+
+    def trim(self):
+        """`fal_ctx_trim`: give the context's cached device memory back to the driver (drains the stream)"""
+        check(self.lib.fal_ctx_trim(self._h), "fal_ctx_trim")
+
     def enable_timing(self, on: bool = True):
         check(self.lib.fal_ctx_enable_timing(self._h, int(on)))
 

@@ -110,6 +110,7 @@ def _run(args) -> int:
         for fn in os.listdir(spectra_dir):
             os.remove(os.path.join(spectra_dir, fn))
     pipe = cluster.ClusterPipeline(device=config.device)
+    pipe.ctx.plan(0)                 # the kernels' code objects, once per process: not between the kernels of the first charge's pass
     charge_path = os.path.join(spectra_dir, "charges.json")
     if os.path.isfile(charge_path) and not config.overwrite:                                   # falcon.py:143-149
         with open(charge_path) as f:

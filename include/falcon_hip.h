@@ -61,6 +61,14 @@ int fal_device_count(int* count);
 int fal_ctx_create(int device, void* stream, int own_stream, fal_ctx** out);
 int fal_ctx_destroy(fal_ctx* ctx);
 int fal_ctx_sync(fal_ctx* ctx);
+/* The one-shot call pattern of the reference (falcon.py:153-193: generate_clusters ONCE per precursor charge, in a fresh
+ * process) makes the FIRST pass the only one.  fal_ctx_plan: before it, load the code objects of every kernel on the context's
+ * device (otherwise loaded one translation unit at a time between the first pass's kernels) and size the scratch slots that follow
+ * from the shape alone (n spectra, k_ann, n_probe, batch_size); a host-side call, safe at any time, never shrinks anything.
+ * fal_ctx_trim: return the context's cached device memory (scratch slots, free pool blocks) to the driver -- between jobs of very
+ * different sizes; drains the stream. */
+int fal_ctx_plan(fal_ctx* ctx, int64_t n, int low_dim, int k_ann, int n_probe, int64_t batch_size);
+int fal_ctx_trim(fal_ctx* ctx);
 /* Elapsed milliseconds (HIP events on the context's stream) of the kernels the LAST
  * call of the named stage enqueued; used by bench.py for the roofline figure.
  * stage: 0 vectorize, 1 kmeans/ivf build, 2 coarse probe, 3 fine scan (cosine kernel),

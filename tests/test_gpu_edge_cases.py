@@ -138,3 +138,40 @@ def test_dbscan_ignores_neighbour_ids_outside_the_dataset(ctx):
     lab, n_cl = ctx.linkage_cluster(ti, td, 0.1, "single")
     lab_ref, n_ref = ctx.linkage_cluster(tr, td, 0.1, "single")
     assert n_cl == n_ref and torch.equal(lab, lab_ref)
+
+
+def test_plan_and_trim_bound_the_scratch_and_keep_the_results(ctx):
+    """`fal_ctx_plan` (code objects + shape-dependent scratch before the first pass) and `fal_ctx_trim` (cached device memory back
+    to the driver): the results do not change, trim returns what the passes had grown, a pass after trim runs from empty pools."""
+    import torch
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline, PartitionRunner, SpectrumDataset
+    from oracle import falcon_oracle as fo
+    d = synth.select_charge(synth.generate(30000, seed=17, mz_lo=600.0, mz_hi=612.0), 2)         # flat and indexed buckets
+    ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+    ref, rmed = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"])
+    pipe = ClusterPipeline(device=ctx.device)
+    pipe.ctx.plan(0)                                             # (code objects only: what falcon.main() does at start)
+    pipe.plan(len(ds), 2 ** 15, AnnParams())
+    lab, med = pipe.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, AnnParams())
+    assert np.array_equal(lab.cpu().numpy(), ref) and np.array_equal(med.cpu().numpy(), rmed)
+    del lab, med
+    pipe.last = {}
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    pipe.trim()
+    free_after = torch.cuda.mem_get_info()[0]
+    assert free_after - free_before > 50e6, (free_before, free_after)        # the flat scan's hand-off alone is larger
+    lab, med = pipe.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, AnnParams())
+    assert np.array_equal(lab.cpu().numpy(), ref) and np.array_equal(med.cpu().numpy(), rmed)
+    runner = PartitionRunner(ctx.device, 2)
+    try:
+        args = (20.0, "ppm", None, 0.05, 2 ** 15, AnnParams())
+        runner.plan([ds], *args)
+        out = runner.run([ds], *args)
+        assert np.array_equal(out[0][0].cpu().numpy(), ref)
+        runner.trim()
+        out = runner.run([ds], *args)
+        assert np.array_equal(out[0][0].cpu().numpy(), ref)
+    finally:
+        runner.close()
