@@ -118,6 +118,32 @@ class SpectrumDataset:
             up.append(t.to(dev, dtype=dt, non_blocking=non_blocking))
         return SpectrumDataset(*up, self.precursor_charge)
 
+    def take_rows(self, rows: np.ndarray) -> "SpectrumDataset":
+        """Host-side CSR gather: the sub-dataset of `rows` (any order) of a HOST-resident dataset, in pinned memory where torch
+        can pin it -- what one GPU of a multi-GPU job uploads instead of the whole partition (a rank touches the peaks
+        of its own windows only; reference analogue: `dataset.take(idx)` per block, cluster.py:107-141)."""
+        import torch
+        as_np = lambda t: t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        rows = np.asarray(rows, np.int64)
+        indptr = as_np(self.indptr)
+        cnt = indptr[rows + 1] - indptr[rows]
+        out = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum(cnt, out=out[1:])
+        pos = np.repeat(indptr[rows] - out[:-1], cnt) + np.arange(int(out[-1]), dtype=np.int64)
+
+        def pick(col, idx, dt):
+            src = as_np(col)
+            t = torch.empty(len(idx), dtype=dt, pin_memory=torch.cuda.is_available())
+            dst = t.numpy()
+            if src.dtype == dst.dtype:
+                np.take(src, idx, out=dst)
+            else:
+                dst[:] = src[idx]
+            return t
+        rt = None if self.retention_time is None else pick(self.retention_time, rows, torch.float32)
+        return SpectrumDataset(pick(self.precursor_mz, rows, torch.float32), rt, pick(self.mz, pos, torch.float32),
+                               pick(self.intensity, pos, torch.float32), torch.from_numpy(out), self.precursor_charge)
+
     @classmethod
     def from_table(cls, table):
         """pyarrow Table / pandas DataFrame with the Lance schema of falcon.py:275-285."""
@@ -163,10 +189,11 @@ class ClusterPipeline:
     # The path in three phases, so that independent partitions (precursor charges, falcon.py:151-160) can be
     # pipelined: `_front` ends with the path's first host synchronisation (bucket boundaries), `_search` only
     # enqueues, `_graph` ends with the second (cluster counts).
-    def _front(self, c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p):
+    def _front(self, c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p, pmz=None):
         """sort by precursor m/z (cluster.py:73-85) + bucket boundaries (a5), on context `c`."""
         import torch
-        pmz = c.to_dev(ds.precursor_mz, torch.float32)
+        if pmz is None:
+            pmz = c.to_dev(ds.precursor_mz, torch.float32)
         order, mzs = c.sort_by_precursor(pmz)
         rts = c.gather_f32(ds.retention_time, order) if (rt_tol is not None and ds.retention_time is not None) else None
         splits = c.precursor_splits(mzs, precursor_tol_mass, precursor_tol_mode, batch_size, p.mz_interval)
@@ -180,8 +207,15 @@ class ClusterPipeline:
     def plan_shards(self, c, datasets, batch_size, p, world):
         """The deal of a multi-partition job to `world` GPUs (`distributed.deal_job`): -> [owner int32[windows] per dataset]
         (an empty array for an empty dataset).  One pass over every partition's precursor column, one wait."""
+        import torch
         from .. import distributed as fdist
-        counts = c.window_counts([ds.precursor_mz for ds in datasets], p.mz_interval)
+        # a host-resident partition crosses PCIe with its precursor column only (4 bytes per spectrum) before the deal; the
+        # device copy stays with the dataset for the front end of the rank's own windows (`_front_windows`)
+        for ds in datasets:
+            if ds.on_host():
+                ds._pmz_dev = c.to_dev(ds.precursor_mz, torch.float32)
+        counts = c.window_counts([getattr(ds, "_pmz_dev", None) if ds.on_host() else ds.precursor_mz for ds in datasets],
+                                 p.mz_interval)
         costs = fdist.window_costs(counts.ravel(), batch_size, p.n_probe).reshape(counts.shape)
         return fdist.deal_job(list(costs), world)
 
@@ -198,13 +232,15 @@ class ClusterPipeline:
         import torch
         from .. import distributed as fdist
         rank, world = shard[0], shard[1]
-        pmz = c.to_dev(ds.precursor_mz, torch.float32)
+        pmz = ds.__dict__.pop("_pmz_dev", None) if ds.on_host() else None      # (uploaded by this pass's plan_shards)
+        if pmz is None:
+            pmz = c.to_dev(ds.precursor_mz, torch.float32)
         n = int(pmz.numel())
         if owner is None:
             owner = self.plan_shards(c, [ds], batch_size, p, world)[0]
         if len(owner) and (owner == rank).all():
             # the whole partition is this rank's: the single-GPU front end, every dataset row in precursor order
-            st = self._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p)
+            st = self._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p, pmz=pmz)
             st.update(rows=st["order"], n_total=n)
             return st
         if not (owner == rank).any():
@@ -403,7 +439,15 @@ class ClusterPipeline:
             front(live[0])
         for pos, i in enumerate(live):
             if states[i]["order"].numel() > 0:
-                if sharded:
+                if sharded and datasets[i].on_host():
+                    # a rank touches the peaks of its own windows only -- of a HOST-resident partition it uploads just
+                    # those: the rows come back (8 bytes each), the host gathers their CSR in sorted order into pinned memory
+                    # (`take_rows`), and the path runs on that sub-dataset as it stands (row i = sorted position i)
+                    front_stream.synchronize()
+                    sub = datasets[i].take_rows(states[i]["rows"].cpu().numpy())
+                    sub = SpectrumDataset(None, None, c.to_dev(sub.mz), c.to_dev(sub.intensity), c.to_dev(sub.indptr))
+                    self._search(sub, states[i], *args, fragment_tol, p, False)      # (order = arange: set in front())
+                elif sharded:
                     # the subset's rows in sorted order = dataset rows `rows`: vectorise gathers them from the CSR
                     st = dict(states[i], order=states[i]["rows"])
                     torch.cuda.current_stream(c.tdev).wait_stream(front_stream)
@@ -522,7 +566,8 @@ class PartitionRunner:
         # largest partition first, each followed by an event: a partition's kernels start when ITS bytes have arrived, the
         # next partition's upload travels under them (pinned memory makes the copies asynchronous).
         arrived = {}
-        if any(datasets[i].on_host() for i in order):
+        sharded = shard is not None and shard[1] > 1
+        if not sharded and any(datasets[i].on_host() for i in order):     # (a sharded rank uploads its own windows only: run_many)
             if not hasattr(self, "_copy_stream"):
                 self._copy_stream = torch.cuda.Stream(device=self.device)
             datasets = list(datasets)

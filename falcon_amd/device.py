@@ -48,14 +48,19 @@ class Context:
             pass
 
     # ------------------------------------------------------------------ helpers
+    h2d_bytes = 0            # bytes this context has copied host -> device through `to_dev` (the multi-GPU tests count them)
+
     def to_dev(self, a, dtype=None):
         torch = _torch()
         if isinstance(a, torch.Tensor):
-            t = a.to(self.tdev)
+            if not a.is_cuda:
+                self.h2d_bytes += a.numel() * a.element_size()
+            t = a.to(self.tdev, non_blocking=True)
             return t.to(dtype).contiguous() if dtype is not None else t.contiguous()
         t = torch.from_numpy(np.ascontiguousarray(a))
         if dtype is not None:
             t = t.to(dtype)
+        self.h2d_bytes += t.numel() * t.element_size()
         return t.to(self.tdev)
 
     def empty(self, shape, dtype):

@@ -23,11 +23,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("n_spectra,mz_lo,mz_hi,regime", [
-    (30000, 500.0, 560.0, "flat"),            # ~350-row windows: flat buckets, thousands of units to deal
-    (60000, 600.0, 606.0, "ivf"),             # ~7,000-row windows: k-means index (n_list 128), prefiltered fine scan
+@pytest.mark.parametrize("n_spectra,mz_lo,mz_hi,regime,mode", [
+    (30000, 500.0, 560.0, "flat", "device"),  # ~350-row windows: flat buckets, thousands of units to deal
+    (60000, 600.0, 606.0, "ivf", "device"),   # ~7,000-row windows: k-means index (n_list 128), prefiltered fine scan
+    # the partitions HOST-resident (PartitionRunner.run(shard=)): a rank uploads the precursor columns and the peaks of its own
+    # windows only -- at most 0.55 of the dataset's bytes cross PCIe per rank at world size 2
+    (30000, 500.0, 560.0, "flat", "host"),
+    (60000, 600.0, 612.0, "ivf", "host"),
 ])
-def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, regime):
+def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, regime, mode):
     import torch
     if torch.cuda.is_initialized():
         pytest.fail("this pytest process already owns a GPU context (a GPU test file sorted in front of this one?): "
@@ -35,7 +39,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, 
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "world2_worker.py"), str(tmp_path), str(n_spectra),
-           str(mz_lo), str(mz_hi)]
+           str(mz_lo), str(mz_hi), mode]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     try:
         log, _ = proc.communicate(timeout=900)
@@ -45,6 +49,9 @@ def test_two_ranks_on_one_gpu_equal_one_rank(tmp_path, n_spectra, mz_lo, mz_hi, 
         pytest.fail("world-size-2 job timed out:\n" + log[-3000:])
     assert proc.returncode == 0, log[-3000:]
     r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in (0, 1))
+    if mode == "host":
+        for r in (r0, r1):
+            assert 0.2 * int(r["dataset_bytes"]) < int(r["h2d_bytes"]) <= 0.55 * int(r["dataset_bytes"]), (int(r["h2d_bytes"]), int(r["dataset_bytes"]))
     single = r0["single_labels"]
     n = len(single)
     assert (int(r0["single_n_list_max"]) > 1) == (regime == "ivf")
@@ -96,6 +103,9 @@ def test_bench_runs_as_a_two_rank_job(scaling, extra):
     assert out["unit"] == "spectra/s" and out["roofline"]["frac"] <= 1.0
     assert abs(out["value"] - 300000 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert out["rccl"]["ranks"] == 2
+    # every rank's host-to-host leg: the partitions in pinned host memory, a rank uploads its own windows only
+    h = out["host_to_host"]
+    assert "error" not in h and h["value_host_to_host"] > 0 and 0.2 < h["uploaded_fraction_rank0"] <= (0.62 if scaling == "weak" else 0.55), h
     if scaling == "weak":
         assert out["strong_scaling"]["value"] > 0 and out["strong_scaling"]["scaling"] == "strong", out["strong_scaling"]
 

@@ -341,3 +341,24 @@ def test_low_dim_is_a_free_integer_rows_are_padded_to_an_instantiated_width(tmp_
     for bad in ("0", "801"):
         with pytest.raises(ValueError):
             c.parse(f"in.mgf out --low_dim {bad}")
+
+
+def test_take_rows_is_the_host_side_csr_gather_of_a_rank():
+    """a rank of a multi-GPU job uploads the peaks of ITS windows only -- `SpectrumDataset.take_rows` gathers them on
+    the host in the order asked for (any order, repeats allowed, empty selection)"""
+    from falcon_amd import synth
+    from falcon_amd.cluster.cluster import SpectrumDataset
+    d = synth.generate(500, seed=8)
+    ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
+    assert ds.on_host()
+    rows = np.array([499, 3, 3, 120, 0], np.int64)
+    sub = ds.take_rows(rows)
+    assert len(sub) == 5 and np.array_equal(sub.precursor_mz.numpy(), d["precursor_mz"][rows])
+    assert np.array_equal(sub.retention_time.numpy(), d["retention_time"][rows])
+    ip = sub.indptr.numpy()
+    for i, r in enumerate(rows):
+        a, b = d["indptr"][r], d["indptr"][r + 1]
+        assert np.array_equal(sub.mz.numpy()[ip[i]:ip[i + 1]], d["mz"][a:b])
+        assert np.array_equal(sub.intensity.numpy()[ip[i]:ip[i + 1]], d["intensity"][a:b])
+    empty = ds.take_rows(np.zeros(0, np.int64))
+    assert len(empty) == 0 and empty.mz.numel() == 0 and list(empty.indptr.numpy()) == [0]
