@@ -359,7 +359,7 @@ def main():
             lasts = pipe.lasts
         else:
             outs, lasts = [], []
-            owners = pipe.plan_shards(ctx, parts, run_args[4], run_args[5], world) if shard is not None else None
+            owners = pipe.plan_shards(ctx, parts, run_args[4], run_args[5], world, tol=run_args[:2]) if shard is not None else None
             for j, ds in enumerate(parts):
                 if shard is not None:
                     o = pipe.run_many([ds], *run_args, shard=(rank, world, [owners[j]]))
@@ -431,7 +431,7 @@ def main():
     def staged_share(parts, run_args, chunks):
         """per-kernel timing of ONE bucket share of a job that runs in `chunks` shares (configs[3] at 50 M spectra): share 0 of the
         same deal `run_chunked` executes, partition by partition, serial, HIP events around every stage"""
-        owners = pipe.plan_shards(ctx, parts, run_args[4], run_args[5], chunks)
+        owners = pipe.plan_shards(ctx, parts, run_args[4], run_args[5], chunks, tol=run_args[:2])
 
         def one(collect):
             for j, ds in enumerate(parts):
@@ -744,7 +744,7 @@ def main():
             if skew:
                 # balance of the job as the multi-GPU deal would cut it (window histogram -> cost model -> deal_job), 8 ranks
                 counts = ctx.window_counts([ds.precursor_mz for ds in big], pc.mz_interval)
-                costs = fdist.window_costs(counts.ravel(), batch, pc.n_probe).reshape(counts.shape)
+                costs = fdist.window_costs(counts, batch, pc.n_probe, pc.mz_interval, ra[:2], pc.n_neighbors_ann, pc.n_neighbors)
                 owners = fdist.deal_job(list(costs), 8)
                 loads = sum(np.bincount(o, weights=c, minlength=8) for o, c in zip(owners, costs))
                 occ = counts[0][counts[0] > 0]

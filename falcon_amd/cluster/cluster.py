@@ -204,7 +204,7 @@ class ClusterPipeline:
             n_list[:] = 1
         return dict(order=order, mzs=mzs, rts=rts, splits=splits, n_list=n_list)
 
-    def plan_shards(self, c, datasets, batch_size, p, world):
+    def plan_shards(self, c, datasets, batch_size, p, world, tol=None):
         """The deal of a multi-partition job to `world` GPUs (`distributed.deal_job`): -> [owner int32[windows] per dataset]
         (an empty array for an empty dataset).  One pass over every partition's precursor column, one wait."""
         import torch
@@ -216,7 +216,8 @@ class ClusterPipeline:
                 ds._pmz_dev = c.to_dev(ds.precursor_mz, torch.float32)
         counts = c.window_counts([getattr(ds, "_pmz_dev", None) if ds.on_host() else ds.precursor_mz for ds in datasets],
                                  p.mz_interval)
-        costs = fdist.window_costs(counts.ravel(), batch_size, p.n_probe).reshape(counts.shape)
+        # (`tol` = (precursor tolerance, mode): the cost model then prices the stored neighbours too)
+        costs = fdist.window_costs(counts, batch_size, p.n_probe, p.mz_interval, tol, p.n_neighbors_ann, p.n_neighbors)
         return fdist.deal_job(list(costs), world)
 
     def _front_windows(self, c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p, shard, owner=None):
@@ -237,7 +238,7 @@ class ClusterPipeline:
             pmz = c.to_dev(ds.precursor_mz, torch.float32)
         n = int(pmz.numel())
         if owner is None:
-            owner = self.plan_shards(c, [ds], batch_size, p, world)[0]
+            owner = self.plan_shards(c, [ds], batch_size, p, world, tol=(precursor_tol_mass, precursor_tol_mode))[0]
         if len(owner) and (owner == rank).all():
             # the whole partition is this rank's: the single-GPU front end, every dataset row in precursor order
             st = self._front(c, ds, precursor_tol_mass, precursor_tol_mode, rt_tol, batch_size, p, pmz=pmz)
@@ -418,7 +419,7 @@ class ClusterPipeline:
             if owners is None:
                 front_stream.wait_stream(torch.cuda.current_stream(c.tdev))
                 with torch.cuda.stream(front_stream):
-                    owners = self.plan_shards(front_ctx, datasets, batch_size, p, shard[1])
+                    owners = self.plan_shards(front_ctx, datasets, batch_size, p, shard[1], tol=args[:2])
 
         def front(i):
             with torch.cuda.stream(front_stream):
@@ -558,7 +559,7 @@ class PartitionRunner:
             # one deal for the whole job (`distributed.deal_job` over every partition's windows), then a slot per partition
             if not hasattr(self, "_planner"):
                 self._planner = ClusterPipeline(device=self.device)
-            owners = self._planner.plan_shards(self._planner.ctx, datasets, args[4], p, shard[1])      # (waits for the counts)
+            owners = self._planner.plan_shards(self._planner.ctx, datasets, args[4], p, shard[1], tol=args[:2])      # (waits for the counts)
             shards = [(shard[0], shard[1], [owners[i]]) for i in range(len(datasets))]
             order = [i for i in order if (owners[i] == shard[0]).any()]        # partitions this rank has windows of
         dev = torch.device("cuda", self.device)

@@ -98,7 +98,19 @@ def deal_job(costs_list, world_size: int, tol: float = 0.03):
     # all units (0.6 ms of heap for 1,600 windows; modelled 1.00)
     loads = np.bincount(owner, weights=allc, minlength=world_size)
     if loads.max() > (1.0 + tol) * loads.mean():
-        owner = shard_units(allc, world_size).astype(np.int32)
+        # longest-processing-time PER PARTITION first: every rank then holds 1 / N of every partition, so its partitions keep
+        # the job's proportions and run side by side on the rank's slots like everyone else's (round 6: LPT over all windows at
+        # once gave one of 8 ranks most of its load in ONE charge partition -- same total work, 24 -> 31 ms on the two-slot
+        # runner, tools/shard_share.py 8 skew); LPT over all windows only where a partition cannot be balanced by itself (a
+        # window above 1 / N of its partition).  The better of the candidates is kept.
+        per_part = np.concatenate([shard_units(np.asarray(c, np.float64), world_size) for c in costs_list]).astype(np.int32)
+        best = loads.max()
+        for cand in (per_part, shard_units(allc, world_size).astype(np.int32)):
+            m = np.bincount(cand, weights=allc, minlength=world_size).max()
+            if m < best:
+                owner, best = cand, m
+            if best <= (1.0 + tol) * loads.mean():
+                break
     out, at = [], 0
     for n in sizes:
         out.append(owner[at:at + n].copy())
@@ -106,17 +118,39 @@ def deal_job(costs_list, world_size: int, tol: float = 0.03):
     return out
 
 
-def window_costs(counts: np.ndarray, batch_size: int, n_probe: int) -> np.ndarray:
+NEIGHBOUR_UNITS = 100.0      # cost of one STORED neighbour in units of one scanned (query, candidate) pair: the exact chains of the
+                             # kept pairs, the k-th key resolution, DBSCAN, refinement and medoids of the 10 M job take 26 ms for 99 M
+                             # stored neighbours against 51 ms of scan + top-k for 10.3 G pairs (profiles/NOTES.md r6)
+CLUSTER_NEIGHBOURS = 8.0     # stored neighbours of a row that are members of its own cluster (data-dependent; a constant here)
+
+
+def window_costs(counts: np.ndarray, batch_size: int, n_probe: int, mz_interval: Optional[float] = None, tol=None,
+                 k_ann: int = 128, n_neighbors: int = 64) -> np.ndarray:
     """Estimated cost of every precursor window from its spectrum count alone: the window becomes ceil(count / batch_size)
     buckets (the chunk rule of cluster.py:197-207; gaps inside a window, which would split it further, are not known
-    before the window is sorted -- they only make the estimate pessimistic), each costed like `bucket_costs`."""
+    before the window is sorted -- they only make the estimate pessimistic), each costed like `bucket_costs`.
+
+    `mz_interval` + `tol` = (mass, "ppm" | "Da") given (round 6): plus the work that follows the STORED neighbours (exact pair
+    chains, k-th key resolution, DBSCAN, refinement, medoids).  A row stores its cluster's members and the share of its k_ann
+    best candidates that passes the precursor tolerance: 2 tol / (m/z width of its bucket) -- and a full window is cut into
+    `chunks` buckets of 1 / chunks of the window's width, so its rows keep more (measured under skew: 16.3 stored neighbours per
+    row on the rank with the fullest windows against 10.5-11.5 elsewhere, the deal 8 % off the model: NOTES r5).  `counts` may
+    be 2-D [partitions, windows]: the window index (column) gives the m/z a ppm tolerance is taken at."""
     counts = np.asarray(counts, np.int64)
     chunks = np.maximum(1, -(-counts // max(int(batch_size), 1)))
     size = counts // chunks                                                   # <= batch_size
     if batch_size > (1 << 20):
         from .cluster.cluster import n_list_rule
-        return chunks * bucket_costs(size, n_list_rule(size, n_probe), n_probe)
-    return chunks * _bucket_cost_table(int(batch_size), int(n_probe))[size]
+        cost = chunks * bucket_costs(size, n_list_rule(size, n_probe), n_probe)
+    else:
+        cost = chunks * _bucket_cost_table(int(batch_size), int(n_probe))[size]
+    if mz_interval and mz_interval > 0 and tol is not None:
+        w = np.broadcast_to(np.arange(counts.shape[-1], dtype=np.float64), counts.shape)
+        tol_mz = float(tol[0]) if tol[1] == "Da" else float(tol[0]) * 1e-6 * (w + 0.5) * float(mz_interval)
+        passing = np.minimum(1.0, 2.0 * tol_mz * chunks / float(mz_interval))
+        stored = np.minimum(float(n_neighbors), CLUSTER_NEIGHBOURS + float(k_ann) * passing)
+        cost = cost + NEIGHBOUR_UNITS * counts * stored
+    return cost
 
 
 _cost_tables = {}

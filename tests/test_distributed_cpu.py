@@ -377,3 +377,27 @@ def test_expected_exchange_bytes_formula():
     assert abs(e["ms_fan_out_7_links"] - 7 * 47e6 / (7 * 153e9) * 1e3) < 1e-9 and abs(e["ms_ring_one_link"] - 7 * e["ms_fan_out_7_links"]) < 1e-9
     one = fd.expected_exchange_bytes(1_000_000, 1, 3.2)
     assert one["received_bytes_per_rank"] == 0 and one["ms_ring_one_link"] == 0.0
+
+
+def test_window_costs_price_the_stored_neighbours_of_full_windows():
+    """under skew the deal modelled 1.00 and measured 1.08 -- a window cut into several buckets keeps more
+    neighbours per row (each bucket spans a fraction of the window's m/z, so a larger share of a row's best candidates passes
+    the precursor tolerance) and everything behind the search (exact chains, DBSCAN, refinement, medoids) follows the stored
+    neighbours.  With the tolerance given, `window_costs` adds that term: a 65 k-row window (2 buckets) costs more per row
+    than two 32 k-row windows' rows, the extra is the neighbour term; without the tolerance the old figure is unchanged."""
+    from falcon_amd import distributed as fd
+    counts = np.zeros((1, 700), np.int64)
+    counts[0, 600] = 65000
+    counts[0, 601] = 32500
+    plain = fd.window_costs(counts, 2 ** 15, 16)
+    assert plain[0, 600] == 2 * plain[0, 601]
+    priced = fd.window_costs(counts, 2 ** 15, 16, 1.0, (20.0, "ppm"), 128, 64)
+    assert priced[0, 600] > 2 * priced[0, 601] > 2 * plain[0, 601]
+    # per row: cluster members + k_ann x (2 tol x chunks / window width), tolerance taken at the window's m/z
+    extra = (priced - plain)[0, 600:602] / counts[0, 600:602] / fd.NEIGHBOUR_UNITS
+    np.testing.assert_allclose(extra, [8 + 128 * 2 * 20e-6 * 600.5 * 2, 8 + 128 * 2 * 20e-6 * 601.5], rtol=1e-12)
+    # Da tolerance: the same everywhere; the count is capped at n_neighbors
+    da = fd.window_costs(counts, 2 ** 15, 16, 1.0, (0.5, "Da"), 128, 64)
+    assert np.allclose((da - plain)[0, 601] / 32500 / fd.NEIGHBOUR_UNITS, 64.0)
+    # 1-D counts keep working (window index = position)
+    assert np.array_equal(fd.window_costs(counts[0], 2 ** 15, 16, 1.0, (20.0, "ppm")), priced[0])
