@@ -646,6 +646,11 @@ def main():
                 # SURVEY 8d's C4 row as written: 1 m/z windows of ~44 k charge-2 spectra kept whole by `--batch_size 65536`
                 # (config.py:119-124) -> n_list 1,024, n_probe 32: more than 512 lists per bucket (VERDICT r4 missing #4)
                 ("f32-b64k", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32", n_probe=32), 560.0, 1, 2 ** 16),
+                # beyond the float16 gate: 1 m/z windows of ~175 k charge-2 spectra kept whole by
+                # `--batch_size 262144` -> n_list 4,096: more than the 2,048 lists the float16 assignment / key quantiser serve,
+                # those buckets take the exact float32 kernels (the charge-3 windows, 75 k rows / 1,024 lists, stay on the float16
+                # paths): the cost of the cliff as a stated number
+                ("f32-b256k", args.configs_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 440.0, 1, 2 ** 18),
                 # a workload that is NOT uniform (synth skew=True: log-normal occupancy of the 1 m/z windows, 5..50 peaks per
                 # spectrum): 300-row flat buckets next to 2^15-row indexed ones in one job
                 ("f32-skew", args.skew_spectra, dict(low_dim=400, dtype="f32", scan="f32"), 1200.0, 1, args.batch_size)]
@@ -674,9 +679,12 @@ def main():
             # (five timed steps after three priming passes: with three a single late scratch growth -- a GB-sized hipMalloc of
             #  one of the two partition contexts -- showed up as + 40 ms on the mean of a 120 ms step)
             steps_c = 5 if chunks == 1 else 3
+            slow = name == "f32-b256k"                            # (seconds per pass: two timed steps behind one priming pass)
+            if slow:
+                steps_c = 2
             try:
                 try:
-                    dtc = timed(big, ra, steps_c, 1, prime=3 if chunks == 1 else 2, chunks=chunks)
+                    dtc = timed(big, ra, steps_c, 0 if slow else 1, prime=1 if slow else (3 if chunks == 1 else 2), chunks=chunks)
                 except Exception as e:
                     if chunks != 2 or "memory" not in repr(e).lower():
                         raise
@@ -705,6 +713,8 @@ def main():
                                                  "precursors in 400-600 m/z",
                                     "f32-b64k": "SURVEY 8d's C4 row as written (43,750-row buckets, n_list 1,024, n_probe 32) at one "
                                                 "GPU's size: precursors in 400-560 m/z, batch_size 65536",
+                                    "f32-b256k": "none: the cliff beyond 2,048 lists per bucket -- precursors in 400-440 m/z, batch_size 262144: "
+                                                 "175 k-row buckets, n_list 4,096 (exact float32 k-means / coarse / fine scan)",
                                     "f32-skew": "none (VERDICT r4 next #7): configs[1]'s parameters on a skewed dataset -- log-normal window "
                                                 "occupancy (fullest window ~70x the median), 5..50 peaks per spectrum",
                                     "f32-50M": "configs[3] (50 M spectra, n_probe 32, n_neighbors_ann 128) at its own size"}[name],
@@ -729,6 +739,13 @@ def main():
                         sc, "list16_kernel<50> (f16 MFMA 32x32x16, list-major; float16 vectors: n_probe lists per query through the "
                             "k-means index, exact float32 chains over the vectors' images)", PEAK_MFMA_F16_TFLOPS,
                         "f16 MFMA 2.5 PFLOP/s dense", "10M_f16")
+                elif name == "f32-b256k":
+                    entry["roofline"] = roofline_of(
+                        sc, "ivf_list4_kernel<50> (fp32 MFMA 32x32x2, list-major: the exact fine scan of the 4,096-list buckets) + "
+                            "list16s_kernel<25> (the 1,024-list buckets of the other charge)", PEAK_MFMA_F32_TFLOPS,
+                        "fp32 MFMA 157.3 TFLOP/s", None,
+                        note="stage 8 sums the launches of both cosine kernels; the job's time is the exact float32 k-means assignment "
+                             "of the 4,096-list buckets (stage_ms.build)")
                 elif args.no_ivf_prefilter:
                     entry["roofline"] = roofline_of(sc, "ivf_list4_kernel<50> (fp32 MFMA 32x32x2, list-major)",
                                                     PEAK_MFMA_F32_TFLOPS, "fp32 MFMA 157.3 TFLOP/s", None)

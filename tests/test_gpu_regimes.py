@@ -113,6 +113,27 @@ def test_config4_as_written_bucket_of_45k_rows_n_list_1024_batch_size_65536(ctx)
     _check_production_equals_oracle(ctx, ds, p, L, ref, rmed, batch_size=2 ** 16)
 
 
+def test_beyond_the_float16_gate_bucket_of_165k_rows_n_list_4096_batch_size_2_18(ctx):
+    """a 1 m/z window of ~165 k charge-2 spectra kept whole by `--batch_size 262144` (config.py:119-124;
+    cluster.py:198-207): n_list 4,096 -- beyond the 2,048 lists the float16 assignment / key quantiser serve, so the bucket
+    takes the exact float32 kernels end to end (k-means assignment, coarse scan, fine scan, select).  The PRODUCTION path
+    (`pipe.run`, default AnnParams) against the oracle directly: neighbour lists, labels, medoids bit for bit (low_dim 64 keeps
+    the oracle's 11 k-means passes over 165 k x 4,096 centroids at seconds)."""
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
+    d, ds = _dense_dataset(236000, 600.02, 600.98, seed=76)
+    p = AnnParams(low_dim=64, n_probe=16, n_neighbors_ann=64, n_neighbors=32)
+    pipe = ClusterPipeline(ctx)
+    labels, medoids = pipe.run(ds, 20.0, "ppm", None, 0.05, 2 ** 18, p)
+    L = pipe.last
+    assert 4096 in list(L["n_list"]) and np.diff(L["splits"]).max() > 160000
+    ref, rmed, im = fo.generate_clusters(d["mz"], d["intensity"], d["indptr"], d["precursor_mz"], d["retention_time"], low_dim=64,
+                                         n_probe=16, n_neighbors_ann=64, n_neighbors=32, batch_size=2 ** 18,
+                                         return_intermediates=True)
+    assert np.array_equal(L["nb_idx"].cpu().numpy(), im["nb_idx"])
+    assert np.array_equal(L["nb_dist"].cpu().numpy().view(np.uint32), im["nb_dist"].view(np.uint32))
+    assert np.array_equal(labels.cpu().numpy(), ref) and np.array_equal(medoids.cpu().numpy(), rmed)
+
+
 def test_skewed_windows_flat_and_indexed_buckets_side_by_side(ctx):
     """`synth.generate(skew=True)`: log-normal window occupancy and 5..50 peaks per spectrum -- forty 1 m/z windows from a few
     rows to several thousand in one partition (flat buckets, n_list 16..128 side by side; spectra with a handful of peaks):
