@@ -134,7 +134,7 @@ def pmc_traffic(workload):
     (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so
     the figure is only reported for the workloads it was measured on (profiles/r5_pmc_traffic.json -- r4 / r3 as the fallback --, written by
     tools/pmc_traffic.sh on the GPU box).  -> (bytes per launch or None, source file or None)"""
-    for fn in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
+    for fn in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if os.path.isfile(path):
             try:

@@ -13,7 +13,7 @@ run() {   # name, program args...
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw_$name -o w -- python3 "$@" > /tmp/ow_$name.txt 2>&1
     tail -1 /tmp/of_$name.txt | cut -c1-200
 }
-run headline $R/bench.py --steps 5 --warmup 1 --no-configs --no-cpu-baseline --partitions pipelined
+run headline $R/bench.py --steps 5 --warmup 1 --no-configs --no-cpu-baseline --no-cold --partitions pipelined
 run 10M_f32 $R/tools/scale_run.py 10000000
 run 10M_f32_dense $R/tools/scale_run.py 10000000 f32 32 f32 400 400 600
 run 10M_f16 $R/tools/scale_run.py 10000000 f32 16 f16 800
@@ -21,8 +21,8 @@ run 10M_f32_b64k $R/tools/scale_run.py 10000000 f32 32 f32 400 400 560 65536
 python3 - <<'PY'
 import sqlite3, collections, json, os
 R = os.environ["GRAFT_REPO_ROOT"]
-KERNEL = {"headline": "dense4_kernel<50>", "10M_f32": "list16_kernel", "10M_f32_dense": "list16_kernel", "10M_f16": "list16_kernel",
-          "10M_f32_b64k": "list16_kernel"}
+KERNEL = {"headline": "dense4_kernel<50", "10M_f32": "list16", "10M_f32_dense": "list16", "10M_f16": "list16",
+          "10M_f32_b64k": "list16"}          # ("list16": list16_kernel (dense query rows) and list16s_kernel (sparse records, round 6))
 def agg(db, counter):
     d = collections.defaultdict(lambda: [0, 0.0])
     for name, v in sqlite3.connect(db).execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
@@ -43,7 +43,7 @@ for w, sub in KERNEL.items():
              for k, v in sorted(f.items(), key=lambda kv: -(2 * kv[1][1] + wr.get(kv[0], [0, 0.0])[1]))[:24]}
     out[w] = {"kernel": ", ".join(ks), "launches": n, "fetch_bytes_per_launch": fb / max(n, 1), "write_bytes_per_launch": wb / max(n, 1),
               "hbm_bytes_per_launch": (fb + wb) / max(n, 1), "kernels": table}
-json.dump(out, open(os.path.join(R, "gpurun_out", "r5_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(R, "gpurun_out", os.environ.get("FALCON_PMC_OUT", "r5_pmc_traffic.json")), "w"), indent=1)
 for w in KERNEL:
     e = out[w]
     print(w, e.get("kernel"), e.get("launches"), "GB/launch", round(e.get("hbm_bytes_per_launch", 0) / 1e9, 3))
