@@ -771,6 +771,9 @@ def main():
                                  "scan_plus_topk_ms_per_Gpair": sc["topk_ms"] / max(sc["pairs"], 1) * 1e9}
             extra.append(entry)
         del big
+        if runner is not None:                                    # (the 50 M job's pools go back before the 1 M dataset returns)
+            runner.trim()
+        pipe.trim()
         torch.cuda.empty_cache()
         concurrent["on"] = was_concurrent
         parts = make_parts(n_total, mz_lo=mz_lo, mz_hi=mz_hi, replicas=replicas)

@@ -494,17 +494,24 @@ class ClusterPipeline:
         for ch in range(n_chunks):
             outs = self.run_many(datasets, precursor_tol_mass, precursor_tol_mode, rt_tol, fragment_tol, batch_size, p,
                                  shard=(ch, n_chunks))
-            for j, ((lab, med), last) in enumerate(zip(outs, self.lasts)):
-                rows = last["rows"]
-                if rows.numel() == 0:
-                    continue
-                labels[j][rows] = lab + off[j]
-                medoids[j].append(rows[med.long()].to(torch.int32))
-                off[j] += int(med.numel())
+            _merge_share(labels, medoids, off, outs, self.lasts)
             if on_chunk is not None:
                 on_chunk(ch, outs, self.lasts)
             del outs
         return [(labels[j], torch.cat(medoids[j]) if medoids[j] else c.empty((0,), torch.int32)) for j in range(len(datasets))]
+
+
+def _merge_share(labels, medoids, off, outs, lasts):
+    """one bucket share's results into the job's: labels by dataset row with share-major cluster ids (the reference offsets the
+    labels of its blocks the same way, cluster.py:144-155), medoids as dataset rows; `off[j]` = clusters of partition j so far"""
+    import torch
+    for j, ((lab, med), last) in enumerate(zip(outs, lasts)):
+        rows = last.get("rows")
+        if rows is None or rows.numel() == 0:
+            continue
+        labels[j][rows] = lab + off[j]
+        medoids[j].append(rows[med.long()].to(torch.int32))
+        off[j] += int(med.numel())
 
 
 class PartitionRunner:
@@ -623,13 +630,7 @@ class PartitionRunner:
         off = [0] * len(datasets)
         for ch in range(n_chunks):
             outs = self.run(datasets, *args, shard=(ch, n_chunks), **kwargs)
-            for j, ((lab, med), last) in enumerate(zip(outs, self.lasts)):
-                rows = last["rows"]
-                if rows.numel() == 0:
-                    continue
-                labels[j][rows] = lab + off[j]
-                medoids[j].append(rows[med.long()].to(torch.int32))
-                off[j] += int(med.numel())
+            _merge_share(labels, medoids, off, outs, self.lasts)
             if on_chunk is not None:
                 on_chunk(ch, outs, self.lasts)
             del outs

@@ -197,6 +197,7 @@ template <int STEPS>
 __global__ __launch_bounds__(256, 1) void list16r_kernel(List16Args a) {
     constexpr int D = STEPS * 16, PIECES = D / 8, RS = D * 2 + 16;
     static_assert(PIECES <= 64, "one load instruction per row");
+    static_assert(128 * RS + 4 * 16 * RS + 4 * 32 * 4 <= 160 * 1024, "the tile, the staging rows and the metadata must fit one CU's 160 KB of LDS");
     __shared__ __attribute__((aligned(16))) unsigned char lrows[128 * RS];       // the tile's list rows (B operand)
     __shared__ __attribute__((aligned(16))) unsigned char tbuf_all[4][16 * RS];  // per wave: 16 query rows on their way to A
     __shared__ __attribute__((aligned(16))) int32_t dmeta[4][32];                // per wave: the chunk's 32 destinations
