@@ -201,10 +201,11 @@ def main():
     ap.add_argument("--big-spectra", type=int, default=50_000_000,
                     help="BASELINE configs[3] at its own size (n_probe 32, n_neighbors_ann 128), run in --big-chunks bucket shares "
                          "(ClusterPipeline.run_chunked); 0 = skip")
-    ap.add_argument("--big-chunks", type=int, default=2,
-                    help="bucket shares of the 50 M configuration (measured alone in a process: 2 shares 962 ms, 3 shares 978, 4 shares "
-                         "992 per pass).  Round 6: the contexts' scratch pools are trimmed between the configurations (fal_ctx_trim), so the "
-                         "2 shares fit inside a default run too; if they do not, the entry falls back to 4 shares and says so")
+    ap.add_argument("--big-chunks", type=int, default=4,
+                    help="bucket shares of the 50 M configuration.  Round 6 (tools/big_job.py, alone in a process): 4 shares 0.86 s per "
+                         "pass with 191 GB of the device in use; 2 shares ask for 309 GB -- more than the 288 GB of HBM (the driver "
+                         "oversubscribes into host memory: 2.7 s per pass), so the default stays 4.  The pools are trimmed between the "
+                         "configurations (fal_ctx_trim); a run with fewer shares that runs out of memory falls back to 4 and says so")
     ap.add_argument("--skew-spectra", type=int, default=2_000_000,
                     help="the skewed-workload entry of `configs` (synth skew=True: log-normal window occupancy, 5..50 peaks); 0 = skip")
     ap.add_argument("--partitions", choices=["auto", "concurrent", "pipelined"], default="auto",
@@ -686,9 +687,12 @@ def main():
                 try:
                     dtc = timed(big, ra, steps_c, 0 if slow else 1, prime=1 if slow else (3 if chunks == 1 else 2), chunks=chunks)
                 except Exception as e:
-                    if chunks != 2 or "memory" not in repr(e).lower():
+                    if chunks < 2 or chunks >= 4 or "memory" not in repr(e).lower():
                         raise
-                    chunks_note = f"2 shares ran out of device memory ({repr(e)[:120]}); ran in 4"
+                    chunks_note = f"{chunks} shares ran out of device memory ({repr(e)[:120]}); ran in 4"
+                    del e
+                    import gc
+                    gc.collect()
                     runner.trim()
                     pipe.trim()
                     chunks = 4
