@@ -27,29 +27,6 @@ struct List16Args {              // cf. ListScanArgs (scan.h); tiles = groups of
     int64_t n_rows;              // rows of X16 (row ids read past a list's end are clamped)
 };
 
-struct Select16Args {
-    const uint16_t* keys;
-    int64_t keys_base;
-    int k;
-    const DenseJob* jobs;        // IVF tile table (q_row0 = first list-order position of the bucket, c_row0 = its list 0)
-    int n_jobs;
-    int64_t tile_begin;
-    const int32_t* tile_job;     // (filled by launch_select16)
-    const int32_t* tile_p0;      // (filled by launch_select16) list-order position of a tile's first query
-    const int64_t* q_sim_off;
-    const int32_t* perm;
-    QThr* thr;                   // hand-off (fused.h), by sorted row
-    float* gmem_v;               // members: approximate value ...
-    uint32_t* gmem_id;           // ... and position in the query's key stream (resolve_kernel: -> row where needed)
-    int2* gsel;                  // optional [n] by sorted row: (smallest key + 1 a window candidate must reach to stay in the
-                                 // race, largest key + 1 that is still ambiguous) -- for kept16_kernel (pairs16.hip)
-    int64_t n_tiles;             // (filled by launch_select16)
-    int64_t max_keys;            // the most keys any query of the search has (picks the kernel form)
-    int32_t* big_count;          // queries with more than 2,048 keys: second pass with 64 keys per lane
-    int32_t* big_list;
-    int big_cap;
-};
-
 struct Kept16Args {              // pairs16.hip
     const uint16_t* keys;
     int64_t keys_base;
@@ -70,6 +47,33 @@ struct Kept16Args {              // pairs16.hip
     uint32_t* gkept_id;          // [n, FAL_FUSED_KEEP] kept candidates (sorted rows), entries 0 .. count - 1
     int32_t* gkcnt;              // [n, 2] count (first 32 | the rest) | 0x100 ambiguous | 0x200 more than the hand-off holds
 };
+
+struct Select16Args {
+    const uint16_t* keys;
+    int64_t keys_base;
+    int k;
+    const DenseJob* jobs;        // IVF tile table (q_row0 = first list-order position of the bucket, c_row0 = its list 0)
+    int n_jobs;
+    int64_t tile_begin;
+    const int32_t* tile_job;     // (filled by launch_select16)
+    const int32_t* tile_p0;      // (filled by launch_select16) list-order position of a tile's first query
+    const int64_t* q_sim_off;
+    const int32_t* perm;
+    QThr* thr;                   // hand-off (fused.h), by sorted row
+    float* gmem_v;               // members: approximate value ...
+    uint32_t* gmem_id;           // ... and position in the query's key stream (resolve_kernel: -> row where needed)
+    int2* gsel;                  // optional [n] by sorted row: (smallest key + 1 a window candidate must reach to stay in the
+                                 // race, largest key + 1 that is still ambiguous) -- for kept16_kernel (pairs16.hip)
+    int64_t n_tiles;             // (filled by launch_select16)
+    int64_t max_keys;            // the most keys any query of the search has (picks the kernel form)
+    const int64_t* tile_l0;      // (filled by launch_select16) global id of list 0 of a tile's bucket
+    int fuse_kept;               // 1: kept16_query (kept16.h) runs as the tail of every query's selection (single-pass searches)
+    Kept16Args kept;             // ... with these arguments (the caller then skips launch_kept16)
+    int32_t* big_count;          // queries with more than 2,048 keys: second pass with 64 keys per lane
+    int32_t* big_list;
+    int big_cap;
+};
+
 
 bool ivf16_supports(int d);
 int launch_gather_pmz(fal_ctx* ctx, const float* pmz, const int32_t* perm, int64_t n, float* out);

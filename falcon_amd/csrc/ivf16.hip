@@ -37,6 +37,7 @@
 #include "ivf.h"
 #include "fused.h"
 #include "ivf16.h"
+#include "kept16.h"
 
 namespace fal {
 
@@ -288,7 +289,7 @@ __device__ __forceinline__ int late_use(int v) {
 //  3. "members": the keys within 2e of T, as (value, stream position) -- resolve_kernel turns the positions into rows for the
 //     few queries that turn out to have an ambiguous window candidate (no probe table / list offsets / perm gathers here)
 template <int R>
-__device__ __forceinline__ void select16_body(const Select16Args& a, const uint16_t* __restrict__ row, int nc, int k, int lane,
+__device__ __forceinline__ int2 select16_body(const Select16Args& a, const uint16_t* __restrict__ row, int nc, int k, int lane,
                                               int out_row_loaded, uint32_t* hist) {
     constexpr int P = R / 8, W = R / 2;
     // Keys in 16-byte pieces (8 per load instruction and lane): the stream is read from the 16-byte boundary in front of it,
@@ -457,11 +458,12 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
         n_mem = 0;
     }
     t.mc = min(n_mem, FAL_FUSED_MEM / 2) | (max(n_mem - FAL_FUSED_MEM / 2, 0) << 16);
+    const int2 sel = make_int2((int)T + 1 - delta, (int)T + 1 + delta);      // (kept16: what a window candidate's key must reach | is ambiguous up to)
     if (lane == 0) {
         a.thr[out_row] = t;
-        if (a.gsel) a.gsel[out_row] = make_int2((int)T + 1 - delta, (int)T + 1 + delta);
+        if (a.gsel) a.gsel[out_row] = sel;
     }
-    if (n_mem == 0) return;
+    if (n_mem == 0) return sel;
     float* gv = a.gmem_v + out_row * FAL_FUSED_MEM;
     uint32_t* gi = a.gmem_id + out_row * FAL_FUSED_MEM;
     int base = 0;
@@ -482,9 +484,10 @@ __device__ __forceinline__ void select16_body(const Select16Args& a, const uint1
             }
         }
     }
+    return sel;
 }
 
-__device__ __forceinline__ void select16_trivial(const Select16Args& a, int out_row_loaded, int flags, int lane) {
+__device__ __forceinline__ int2 select16_trivial(const Select16Args& a, int out_row_loaded, int flags, int lane) {
     const int64_t out_row = late_use(out_row_loaded);
     if (lane == 0) {
         QThr t0{};
@@ -494,6 +497,7 @@ __device__ __forceinline__ void select16_trivial(const Select16Args& a, int out_
         a.thr[out_row] = t0;
         if (a.gsel) a.gsel[out_row] = make_int2(INT32_MIN, INT32_MIN);      // every window candidate stays, none is ambiguous
     }
+    return make_int2(INT32_MIN, INT32_MIN);
 }
 
 // BIG = false: one wave per query slot of the launch's tiles; queries with more keys than 32 per lane are appended to
@@ -527,13 +531,14 @@ __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
             const uint16_t* row = a.keys + (o0 - a.keys_base);
             const int k = a.k;
             const int span = nc + (int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1);      // keys from the 16-byte boundary in front
-            if (nc <= k) select16_trivial(a, out_row, 0, lane);  // every candidate is among the k best
+            int2 sel = make_int2(INT32_MAX, INT32_MIN);
+            if (nc <= k) sel = select16_trivial(a, out_row, 0, lane);  // every candidate is among the k best
             else if (!BIG) {
-                if (span <= 512) select16_body<8>(a, row, nc, k, lane, out_row, hist);
-                else if (span <= 1024) select16_body<16>(a, row, nc, k, lane, out_row, hist);
-                else if (span <= 1536) select16_body<24>(a, row, nc, k, lane, out_row, hist);
-                else if (span <= 2048) select16_body<32>(a, row, nc, k, lane, out_row, hist);
-                else if (WIDE && span <= 2560) select16_body<40>(a, row, nc, k, lane, out_row, hist);
+                if (span <= 512) sel = select16_body<8>(a, row, nc, k, lane, out_row, hist);
+                else if (span <= 1024) sel = select16_body<16>(a, row, nc, k, lane, out_row, hist);
+                else if (span <= 1536) sel = select16_body<24>(a, row, nc, k, lane, out_row, hist);
+                else if (span <= 2048) sel = select16_body<32>(a, row, nc, k, lane, out_row, hist);
+                else if (WIDE && span <= 2560) sel = select16_body<40>(a, row, nc, k, lane, out_row, hist);
                 else if (lane == 0) {
                     const int at = atomicAdd(a.big_count, 1);
                     if (at < a.big_cap) a.big_list[at] = (int32_t)slot;
@@ -542,18 +547,69 @@ __global__ __launch_bounds__(256) void select16_kernel(Select16Args a) {
                 if (span <= 4096) select16_body<64>(a, row, nc, k, lane, out_row, hist);
                 else select16_trivial(a, out_row, 2, lane);      // more keys than the registers hold: exact fallback
             }
+            (void)sel;
         }
         if (!BIG) return;
     }
 }
 
+// select16_kernel<false, false> + kept16_kernel in one (round 6, `FALCON_KEPT16=fused`): a wave takes FOUR consecutive query
+// slots of a tile, brackets their k-th keys one after the other (select16_body), then runs kept16_query once with its four
+// 16-lane groups on the four queries -- the thresholds stay in registers, and the window gathers of kept16 (latency) sit in the
+// same kernel as the selections (VALU).  Single-pass searches only (no query above 2,048 keys).
+__global__ __launch_bounds__(256) void select16k_kernel(Select16Args a) {
+    __shared__ __attribute__((aligned(16))) uint32_t hist_all[4][256 * kSelect16Copies];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4;
+    uint32_t* hist = hist_all[w];
+    const int64_t g = (int64_t)blockIdx.x * 4 + w;              // group of four slots
+    if (g >= 8 * a.n_tiles) return;
+    const int64_t slot0 = 32 * a.tile_begin + 4 * g;
+    const int64_t t = slot0 >> 5;
+    const int32_t p0 = a.tile_p0[t - a.tile_begin];
+    const int64_t l0 = a.tile_l0[t - a.tile_begin];
+    int64_t off[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) off[i] = a.q_sim_off[slot0 + i];
+    bool live_g = false;
+    int64_t p_g = 0, row_g = 0;
+    const uint16_t* krow_g = a.keys;
+    int2 sel_g = make_int2(INT32_MAX, INT32_MIN);
+#pragma unroll 1
+    for (int qi = 0; qi < 4; ++qi) {
+        const int64_t slot = slot0 + qi;
+        const int64_t o0 = qi == 0 ? off[0] : qi == 1 ? off[1] : qi == 2 ? off[2] : off[3];
+        const int64_t o1 = qi == 0 ? off[1] : qi == 1 ? off[2] : qi == 2 ? off[3] : off[4];
+        const int nc = (int)(o1 - o0);
+        if (nc <= 0) continue;                                   // (padding slot of a bucket's last tile)
+        const int out_row = a.perm[(int64_t)p0 + (slot & 31)];
+        const uint16_t* row = a.keys + (o0 - a.keys_base);
+        const int k = a.k;
+        const int span = nc + (int)((reinterpret_cast<uintptr_t>(row) & 15) >> 1);
+        int2 sel;
+        if (nc <= k) sel = select16_trivial(a, out_row, 0, lane);
+        else if (span <= 512) sel = select16_body<8>(a, row, nc, k, lane, out_row, hist);
+        else if (span <= 1024) sel = select16_body<16>(a, row, nc, k, lane, out_row, hist);
+        else if (span <= 1536) sel = select16_body<24>(a, row, nc, k, lane, out_row, hist);
+        else sel = select16_body<32>(a, row, nc, k, lane, out_row, hist);        // (span <= 2,048: the launcher's condition)
+        if (grp == qi) {
+            live_g = true;
+            p_g = (int64_t)p0 + (slot & 31);
+            row_g = out_row;
+            krow_g = row;
+            sel_g = sel;
+        }
+    }
+    kept16_query(a.kept, live_g, p_g, row_g, l0, krow_g, sel_g, lane);
+}
+
 __global__ void tile_job16_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t tile_begin, int64_t n_tiles,
-                                  int32_t* __restrict__ tile_job, int32_t* __restrict__ tile_p0) {
+                                  int32_t* __restrict__ tile_job, int32_t* __restrict__ tile_p0, int64_t* __restrict__ tile_l0) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n_tiles) {
         const int j = find_job(jobs, n_jobs, tile_begin + i);
         tile_job[i] = j;
         tile_p0[i] = (int32_t)(jobs[j].q_row0 + 32 * (tile_begin + i - jobs[j].tile0));      // list-order position of the tile's query 0
+        tile_l0[i] = jobs[j].c_row0;                                                        // global id of its bucket's list 0
     }
 }
 
@@ -616,21 +672,28 @@ int launch_select16(fal_ctx* ctx, const Select16Args& a_in, int64_t n_tiles) {
     // tile -> job table, then the list of queries with more than 2,048 keys (count in front)
     int32_t* tj = nullptr;
     ctx->release(SLOT_TILEJOB);        // a launcher-local table: the previous launcher's pointer is dead
-    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(n_tiles, 1 << 16) + 33 * n_tiles + 64), (void**)&tj));
+    FAL_TRY(ctx->reserve(SLOT_TILEJOB, sizeof(int32_t) * (size_t)(std::max<int64_t>(n_tiles, 1 << 16) + 35 * n_tiles + 64 + 4), (void**)&tj));
     a.big_count = tj + std::max<int64_t>(n_tiles, 1 << 16);
     a.big_list = a.big_count + 16;
     int32_t* tp0 = a.big_list + 32 * n_tiles;
+    int64_t* tl0 = reinterpret_cast<int64_t*>(tj + ((std::max<int64_t>(n_tiles, 1 << 16) + 33 * n_tiles + 16 + 1) & ~(int64_t)1));      // (8-byte aligned)
     a.big_cap = (int)std::min<int64_t>(32 * n_tiles, INT32_MAX);
     FAL_REQUIRE(n_tiles * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many queries in one select launch");
     StageScope ts(ctx, ST_SELECT);
     FAL_CHECK_HIP(hipMemsetAsync(a.big_count, 0, sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(tile_job16_kernel, dim3((unsigned)ceil_div(n_tiles, 256)), dim3(256), 0, ctx->stream, a.jobs, a.n_jobs,
-                       a.tile_begin, n_tiles, tj, tp0);
+                       a.tile_begin, n_tiles, tj, tp0, tl0);
     a.tile_job = tj;
     a.tile_p0 = tp0;
-    if (a.max_keys > 2048) hipLaunchKernelGGL((select16_kernel<false, true>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
+    a.tile_l0 = tl0;
+    // (a query's keys are read from the 16-byte boundary in front of its stream: up to 7 keys more than it has)
+    const bool two_pass = a.max_keys + 7 > 2048;
+    if (two_pass) a.fuse_kept = 0;                        // (kept16_kernel follows the second pass: launch_kept16)
+    a.kept.tile_job = tj;
+    if (two_pass) hipLaunchKernelGGL((select16_kernel<false, true>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
+    else if (a.fuse_kept) hipLaunchKernelGGL(select16k_kernel, dim3((unsigned)(n_tiles * 2)), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL((select16_kernel<false, false>), dim3((unsigned)(n_tiles * 8)), dim3(256), 0, ctx->stream, a);
-    if (a.max_keys > 2048)
+    if (two_pass)
         hipLaunchKernelGGL((select16_kernel<true, false>), dim3((unsigned)(ctx->num_cus * 4)), dim3(256), 0, ctx->stream, a);
     FAL_CHECK_HIP(hipGetLastError());
     return FAL_OK;

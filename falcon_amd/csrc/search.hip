@@ -8,6 +8,7 @@
 // the buffer's HBM round trip costs; measured 160 MiB: 4.5 ms, 1 GiB: 3.5 ms of scan at 1 M spectra).
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 #include "scan.h"
 #include "ivf.h"
@@ -740,21 +741,26 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             la.tile_begin = lt_host[(size_t)L0]; la.n_tiles_max = lt_host[(size_t)L1] - lt_host[(size_t)L0];
             la.keys = keys; la.keys_base = base; la.sink = keys + need_fine; la.n_rows = ivf->n;
             FAL_TRY(launch_list16(ctx, la));
+            Kept16Args ka{};
+            ka.keys = keys; ka.keys_base = base; ka.jobs = coarse_dev; ka.tile_begin = t0; ka.n_probe = np;
+            ka.probes = probes; ka.list_off = ivf->list_off; ka.q_sim_off = q_sim_off; ka.perm = ivf->perm; ka.pmz_l = pmz_l;
+            ka.rt = nf->rt; ka.tol = nf->tol; ka.rt_tol = nf->rt_tol; ka.tol_f = fa.tol_f; ka.rt_f = fa.rt_f; ka.is_da = nf->is_da;
+            ka.gsel = gsel; ka.gkept_id = fa.gkept_id; ka.gkcnt = fa.gkcnt;
+            ka.n_tiles = t1 - t0;
             Select16Args sa{};
             sa.keys = keys; sa.keys_base = base; sa.k = k_ann; sa.jobs = coarse_dev; sa.n_jobs = (int)coarse.size();
             sa.tile_begin = t0; sa.q_sim_off = q_sim_off;
             sa.perm = ivf->perm; sa.thr = fa.thr; sa.gmem_v = fa.gmem_v; sa.gmem_id = fa.gmem_id;
             sa.max_keys = max_total;
             sa.gsel = gsel;
+            // FALCON_KEPT16=fused (A/B switch, read per launch; single-pass searches -- no query above 2,048 keys): kept16 as the
+            // tail of the selection kernel, four queries per wave (select16k_kernel)
+            const char* ke = getenv("FALCON_KEPT16");
+            const bool fuse_kept = max_total + 7 <= 2048 && ke && !strcmp(ke, "fused");
+            sa.fuse_kept = fuse_kept ? 1 : 0;
+            sa.kept = ka;
             FAL_TRY(launch_select16(ctx, sa, t1 - t0));
-            {
-                Kept16Args ka{};
-                ka.keys = keys; ka.keys_base = base; ka.jobs = coarse_dev; ka.tile_begin = t0; ka.n_probe = np;
-                ka.probes = probes; ka.list_off = ivf->list_off; ka.q_sim_off = q_sim_off; ka.perm = ivf->perm; ka.pmz_l = pmz_l;
-                ka.rt = nf->rt; ka.tol = nf->tol; ka.rt_tol = nf->rt_tol; ka.tol_f = fa.tol_f; ka.rt_f = fa.rt_f; ka.is_da = nf->is_da;
-                ka.gsel = gsel; ka.gkept_id = fa.gkept_id; ka.gkcnt = fa.gkcnt;
-                FAL_TRY(launch_kept16(ctx, ka, t1 - t0));
-            }
+            if (!fuse_kept) FAL_TRY(launch_kept16(ctx, ka, t1 - t0));
         }
         FAL_TRY(launch_pairs16(ctx, fa, d, *std::max_element(xt32, xt32 + 8)));
         FAL_TRY(launch_fused_ivf_tail(ctx, fa, d, *std::max_element(xt32, xt32 + 8), max_cand));

@@ -348,9 +348,12 @@ def test_list16s_sparse_query_records_give_the_staged_lists(ctx, monkeypatch, d,
     sim, idx = plain.search(n_probe, k_ann)
     e_idx, e_dist = ctx.filter_neighbors(sim, idx, mz_d, rt_d, tol, mode, rt_tol, keep)
     out = {}
-    for form in ("s", "d"):
+    for form in ("s", "d", "fused"):
         if form == "d":
             monkeypatch.setenv("FALCON_LIST16", "d")
+        if form == "fused":                    # kept16 as the tail of the selection kernel (select16k_kernel: round 6 A/B switch)
+            monkeypatch.delenv("FALCON_LIST16")
+            monkeypatch.setenv("FALCON_KEPT16", "fused")
         pre = ctx.ivf_build(Xd, off, nl, Xpre=x16, Xkm=x16, prefilter_which=2)       # (Xkm: the build sees float16 rows -> records)
         g_idx, g_dist = pre.search_neighbors(n_probe, k_ann, mz_d, rt_d, tol, mode, rt_tol, keep)
         ctx.sync()
