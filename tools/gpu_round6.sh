@@ -43,8 +43,8 @@ if [ "$what" = pmc ]; then
   FALCON_PMC_OUT=r6_pmc_traffic.json bash tools/pmc_traffic.sh
 fi
 if [ "$what" = parity ]; then
-  (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3) > $O/r6_gpu_suite_final.txt; tail -1 $O/r6_gpu_suite_final.txt
-  (FALCON_DEBUG_POISON=1 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3) > $O/r6_gpu_suite_under_poison.txt; tail -1 $O/r6_gpu_suite_under_poison.txt
+  (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|rror" | tail -3) > $O/r6_gpu_suite_final.txt; tail -1 $O/r6_gpu_suite_final.txt
+  (FALCON_DEBUG_POISON=1 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|rror" | tail -3) > $O/r6_gpu_suite_under_poison.txt; tail -1 $O/r6_gpu_suite_under_poison.txt
   timeout 1500 python tools/fuzz_parity.py 70 60606 > $O/r6_fuzz_parity.txt 2>&1; tail -1 $O/r6_fuzz_parity.txt; grep -c "^OK" $O/r6_fuzz_parity.txt
   (FALCON_STRESS_REPS=600 timeout 1500 python -m pytest tests/test_gpu_stress.py -q 2>&1 | tail -2) > $O/r6_stress_600.txt; tail -1 $O/r6_stress_600.txt
 fi
