@@ -48,6 +48,10 @@ struct SelectArgs {
 bool dense4_supports(int d);
 int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, const DenseJob* jobs_host, int n_jobs, float* sims,
                   int64_t sims_base);
+// the same scan with the query tile split along K between two waves per tile: two waves per SIMD (dense4ab.hip; low_dim 400)
+bool dense4ab_supports(int d);
+int launch_dense4ab(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, const DenseJob* jobs_host, int n_jobs, float* sims,
+                    int64_t sims_base);
 int launch_dense_tiny4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base);
 // flat buckets of fewer than 64 rows at low_dim > 512: exact fmaf chains on the vector ALU (scan.hip)
 int launch_flat_exact_small(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, int n_jobs, float* sims, int64_t sims_base);

@@ -5,6 +5,7 @@
 // snapshot).  See simtile.h for the tile algorithm, DESIGN.md for the roofline.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include "common.h"
 #include "simtile.h"
@@ -476,6 +477,10 @@ bool dense4_supports(int d) { return d % 8 == 0 && d >= 32 && (d <= 400 || (d > 
 int launch_dense4(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, const DenseJob* jobs_host, int n_jobs, float* sims,
                   int64_t sims_base) {
     if (n_jobs <= 0) return FAL_OK;
+    {
+        const char* e = getenv("FALCON_DENSE4");              // "ab": the two-waves-per-SIMD form (dense4ab.hip), read per launch
+        if (e && !strcmp(e, "ab") && dense4ab_supports(d)) return launch_dense4ab(ctx, X, d, jobs, jobs_host, n_jobs, sims, sims_base);
+    }
     const bool split = d > 512;
     const int dv = split ? d / 2 : d;                        // columns one pass sees
     const int dh4 = dv / 8;

@@ -47,6 +47,25 @@ def test_flat_exhaustive_topk(ctx, d, k):
     assert np.array_equal(idx[a, :5], np.arange(a, a + 5))
 
 
+def test_dense4ab_two_waves_per_simd_form_gives_the_same_similarities(ctx, monkeypatch):
+    """`FALCON_DENSE4=ab` (dense4ab.hip, round 6): the flat scan with the query tile split along K between two waves per tile --
+    wave A runs the first half of every block's chain, hands the accumulators over through LDS, wave B finishes and stores.
+    Same chain, same stores: similarities, ids and tie order of the oracle, bit for bit (low_dim 400; groups with idle tiles,
+    partial last tiles, one-chunk and many-chunk buckets)."""
+    import torch
+    monkeypatch.setenv("FALCON_DENSE4", "ab")
+    sizes = [33, 100, 128, 129, 257, 700, 1500, 64, 4000, 31]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    X = unit_vectors(off[-1], 400, 5)
+    X[off[4]:off[4] + 5] = X[off[4]]
+    idxr = ctx.ivf_build(torch.from_numpy(X).to(ctx.tdev), off, np.ones(len(sizes), np.int32))
+    sim, idx = idxr.search(16, 128)
+    sim, idx = sim.cpu().numpy(), idx.cpu().numpy()
+    for a, b in zip(off[:-1], off[1:]):
+        rs, ri = fo.exhaustive_topk(X[a:b], 128, base=a)
+        assert_topk_exact(sim[a:b], idx[a:b], rs, ri, what=f"bucket {a}:{b}")
+
+
 def test_small_flat_buckets_beyond_low_dim_512_are_exact(ctx):
     """float16 vectors at low_dim 800 (BASELINE configs[4]): flat buckets of fewer than 64 rows are scanned by exact fmaf chains on
     the vector ALU (flat_exact_small_kernel) -- similarities bit-identical to the oracle's chain over the float32 images of the

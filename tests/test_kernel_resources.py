@@ -28,6 +28,7 @@ def asm_dir(tmp_path_factory):
     ("scan.hip", "dense_kernel", 10),          # DH4 in {8,16,32,50,64} x {store, arg-max}
     ("scan.hip", "dense4_kernel", 6),          # the shared-stream flat scan: DH4 in {8,16,32,50} + the two K-half passes of DH4 = 50
     ("scan.hip", "dense_tiny4_kernel", 4),
+    ("dense4ab.hip", "dense4ab_kernel", 1),
     ("scan16.hip", "scan16_kernel", 10),
     ("ivf_fine.hip", "ivf_list4_kernel", 7),   # DH4 in {8,16,32,50,64} + the two K-half passes
     ("ivf16.hip", "list16_kernel", 5),
@@ -53,7 +54,7 @@ def _dma_sources():
 
 
 def test_dma_sources_are_the_known_ones():
-    assert _dma_sources() == ["assign.hip", "ivf16.hip", "ivf_fine.hip", "list16s.hip", "scan.hip"]
+    assert _dma_sources() == ["assign.hip", "dense4ab.hip", "ivf16.hip", "ivf_fine.hip", "list16s.hip", "scan.hip"]
 
 
 @pytest.mark.parametrize("src", _dma_sources())
