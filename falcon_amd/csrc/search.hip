@@ -386,42 +386,57 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     }
     // a batch = jobs [j0, j1): [j0, jm) go to the f16-MFMA kernel (128-query tiles), [jm, jk) to the shared-stream fp32 kernel
     // (groups of four 32-query tiles), [jk, j1) to the one-wave fp32 kernel
-    struct FlatBatch { size_t j0, jm, jk, j1; int64_t tiles, list_tiles16, list_tiles32, floats; };
+    // (round 6: [js, jk) -- buckets of 33 .. small_max rows -- to the ONE-WAVE fp32 kernel, a wave per 32-query tile with no staircase
+    //  to wait in: dense4_kernel's four lockstep waves idle half of their steps on buckets of two or three tiles)
+    struct FlatBatch { size_t j0, jm, js, jk, j1; int64_t tiles, list_tiles16, list_tiles32, list_tiles1, floats; };
     std::vector<FlatBatch> flat_batches;
     size_t need_flat = 0;
     const bool have16 = ivf->X16 != nullptr;
     const bool have4 = ivf->X && dense4_supports(d);       // the shared-stream fp32 kernels (scan.hip)
+    static const int small_max_env = [] {
+        const char* e = getenv("FALCON_DENSE1_MAX");
+        return e ? atoi(e) : 0;
+    }();
+    const int64_t small_max = (have4 && d <= 512) ? std::max(32, small_max_env) : 32;      // (no one-wave fp32 kernel beyond 512 columns)
     const int64_t thr16 = ivf->X ? 64 : 0;                 // without float32 rows everything takes the f16 kernel; buckets below it: the fp32
                                                            // matrix kernels up to low_dim 512, exact chains on the vector ALU beyond
     FAL_REQUIRE(have16 || ivf->X || border.empty(), FAL_EINVAL, "fal_ivf_search_topk: the index has no vectors to scan");
     {
-        FlatBatch cur{0, 0, 0, 0, 0, 0, 0, 0};
-        int64_t xt16[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        FlatBatch cur{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t xt16[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt32[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xt1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         auto close = [&]() {
             if (cur.j1 > cur.j0) {
                 cur.list_tiles16 = *std::max_element(xt16, xt16 + 8);
                 cur.list_tiles32 = *std::max_element(xt32, xt32 + 8);
+                cur.list_tiles1 = *std::max_element(xt1, xt1 + 8);
                 flat_batches.push_back(cur);
                 need_flat = std::max(need_flat, (size_t)cur.floats);
             }
-            cur = FlatBatch{cur.j1, cur.j1, cur.j1, cur.j1, 0, 0, 0, 0};
+            cur = FlatBatch{cur.j1, cur.j1, cur.j1, cur.j1, cur.j1, 0, 0, 0, 0, 0};
             std::fill(xt16, xt16 + 8, 0);
             std::fill(xt32, xt32 + 8, 0);
+            std::fill(xt1, xt1 + 8, 0);
         };
         for (int64_t b : border) {
             const int64_t row0 = ivf->bucket_off[b], nb = ivf->bucket_off[b + 1] - row0;
             const int64_t tiles = ceil_div(nb, 32), floats = tiles * 32 * ((nb + 31) & ~31ll);
             if (cur.floats + floats > (int64_t)cap && cur.j1 > cur.j0) close();
             const bool use16 = have16 && nb >= thr16;      // sizes are non-increasing: the f16 part is a prefix ...
-            const bool use4 = !use16 && have4 && nb > 32;  // ... and the shared-stream part follows it; then the one-block buckets
+            const bool use4 = !use16 && have4 && nb > small_max;  // ... and the shared-stream part follows it; then the small ones
+            const bool use1 = !use16 && !use4 && have4 && nb > 32;      // ... the one-wave part; then the one-block buckets
             int64_t xtile0;
             if (use16) {
                 const int x = (int)((cur.j1 - cur.j0) & 7);
                 xtile0 = xt16[x];
                 xt16[x] += ceil_div(nb, 128);
-                cur.jm = cur.jk = cur.j1 + 1;
+                cur.jm = cur.js = cur.jk = cur.j1 + 1;
             } else if (use4) {
                 xtile0 = 0;                                  // (launch_dense4 lists the groups of these jobs itself)
+                cur.js = cur.jk = cur.j1 + 1;
+            } else if (use1) {
+                const int x = (int)((cur.j1 - cur.js) & 7);
+                xtile0 = xt1[x];
+                xt1[x] += tiles;
                 cur.jk = cur.j1 + 1;
             } else {
                 const int x = (int)((cur.j1 - cur.jk) & 7);
@@ -506,8 +521,11 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             FAL_TRY(launch_scan16(ctx, ivf->x16_planes, ivf->X16, d, jb, (int)(fb.jm - fb.j0), fb.list_tiles16, buf, 0,
                                   buf + sims_floats));
         // (flat buckets keep their rows' positions in list order: the sorted rows serve)
-        if (fb.jk > fb.jm)
-            FAL_TRY(launch_dense4(ctx, ivf->X, d, flat_dev + fb.jm, flat.data() + fb.jm, (int)(fb.jk - fb.jm), buf, 0));
+        if (fb.js > fb.jm)
+            FAL_TRY(launch_dense4(ctx, ivf->X, d, flat_dev + fb.jm, flat.data() + fb.jm, (int)(fb.js - fb.jm), buf, 0));
+        if (fb.jk > fb.js)
+            FAL_TRY(launch_dense(ctx, ST_SCAN, EPI_STORE, ivf->X, ivf->X, d, flat_dev + fb.js, (int)(fb.jk - fb.js), 0, fb.tiles, buf, 0,
+                                 nullptr, fb.list_tiles1));
         if (fb.j1 > fb.jk && d > 512)
             FAL_TRY(launch_flat_exact_small(ctx, ivf->X, d, flat_dev + fb.jk, (int)(fb.j1 - fb.jk), buf, 0));
         else if (fb.j1 > fb.jk && have4)
