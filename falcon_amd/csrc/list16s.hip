@@ -43,8 +43,12 @@ namespace fal {
 
 typedef _Float16 half8s __attribute__((ext_vector_type(8)));
 
-template <int STEPS>
+// KN: timing experiments with WRONG results (FALCON_L16_KNOCK, tools/list16_ab.py): 1 = no key stores, 2 = four 8-byte stores per
+// lane at addresses rounded down to 8 bytes (the store shape a padded key stream would allow, without the transposition),
+// 3 = 2 + a wave-private LDS transposition in quarter rounds in front of them
+template <int STEPS, int KN = 0>
 __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16Args a) {
+    constexpr int kStores = KN == 0 ? 16 : KN == 1 ? 0 : 4;
     constexpr int D = STEPS * 16, DH = D / 2;
     constexpr int kRowOps = 2;                            // row DMAs per step and wave (4 records of 256 B each)
     constexpr int NB = STEPS < 4 ? STEPS : 4;             // LDS operand reads in flight ahead of the MFMAs
@@ -55,6 +59,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
     __shared__ __attribute__((aligned(16))) unsigned char stage1[32 * 256];
     __shared__ __attribute__((aligned(16))) unsigned char stage2[32 * 256];
     __shared__ int32_t meta[8][64];                       // per chunk: [0, 32) sorted row of query r, [32, 64) its destination (low dword)
+    __shared__ __attribute__((aligned(16))) unsigned char xpose[KN == 3 ? 4 * 576 : 16];
     const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
     const int64_t lt = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= per_xcd) return;
@@ -152,6 +157,29 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
     };
     auto epilogue = [&]() {
         const int left = nq - 32 * prev_c - 4 * h;         // queries q0 < left of this chunk exist (all 32, except in a list's last chunk)
+        if (KN == 1) return;
+        if (KN >= 2) {
+            const int32_t* md = &meta[prev_c & 7][32];
+            unsigned char* xp = xpose + (KN == 3 ? 576 * w : 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qi = 8 * g + (lane >> 3);
+                uint32_t off = ((((uint32_t)md[qi] << 1) + 2u * ((uint32_t)(32 * slice) - base_lo)) & ~7u) + 8u * (uint32_t)(lane & 7);
+                off = (active && 4 * (lane & 7) < nrow && qi < nq - 32 * prev_c) ? off : (sink_off & ~7u);
+                uint2 v = make_uint2(pk[2 * g], pk[2 * g + 1]);
+                if (KN == 3) {
+                    // D[query (i & 3) + 4 h of this round][list row r] -> [8 queries][32 rows + pad] of 2 bytes
+                    unsigned char* wp = xp + (4 * h) * 72 + 2 * r;
+                    *reinterpret_cast<uint16_t*>(wp) = (uint16_t)(v.x & 0xFFFFu);
+                    *reinterpret_cast<uint16_t*>(wp + 72) = (uint16_t)(v.x >> 16);
+                    *reinterpret_cast<uint16_t*>(wp + 144) = (uint16_t)(v.y & 0xFFFFu);
+                    *reinterpret_cast<uint16_t*>(wp + 216) = (uint16_t)(v.y >> 16);
+                    v = *reinterpret_cast<const uint2*>(xp + (lane >> 3) * 72 + 8 * (lane & 7));
+                }
+                asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(a.keys) : "memory");
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int q0 = (i & 3) + 8 * (i >> 2);
@@ -194,8 +222,8 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
     // front of step c needs the wave's OWN records of chunk c + 1 (issued first thing in step c - 2): everything issued after them
     // may stay in flight -- (16 + 1) of step c - 2 and (kRowOps + 16 + 1) of step c - 1.  The metadata read by step c's row DMAs
     // (chunk c + 3: issued last in step c - 3) is older than that.  Steps 0 and 1 have less behind them.
-    constexpr int kAllow = (16 + 1) + (kRowOps + 16 + 1), kAllowIdle = 1 + (kRowOps + 1);
-    constexpr int kFirst = kRowOps + 16 + 1, kFirstIdle = kRowOps + 1;
+    constexpr int kAllow = (kStores + 1) + (kRowOps + kStores + 1), kAllowIdle = 1 + (kRowOps + 1);
+    constexpr int kFirst = kRowOps + kStores + 1, kFirstIdle = kRowOps + 1;
     uint32_t prev0[4], prev1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) prev0[j] = prev1[j] = (uint32_t)(2 * D) | ((uint32_t)(2 * D) << 16);     // (the dump slot of row 0)
@@ -269,7 +297,15 @@ int launch_list16s(fal_ctx* ctx, const List16Args& a) {
         case 4: hipLaunchKernelGGL((list16s_kernel<4>), grid, block, 0, ctx->stream, a); break;
         case 8: hipLaunchKernelGGL((list16s_kernel<8>), grid, block, 0, ctx->stream, a); break;
         case 16: hipLaunchKernelGGL((list16s_kernel<16>), grid, block, 0, ctx->stream, a); break;
-        case 25: hipLaunchKernelGGL((list16s_kernel<25>), grid, block, 0, ctx->stream, a); break;
+        case 25: {
+            const char* ke = getenv("FALCON_L16_KNOCK");      // timing experiments (wrong results)
+            const int kn = ke ? atoi(ke) : 0;
+            if (kn == 1) hipLaunchKernelGGL((list16s_kernel<25, 1>), grid, block, 0, ctx->stream, a);
+            else if (kn == 2) hipLaunchKernelGGL((list16s_kernel<25, 2>), grid, block, 0, ctx->stream, a);
+            else if (kn == 3) hipLaunchKernelGGL((list16s_kernel<25, 3>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((list16s_kernel<25>), grid, block, 0, ctx->stream, a);
+            break;
+        }
         case 50: hipLaunchKernelGGL((list16s_kernel<50>), grid, block, 0, ctx->stream, a); break;
         default:
             set_error("list16s: low_dim %d has no instantiation (64, 128, 256, 400, 800)", a.d);

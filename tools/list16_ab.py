@@ -31,8 +31,12 @@ STAGES = ("vectorize", "build", "coarse", "scan", "select", "filter", "dbscan", 
 
 
 def one_pass(form):
+    os.environ.pop("FALCON_L16_KNOCK", None)
     if form == "lockstep":
         os.environ.pop("FALCON_LIST16", None)
+    elif form[0] == "k":             # k1 / k2 / k3: the default form with FALCON_L16_KNOCK (timing experiments, wrong results)
+        os.environ.pop("FALCON_LIST16", None)
+        os.environ["FALCON_L16_KNOCK"] = form[1:]
     else:
         os.environ["FALCON_LIST16"] = form
     tot = {k: 0.0 for k in STAGES}
