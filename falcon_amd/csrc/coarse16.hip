@@ -208,10 +208,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
     const int np = a.np;
     auto gcount = [&](bool pred) -> int { return __popc((uint32_t)(__ballot(pred) >> sh) & 0xFFFFu); };
     auto id_of = [&](int x) -> int { return (16 * (x >> 3) + sub) * 8 + (x & 7); };
-    uint32_t hi[4], mem[4];
-    int need[4], nmem[4], want[4];
-    int64_t pq[4];
-    bool emit[4], amb[4];
+    // The rounds' results wait in LDS for the rank-and-emit phase (per lane: the masks of its keys above / within the bound; per
+    // query: the counts).  Held in registers across the round of exact chains they were spilled: 49 dwords per lane at the
+    // 96-register cap = 12.5 KB of scratch written (and read back) per wave -- 7.8 GB of the 9.1 GB this kernel wrote per 10 M
+    // pass for 1.3 GB of probe lists (round 6, profiles/NOTES.md).
+    __shared__ uint32_t s_hi[4][64], s_mem[4][64];
+    __shared__ int32_t q_need[16], q_nmem[16], q_flag[16];                    // flag: 1 emit, 2 ambiguous
     // The wave's 16 queries are consecutive slots of ONE tile: one job lookup, one load of their sorted rows (lane = query), and --
     // with 8 keys per lane -- the keys of all four rounds in flight before the first is worked on (the first form paid the chain
     // tile -> job -> perm -> keys once per round).
@@ -307,6 +309,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
             q_cnt[qi] = ambiguous ? n_mem : 0;
             q_row[qi] = row;
             q_cbase[qi] = job.c_row0;
+            q_need[qi] = nd;
+            q_nmem[qi] = n_mem;
+            q_flag[qi] = ((live && wnt > 0 && !handed) ? 1 : 0) | (ambiguous ? 2 : 0);
         }
         int base = 0;
 #pragma unroll
@@ -316,17 +321,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
             if (m1) m_id[qi][base + __popc(gm & ((1u << sub) - 1u))] = id_of(j);
             base += __popc(gm);
         }
-        hi[rd] = h; mem[rd] = m; need[rd] = nd; nmem[rd] = n_mem; want[rd] = wnt; pq[rd] = p;
-        emit[rd] = live && wnt > 0 && !handed; amb[rd] = ambiguous;
+        s_hi[rd][lane] = h;
+        s_mem[rd][lane] = m;
         if (live && !handed)
             for (int i = wnt + sub; i < np; i += 16) a.probes[p * np + i] = -1;
     }
     wave_lds_sync();
     {
-        int off[17];
+        int off[17];                                                 // (wave-uniform: scalar registers)
         off[0] = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) off[k + 1] = off[k] + q_cnt[k];
+        for (int k = 0; k < 16; ++k) off[k + 1] = off[k] + __builtin_amdgcn_readfirstlane(q_cnt[k]);
         if (a.sp_cols == nullptr) {
             for (int i = lane; i < off[16]; i += 64) {
                 int k = 0;
@@ -368,28 +373,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KPL == 8 ? 5
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
         const int qi = 4 * rd + grp;
-        uint32_t m = mem[rd];
-        if (amb[rd]) {
+        uint32_t m = s_mem[rd][lane];
+        const uint32_t h = s_hi[rd][lane];
+        const int flag = q_flag[qi], n_mem = q_nmem[qi], nd = q_need[qi];
+        if (flag & 2) {
 #pragma unroll
             for (int j = 0; j < KPL; ++j) {
                 if (!((m >> j) & 1u)) continue;
                 const int me = id_of(j);
                 float mine = 0.f;
-                for (int i = 0; i < nmem[rd]; ++i) mine = m_id[qi][i] == me ? m_val[qi][i] : mine;
+                for (int i = 0; i < n_mem; ++i) mine = m_id[qi][i] == me ? m_val[qi][i] : mine;
                 int rank = 0;
-                for (int i = 0; i < nmem[rd]; ++i) {
+                for (int i = 0; i < n_mem; ++i) {
                     const float v = m_val[qi][i];
                     const int id = m_id[qi][i];
                     rank += (v > mine || (v == mine && id < me)) ? 1 : 0;
                 }
-                if (rank >= need[rd]) m &= ~(1u << j);
+                if (rank >= nd) m &= ~(1u << j);
             }
         }
-        int32_t* out = a.probes + pq[rd] * np;
+        int32_t* out = a.probes + (qi < n_live ? p0 + qi : 0) * np;
         int base = 0;
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
-            const bool in = emit[rd] && (((hi[rd] | m) >> j) & 1u);
+            const bool in = (flag & 1) && (((h | m) >> j) & 1u);
             const uint32_t gm = (uint32_t)(__ballot(in) >> sh) & 0xFFFFu;
             if (in) out[base + __popc(gm & ((1u << sub) - 1u))] = id_of(j);
             base += __popc(gm);
@@ -752,6 +759,7 @@ int launch_coarse16(fal_ctx* ctx, const Coarse16Args& a_in) {
     FAL_CHECK_HIP(hipMemsetAsync(a.ovf_count, 0, sizeof(int32_t), ctx->stream));
     const unsigned list_grid = (unsigned)std::min<int64_t>(a.n_tiles * 4, (int64_t)ctx->num_cus * 16);
     if (a.stride <= 128) {
+        // (five waves per SIMD with 28 dwords per lane of spills left beats four with 8: coarse stage 6.5 vs 6.85 ms per 10 M)
         hipLaunchKernelGGL((coarse16w_kernel<8>), dim3((unsigned)(a.n_tiles * 2)), dim3(64), 0, ctx->stream, a);
         hipLaunchKernelGGL((coarse16_kernel<8, 16>), dim3(list_grid), dim3(256), 0, ctx->stream, a);
     } else if (a.stride > 512) {
