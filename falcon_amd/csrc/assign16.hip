@@ -57,7 +57,7 @@ struct Assign16Args {
     float* part_b;           // [n_sub, n] best value of subgroup sg = 4 * group + wave (n_sub = the launch's most lists / 32)
     float* part_s;           // [n_sub, n] its runner-up
     int32_t* part_id;        // [n_sub, n] bucket-local id of its best
-    int64_t n;               // rows (stride of the partial arrays)
+    int64_t n;               // rows of the merge buckets (stride of the partial arrays; a row's index: job.part0 + row - job.row0)
     const AssignJob* mjobs;  // merge jobs: (row segment) x (ALL lists of the bucket); the exact kernels' entries refer to these
     int64_t n_mjobs;
     const uint16_t* sp_cols; // optional [n, 64] the rows' sparse form (ivf.h): assign_exact_rows_kernel walks a row's entries
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void assign16_kernel(Assig
             const int g = job.id_base >> 7;
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww) {
-                const int64_t at = (int64_t)(4 * g + ww) * a.n + row;
+                const int64_t at = (int64_t)(4 * g + ww) * a.n + (job.part0 + c0 + lane);
                 a.part_b[at] = r_best[par][ww][lane];
                 a.part_s[at] = r_second[par][ww][lane];
                 a.part_id[at] = job.id_base + r_id[par][ww][lane];
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void assign_exact_rows_kernel(Assign16Args a, c
             float pb = -INFINITY, ps = -INFINITY;
             int pid = 0;
             if (lane < nsg) {
-                const int64_t at = (int64_t)lane * a.n + row;
+                const int64_t at = (int64_t)lane * a.n + (job.part0 + (row - job.row0));
                 pb = a.part_b[at];
                 ps = a.part_s[at];
                 pid = a.part_id[at];
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void assign16_merge_kernel(Assign16Args a, int
         int ti[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
         float rest = -INFINITY;
         for (int sg = 0; sg < nsg; ++sg) {
-            const int64_t at = (int64_t)sg * a.n + row;
+            const int64_t at = (int64_t)sg * a.n + (job.part0 + i);
             float v = a.part_b[at];
             int id = a.part_id[at];
             rest = fmaxf(rest, a.part_s[at]);
@@ -487,7 +487,8 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count) {
 // to each other]
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
-                    uint16_t* ckeys, int ckeys_stride, const uint16_t* sp_cols, const float* sp_vals, int merge_max_lists) {
+                    uint16_t* ckeys, int ckeys_stride, const uint16_t* sp_cols, const float* sp_vals, int merge_max_lists,
+                    int64_t merge_rows) {
     if (n_single + n_merge <= 0) return FAL_OK;
     // work lists of the exact kernels: a row enters at most one of them once per pass, so n_rows entries never overflow
     int32_t* amb = nullptr;
@@ -497,7 +498,7 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
     Assign16Args a{};
     a.X16 = reinterpret_cast<const __half*>(X16); a.C16 = reinterpret_cast<const __half*>(C16);
     a.jobs = jobs; a.n_jobs = n_single; a.assign = assign; a.amb_list = amb + 16; a.amb_count = amb; a.amb_cap = amb_cap;
-    a.pair_list = amb + 16 + 5 * (size_t)amb_cap; a.ckeys = ckeys; a.ckeys_stride = ckeys_stride; a.n = n_rows;
+    a.pair_list = amb + 16 + 5 * (size_t)amb_cap; a.ckeys = ckeys; a.ckeys_stride = ckeys_stride; a.n = std::max<int64_t>(merge_rows, 1);
     a.sp_cols = sp_cols; a.sp_vals = sp_vals;
     StageScope ts(ctx, stage);
     const dim3 block(256);
@@ -525,8 +526,11 @@ int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, co
         float* part = nullptr;
         const size_t n_sub = 4 * (size_t)std::max(1, (merge_max_lists + kAssignGroup - 1) / kAssignGroup);      // four per group job, whole groups
         FAL_REQUIRE(merge_max_lists <= kAssignMergeLists, FAL_EINTERNAL, "assign16: a merge job with %d lists", merge_max_lists);
-        FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * 3 * n_sub * (size_t)n_rows, (void**)&part));
-        a.part_b = part; a.part_s = part + n_sub * (size_t)n_rows; a.part_id = reinterpret_cast<int32_t*>(part + 2 * n_sub * (size_t)n_rows);
+        // (sized by the rows of the MERGE buckets -- AssignJob::part0 --, not by the partition's: one 2,048-list bucket among 10 M
+        // rows asked for 7.7 GB)
+        const size_t n_part = (size_t)a.n;
+        FAL_TRY(ctx->reserve(SLOT_PROBE_SIM, sizeof(float) * 3 * n_sub * n_part, (void**)&part));
+        a.part_b = part; a.part_s = part + n_sub * n_part; a.part_id = reinterpret_cast<int32_t*>(part + 2 * n_sub * n_part);
         a.jobs = jobs + n_single + n_merge; a.n_jobs = n_group;
         FAL_TRY(run(true));
         a.mjobs = jobs + n_single; a.n_mjobs = n_merge;

@@ -670,6 +670,7 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
         const bool use16 = X16 != nullptr && assign16_supports(low_dim) && ivf->rows_signed == 0;
         std::vector<AssignJob> hjobs, mjobs, gjobs;    // single-group jobs; merge jobs and their group jobs (129..kAssignMergeLists lists)
         int merge_max_lists = 0;
+        int64_t merge_rows = 0;                        // rows of the merge buckets: the partial arrays' rows (AssignJob::part0)
         for (const BucketDev& b : bk) {
             if (use16 && b.n_list <= kAssignGroup) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg)
@@ -678,9 +679,10 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                 merge_max_lists = std::max(merge_max_lists, (int)b.n_list);
                 for (int64_t s0 = 0; s0 < b.n; s0 += kAssignSeg) {
                     const int32_t nr = (int32_t)std::min<int64_t>(kAssignSeg, b.n - s0);
-                    mjobs.push_back({b.row0 + s0, b.list0, nr, b.n_list, 0, 0});
+                    mjobs.push_back({b.row0 + s0, b.list0, nr, b.n_list, 0, (int32_t)merge_rows});
                     for (int t0 = 0; t0 < b.n_list; t0 += kAssignGroup)      // the groups of a segment next to each other: they
-                        gjobs.push_back({b.row0 + s0, b.list0 + t0, nr, std::min(kAssignGroup, b.n_list - t0), t0, 0});   // share its rows in L2
+                        gjobs.push_back({b.row0 + s0, b.list0 + t0, nr, std::min(kAssignGroup, b.n_list - t0), t0, (int32_t)merge_rows});   // share its rows in L2
+                    merge_rows += nr;
                 }
             } else if (b.n_list <= 64) {
                 for (int64_t s0 = 0; s0 < b.n; s0 += wseg)
@@ -756,11 +758,20 @@ int fal_ivf_build_x16(fal_ctx* ctx, const float* X, const void* X16, int64_t n, 
                     int max_nl = 0;
                     for (const BucketDev& b : bk) max_nl = std::max(max_nl, (int)b.n_list);
                     ivf->ckeys_stride = kAssignGroup * (int)ceil_div(max_nl, kAssignGroup);
-                    B_TRY(ctx->pool_alloc(sizeof(uint16_t) * (size_t)n * ivf->ckeys_stride, (void**)&ivf->ckeys));
+                    // n x stride keys: ONE 2,048-list bucket sizes them for every row of the partition (41 GB at 10 M rows).  Beyond
+                    // a budget (FALCON_CKEYS_MB, default 32 GB), or when the allocation fails, the index is built without them and the
+                    // coarse quantiser scans in float32 (search.hip `from_keys`: the same probes, slower).
+                    const char* ke = getenv("FALCON_CKEYS_MB");
+                    const size_t budget = (ke ? (size_t)atoll(ke) : (size_t)32768) << 20;
+                    const size_t key_bytes = sizeof(uint16_t) * (size_t)n * ivf->ckeys_stride;
+                    if (key_bytes > budget || ctx->pool_alloc(key_bytes, (void**)&ivf->ckeys) != FAL_OK) {
+                        ivf->ckeys = nullptr;
+                        (void)hipGetLastError();
+                    }
                 }
                 B_TRY(launch_assign16(ctx, ST_BUILD, X16, X, C16, ivf->centroids, low_dim, hjobs_dev, n_single, n_merge, n_group, n,
                                       ivf->assign, it == kmeans_iters ? ivf->ckeys : nullptr, ivf->ckeys_stride, sp_cols, sp_vals,
-                                      merge_max_lists));
+                                      merge_max_lists, merge_rows));
             }
             if (!djobs.empty())
                 B_TRY(launch_dense(ctx, ST_BUILD, EPI_ARGMAX, X, ivf->centroids, low_dim, djobs_dev, (int)djobs.size(), 0,

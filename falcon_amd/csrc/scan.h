@@ -73,7 +73,8 @@ struct AssignJob {
     int32_t nrows;       // rows in the segment (<= kAssignSeg)
     int32_t ncent;       // centroids in the group (1..kAssignGroup)
     int32_t id_base;     // bucket-local list id of the group's first centroid
-    int32_t pad;
+    int32_t part0;       // merge / group jobs (assign16.hip): position of the segment's first row among the rows of ALL merge
+                         // buckets = the row index of the partial arrays (0 elsewhere)
 };
 // keys: u64[n] scratch (cleared here); assign[i] is written for every row a job covers
 // jobs[0, n_jobs): 4-wave jobs (<= 128 centroids each); jobs[n_jobs, n_jobs + n_wave_jobs): one-wave jobs (<= 32 centroids)
@@ -86,7 +87,7 @@ int launch_cvt_f16(fal_ctx* ctx, const float* in, void* out, int64_t count);
 int launch_assign16(fal_ctx* ctx, int stage, const void* X16, const float* X, const void* C16, const float* Cn, int d,
                     const AssignJob* jobs, int64_t n_single, int64_t n_merge, int64_t n_group, int64_t n_rows, int32_t* assign,
                     uint16_t* ckeys = nullptr, int ckeys_stride = 0, const uint16_t* sp_cols = nullptr,
-                    const float* sp_vals = nullptr, int merge_max_lists = 4 * kAssignGroup);
+                    const float* sp_vals = nullptr, int merge_max_lists = 4 * kAssignGroup, int64_t merge_rows = 0);
 // List-major IVF fine scan (ivf_fine.hip): tile = (one inverted list, 32 of the queries that probe it)
 struct ListScanArgs {
     const float* Xl;             // vectors in (bucket, list, row) order

@@ -77,6 +77,24 @@ def test_config3_regime_buckets_of_8750_rows_n_list_128(ctx):
     _check_production_equals_oracle(ctx, ds, p, L, ref, rmed)
 
 
+def test_an_index_built_without_the_coarse_keys_gives_the_same_result(ctx, monkeypatch):
+    """`FALCON_CKEYS_MB` (csrc/ivf.hip): the (row, centroid) keys the final k-means pass leaves for the coarse quantiser are n x
+    stride -- one 2,048-list bucket sizes them for every row of its partition.  Beyond the budget (or when the allocation fails)
+    the index is built without them and the coarse quantiser scans in float32: the same probes, the same neighbour lists."""
+    from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
+    d, ds = _dense_dataset(26000, 600.0, 602.0, seed=75)
+    p = AnnParams()
+    a = ClusterPipeline(ctx)
+    la, ma = a.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, p)
+    assert 128 in list(a.last["n_list"])
+    monkeypatch.setenv("FALCON_CKEYS_MB", "0")
+    b = ClusterPipeline(ctx)
+    lb, mb = b.run(ds, 20.0, "ppm", None, 0.05, 2 ** 15, p)
+    assert np.array_equal(la.cpu().numpy(), lb.cpu().numpy()) and np.array_equal(ma.cpu().numpy(), mb.cpu().numpy())
+    for k in ("nb_idx", "nb_dist"):
+        assert np.array_equal(a.last[k].cpu().numpy(), b.last[k].cpu().numpy()), k
+
+
 def test_config4_regime_bucket_of_25k_rows_n_list_512_n_probe_32(ctx):
     """one 1 m/z window of ~25 k charge-2 spectra: n_list 512, n_probe 32, k_ann 128 (BASELINE configs[3])."""
     from falcon_amd.cluster.cluster import AnnParams, ClusterPipeline
