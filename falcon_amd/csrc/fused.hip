@@ -551,17 +551,16 @@ __device__ __forceinline__ void push_fallback(const FusedArgs& a, int64_t row, i
 // resolve_kernel: one wave per query (4 per workgroup, 8 queries each per 32-query tile): ambiguous candidates against
 // the exact k-th key, sort, neighbour lists
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void resolve_kernel(FusedArgs a, int d) {
-    __shared__ uint32_t s_u_all[4 * 64];
-    __shared__ uint32_t s_lo_all[4 * 64];
+template <int OCC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) void resolve_occ_kernel(FusedArgs a, int d) {
+    __shared__ uint2 s_key_all[4 * 64];                        // kept candidates: (x = ~id, y = sortable similarity)
     __shared__ int32_t seg_off_all[4][FAL_MAX_N_PROBE + 1];      // IVF: key-stream offset / first position of every probed list
     __shared__ int64_t seg_src_all[4][FAL_MAX_N_PROBE];
     int ji, lt;
     if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t* s_u = s_u_all + 64 * w;
-    uint32_t* s_lo = s_lo_all + 64 * w;
+    uint2* s_key = s_key_all + 64 * w;
     const int nc = job.nc, k = a.k;
     const int64_t row0 = job.q_row0;
     const int nqw = min(32, nc - 32 * lt);
@@ -570,15 +569,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // the others to the second.  As ONE loop the exact chains' addresses and masks (loop invariants of the heavy branch) were
     // hoisted in front of it and spilled there, at the kernel's 80-register cap: 24 dwords per lane = 6 KB of scratch writes per
     // wave = 768 B per query -- 7.7 GB of the 12.9 GB this kernel wrote per 10 M pass for 5.1 GB of neighbour rows (round 6).
-    auto one = [&](int ql, auto heavy) __attribute__((always_inline)) -> bool {
+    // A query's hand-off: every load of the common path, issued together (one memory round trip, not four) -- and, in the first
+    // pass, one query AHEAD of its use (the wave's eight queries were eight round trips in a row).
+    struct Hand { int i0, i1; uint32_t ku, ki; QThr t; };
+    auto fetch = [&](int ql) __attribute__((always_inline)) -> Hand {
+        const int64_t row = row0 + 32 * lt + ql;
+        Hand h{};
+        h.i0 = a.gkcnt[row * 2];
+        h.i1 = a.gkcnt[row * 2 + 1];
+        h.ku = a.gkept_u[row * FAL_FUSED_KEEP + lane];
+        h.ki = a.gkept_id[row * FAL_FUSED_KEEP + lane];
+        if (need_thr) h.t = a.thr[row];
+        return h;
+    };
+    auto one = [&](int ql, const Hand& hand, auto heavy) __attribute__((always_inline)) -> bool {
         constexpr bool HEAVY = decltype(heavy)::value;
         const int64_t row = row0 + 32 * lt + ql;
-        // every load of the common path is issued before the first use (one memory round trip, not four)
-        const int i0 = a.gkcnt[row * 2], i1 = a.gkcnt[row * 2 + 1];
-        const uint32_t ku_l = a.gkept_u[row * FAL_FUSED_KEEP + lane];
-        const uint32_t ki_l = a.gkept_id[row * FAL_FUSED_KEEP + lane];
-        QThr t{};
-        if (need_thr) t = a.thr[row];
+        const int i0 = hand.i0, i1 = hand.i1;
+        const uint32_t ku_l = hand.ku, ki_l = hand.ki;
+        const QThr t = hand.t;
         const int k0 = i0 & 0xFF, k1 = i1 & 0xFF;
         bool fb = ((i0 | i1) & 0x200) != 0;
         bool amb = ((i0 | i1) & 0x100) != 0;
@@ -719,24 +728,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const unsigned long long km = __ballot(keepit);
         if (keepit) {
             const int at = __popcll(km & ((1ull << lane) - 1ull));
-            s_u[at] = u;
-            s_lo[at] = ~id;
+            s_key[at] = make_uint2(~id, u);
         }
         const int c = __popcll(km);
         wave_lds_sync();
         if (a.nb_count && lane == 0) a.nb_count[row] = min(c, a.keep);
-        sort_and_store_nb<1>(s_u, s_lo, c, a.keep, lane, a.nb_idx + row * a.keep, a.nb_dist + row * a.keep);
+        rank_or_sort_and_store_nb(s_key, c, a.keep, lane, a.nb_idx + row * a.keep, a.nb_dist + row * a.keep);
         wave_lds_sync();
         return false;
     };
     uint32_t later = 0;
-    for (int ql = w; ql < nqw; ql += 4)
-        if (one(ql, std::false_type{})) later |= 1u << (ql >> 2);
+    if (w >= nqw) return;
+    Hand cur = fetch(w);
+    for (int ql = w; ql < nqw; ql += 4) {
+        Hand nxt = cur;
+        if (ql + 4 < nqw) nxt = fetch(ql + 4);
+        if (one(ql, cur, std::false_type{})) later |= 1u << (ql >> 2);
+        cur = nxt;
+    }
     later = (uint32_t)__builtin_amdgcn_readfirstlane((int)later);
     if (later == 0) return;
     asm volatile("" ::: "memory");
     for (int ql = w; ql < nqw; ql += 4)
-        if ((later >> (ql >> 2)) & 1u) one(ql, std::true_type{});
+        if ((later >> (ql >> 2)) & 1u) one(ql, fetch(ql), std::true_type{});
+}
+
+// (A/B switch FALCON_RESOLVE_OCC = 6 | 7 | 8 waves per SIMD: 80 / 72 / 64 registers)
+static void launch_resolve(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32) {
+    const char* oe = getenv("FALCON_RESOLVE_OCC");
+    const int occ = oe ? atoi(oe) : 6;
+    const dim3 grid((unsigned)(list_tiles32 * 8)), block(256);
+    if (occ == 8) hipLaunchKernelGGL(resolve_occ_kernel<8>, grid, block, 0, ctx->stream, a, d);
+    else if (occ == 7) hipLaunchKernelGGL(resolve_occ_kernel<7>, grid, block, 0, ctx->stream, a, d);
+    else hipLaunchKernelGGL(resolve_occ_kernel<6>, grid, block, 0, ctx->stream, a, d);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -864,7 +888,7 @@ int launch_fused_ivf_tail(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_
     if (a.n_jobs32 <= 0 || list_tiles32 <= 0) return FAL_OK;
     FAL_REQUIRE(list_tiles32 * 8 < (int64_t)INT32_MAX, FAL_EUNSUPPORTED, "too many tiles in one launch");
     StageScope ts(ctx, ST_SELECT);
-    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
+    launch_resolve(ctx, a, d, list_tiles32);
     FAL_CHECK_HIP(hipGetLastError());
     // exact fallback over the probed lists
     const int64_t stride = ((max_cand + 63) & ~63ll) + (int64_t)kSimsSlack;
@@ -933,7 +957,7 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
     }
     {
         StageScope ts(ctx, ST_SELECT);
-        hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
+        launch_resolve(ctx, a, d, list_tiles32);
         FAL_CHECK_HIP(hipGetLastError());
     }
     {
@@ -953,4 +977,4 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
 bool fused_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
 
 }  // namespace fal
-FAL_WARM_KERNEL(fal::resolve_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
+FAL_WARM_KERNEL(fal::resolve_occ_kernel<6>);      // (fal_ctx_plan: this unit's code object is loaded up front)

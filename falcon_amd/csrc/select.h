@@ -448,6 +448,45 @@ __device__ __forceinline__ void sort_and_store_nb(const uint32_t* f_u, const uin
     }
 }
 
+// The same for <= 64 survivors held as 64-bit keys (x = ~id, y = sortable similarity) in LDS.  Up to 16 of them (the usual case:
+// ~10 per query) are RANKED instead of sorted -- every lane counts the keys above its own with broadcast reads, 2 VALU + 1 LDS
+// instruction per key against ~9 per stage of the 10-stage network: resolve_kernel is VALU-bound (0.77 of the SIMDs' VALU
+// cycles, round 6 counters) and the sort was a third of its instructions.  Keys are unique (ids are), so ranks are the sorted
+// positions: identical output.
+__device__ __forceinline__ void rank_or_sort_and_store_nb(const uint2* keys, int c, int keep, int lane, int32_t* __restrict__ onb,
+                                                          float* __restrict__ odist) {
+    const uint2 mine = lane < c ? keys[lane] : make_uint2(0u, 0u);
+    if (c <= 16) {
+        const unsigned long long me = ((unsigned long long)mine.y << 32) | mine.x;
+        int rank = 0;
+        for (int j = 0; j < c; ++j) {
+            const uint2 kj = keys[j];
+            rank += ((((unsigned long long)kj.y << 32) | kj.x) > me) ? 1 : 0;
+        }
+        if (lane < c && rank < keep) {
+            onb[rank] = (int32_t)~mine.x;
+            odist[rank] = fminf(fmaxf(1.0f - sortable_f32(mine.y), 0.f), 1.f);
+        }
+        for (int e = c + lane; e < keep; e += 64) {
+            onb[e] = -1;
+            odist[e] = INFINITY;
+        }
+        return;
+    }
+    uint32_t hi = mine.y, lo = mine.x;
+    if (c <= 32) sort_small<32>(hi, lo, lane);
+    else sort_small<64>(hi, lo, lane);
+    if (lane < keep) {
+        const bool valid = lane < c;
+        onb[lane] = valid ? (int32_t)~lo : -1;
+        odist[lane] = valid ? fminf(fmaxf(1.0f - sortable_f32(hi), 0.f), 1.f) : INFINITY;
+    }
+    for (int e = 64 + lane; e < keep; e += 64) {
+        onb[e] = -1;
+        odist[e] = INFINITY;
+    }
+}
+
 __device__ __forceinline__ void filter_sort_store(const SelectArgs& a, const uint32_t* sel_u, const uint32_t* sel_id,
                                                   uint32_t* f_u, uint32_t* f_lo, int carry, int64_t row, int lane) {
     const float qmz = a.f_pmz[row];
