@@ -551,8 +551,8 @@ __device__ __forceinline__ void push_fallback(const FusedArgs& a, int64_t row, i
 // resolve_kernel: one wave per query (4 per workgroup, 8 queries each per 32-query tile): ambiguous candidates against
 // the exact k-th key, sort, neighbour lists
 // ------------------------------------------------------------------------------------------------------------
-template <int OCC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) void resolve_occ_kernel(FusedArgs a, int d) {
+// (6 / 7 / 8 waves per SIMD = 80 / 72 / 64 registers: no difference, round 6)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void resolve_kernel(FusedArgs a, int d) {
     __shared__ uint2 s_key_all[4 * 64];                        // kept candidates: (x = ~id, y = sortable similarity)
     __shared__ int32_t seg_off_all[4][FAL_MAX_N_PROBE + 1];      // IVF: key-stream offset / first position of every probed list
     __shared__ int64_t seg_src_all[4][FAL_MAX_N_PROBE];
@@ -753,14 +753,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         if ((later >> (ql >> 2)) & 1u) one(ql, fetch(ql), std::true_type{});
 }
 
-// (A/B switch FALCON_RESOLVE_OCC = 6 | 7 | 8 waves per SIMD: 80 / 72 / 64 registers)
 static void launch_resolve(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32) {
-    const char* oe = getenv("FALCON_RESOLVE_OCC");
-    const int occ = oe ? atoi(oe) : 6;
-    const dim3 grid((unsigned)(list_tiles32 * 8)), block(256);
-    if (occ == 8) hipLaunchKernelGGL(resolve_occ_kernel<8>, grid, block, 0, ctx->stream, a, d);
-    else if (occ == 7) hipLaunchKernelGGL(resolve_occ_kernel<7>, grid, block, 0, ctx->stream, a, d);
-    else hipLaunchKernelGGL(resolve_occ_kernel<6>, grid, block, 0, ctx->stream, a, d);
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)(list_tiles32 * 8)), dim3(256), 0, ctx->stream, a, d);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -977,4 +971,4 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a_in, int d, int64_t n_rows, int
 bool fused_supports(int d) { return d == 64 || d == 128 || d == 256 || d == 400; }
 
 }  // namespace fal
-FAL_WARM_KERNEL(fal::resolve_occ_kernel<6>);      // (fal_ctx_plan: this unit's code object is loaded up front)
+FAL_WARM_KERNEL(fal::resolve_kernel);      // (fal_ctx_plan: this unit's code object is loaded up front)
