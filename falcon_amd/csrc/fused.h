@@ -27,6 +27,8 @@ struct FusedArgs {
     int n_jobs128;
     const DenseJob* jobs32;      // every flat bucket, 32-query tiles (band_kernel, resolve_kernel, fallback)
     int n_jobs32;
+    const int32_t* tile_job32;   // optional [grid]: job of workgroup `bid` of a 32-query-tile launch (-1: none) -- find_job_xcd's
+                                 // binary search (seven dependent loads at 600 buckets) done once per search (launch_tile_job32)
     int k;                       // n_neighbors_ann
     const float* pmz;            // [n] precursor m/z by sorted row
     const float* rt;             // [n] or nullptr
@@ -70,6 +72,17 @@ int launch_fused(fal_ctx* ctx, const FusedArgs& a, int d, int64_t n_rows, int64_
 // IVF buckets: hand-off buffers and the fallback list (before select16_kernel runs), then the exact tail --
 // band_kernel over the precursor windows (candidates outside the query's probed lists masked out), resolve_kernel, and the
 // exact fallback over the probed lists.  max_cand = upper bound of the candidates of one query.
+// the job and local tile of workgroup `bid` of a launch over the 32-query tiles (XCD lists: simtile.h find_job_xcd)
+__device__ __forceinline__ bool find_job32(const FusedArgs& a, unsigned bid, int* job_index, int* local_tile) {
+    if (a.tile_job32 == nullptr) return find_job_xcd(a.jobs32, a.n_jobs32, bid, job_index, local_tile);
+    const int j = a.tile_job32[bid];
+    if (j < 0) return false;
+    *job_index = j;
+    *local_tile = (int)((int64_t)(bid >> 3) - a.jobs32[j].xtile0);
+    return true;
+}
+// table[bid] for bid < 8 * list_tiles32 (FusedArgs::tile_job32)
+int launch_tile_job32(fal_ctx* ctx, const DenseJob* jobs32, int n_jobs32, int64_t list_tiles32, int32_t* table);
 int fused_prepare(fal_ctx* ctx, FusedArgs* a, int64_t n_rows);
 int launch_fused_ivf_tail(fal_ctx* ctx, const FusedArgs& a, int d, int64_t list_tiles32, int64_t max_cand);
 

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64, 1) void band_kernel(FusedArgs a) {
     __shared__ uint32_t kept_id[32 * kStride];
     extern __shared__ uint32_t pmask[];                       // IVF: [32][mask_words] probed lists of the tile's queries
     int ji, lt;
-    if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
+    if (!find_job32(a, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int nc = job.nc;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     __shared__ int32_t seg_off_all[4][FAL_MAX_N_PROBE + 1];      // IVF: key-stream offset / first position of every probed list
     __shared__ int64_t seg_src_all[4][FAL_MAX_N_PROBE];
     int ji, lt;
-    if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
+    if (!find_job32(a, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint2* s_key = s_key_all + 64 * w;
@@ -851,6 +851,22 @@ static float float_le_bound(double tol, double scale) {
     float y;
     memcpy(&y, &lo, 4);
     return y;
+}
+
+__global__ void tile_job32_kernel(const DenseJob* __restrict__ jobs, int n_jobs, int64_t grid, int32_t* __restrict__ table) {
+    const int64_t bid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (bid >= grid) return;
+    int ji = -1, lt = 0;
+    if (!find_job_xcd(jobs, n_jobs, (unsigned)bid, &ji, &lt)) ji = -1;
+    table[bid] = ji;
+}
+
+int launch_tile_job32(fal_ctx* ctx, const DenseJob* jobs32, int n_jobs32, int64_t list_tiles32, int32_t* table) {
+    const int64_t grid = list_tiles32 * 8;
+    if (grid <= 0) return FAL_OK;
+    hipLaunchKernelGGL(tile_job32_kernel, dim3((unsigned)ceil_div(grid, 256)), dim3(256), 0, ctx->stream, jobs32, n_jobs32, grid, table);
+    FAL_CHECK_HIP(hipGetLastError());
+    return FAL_OK;
 }
 
 int fused_prepare(fal_ctx* ctx, FusedArgs* ap, int64_t n_rows) {

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ int32_t off[33];
     __shared__ __attribute__((aligned(16))) unsigned char tbuf[4][64 * kSlot];
     int ji, lt;
-    if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
+    if (!find_job32(a, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
     const int nqw = min(32, job.nc - 32 * lt);
     const int64_t row_t = job.q_row0 + 32 * lt;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned char* tbuf = smem + (size_t)32 * d * sizeof(QT);    // [4][64 * kSlot]
     int32_t* off = reinterpret_cast<int32_t*>(tbuf + 4 * 64 * kSlot);   // [33]
     int ji, lt;
-    if (!find_job_xcd(a.jobs32, a.n_jobs32, blockIdx.x, &ji, &lt)) return;
+    if (!find_job32(a, blockIdx.x, &ji, &lt)) return;
     const DenseJob job = a.jobs32[ji];
     const int nqw = min(32, job.nc - 32 * lt);
     const int64_t row_t = job.q_row0 + 32 * lt;

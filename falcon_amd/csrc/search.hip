@@ -722,10 +722,14 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
             xt32[x] += ceil_div(cj.nq, 32);
         }
         DenseJob* jd = nullptr;
-        FAL_TRY(ctx->reserve(SLOT_JOBS3, sizeof(DenseJob) * j32.size(), (void**)&jd));
+        const int64_t tiles32 = *std::max_element(xt32, xt32 + 8);
+        const size_t jd_bytes = (sizeof(DenseJob) * j32.size() + 15) & ~(size_t)15;
+        FAL_TRY(ctx->reserve(SLOT_JOBS3, jd_bytes + sizeof(int32_t) * (size_t)(8 * tiles32), (void**)&jd));
         FAL_TRY(ctx->upload(jd, j32.data(), sizeof(DenseJob) * j32.size()));
+        int32_t* tj32 = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(jd) + jd_bytes);
+        FAL_TRY(launch_tile_job32(ctx, jd, (int)j32.size(), tiles32, tj32));
         FusedArgs fa{};
-        fa.X = ivf->X; fa.jobs32 = jd; fa.n_jobs32 = (int)j32.size();
+        fa.X = ivf->X; fa.jobs32 = jd; fa.n_jobs32 = (int)j32.size(); fa.tile_job32 = tj32;
         fa.k = k_ann; fa.pmz = nf->pmz; fa.rt = nf->rt; fa.tol = nf->tol; fa.rt_tol = nf->rt_tol; fa.is_da = nf->is_da;
         fa.keep = nf->keep; fa.nb_idx = nf->nb_idx; fa.nb_dist = nf->nb_dist; fa.nb_count = nf->nb_count;
         fa.ivf = 1; fa.assign = ivf->assign; fa.pos_of_row = ivf->pos_of_row; fa.probes = probes; fa.n_probe = np;
