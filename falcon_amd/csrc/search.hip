@@ -684,7 +684,11 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     int64_t max_total = 0;                                   // the most candidates any query has
     FAL_CHECK_HIP(hipMemcpyAsync(&max_total, totals + n_slots + 1, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     FAL_CHECK_HIP(hipStreamSynchronize(st));
-    // batches of whole IVF buckets (every list of a bucket touches queries all over the bucket)
+    // batches of whole IVF buckets (every list of a bucket touches queries all over the bucket).  The float16 path's batches hold
+    // 2-byte keys: the same BYTES as a batch of float32 sims = twice the candidates (fewer, larger launches of the three per-batch
+    // kernels: -1.3 ms per 10 M pass; smaller batches -- down to the 256 MB of the memory-side cache -- only lose, NOTES r6)
+    const bool key_path = want_rows && ivf->X && ivf16_supports(d) && max_total <= 4096;
+    const int64_t cap_fine = key_path ? (int64_t)std::min<size_t>(2 * cap, ((size_t)1 << 31) - 4 * kSimsSlack) : (int64_t)cap;
     struct IvfBatch { size_t j0, j1; };
     std::vector<IvfBatch> ivf_batches;
     size_t need_fine = 0;
@@ -693,7 +697,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
         for (size_t j = 0; j < coarse.size(); ++j) {
             const int64_t t_end = coarse[j].tile0 + ceil_div(coarse[j].nq, 32);
             const int64_t span = qoff[(size_t)t_end] - qoff[(size_t)coarse[j0].tile0];
-            if (span > (int64_t)cap && j > j0) {
+            if (span > cap_fine && j > j0) {
                 ivf_batches.push_back({j0, j});
                 j0 = j;
             }
@@ -708,7 +712,7 @@ static int search_impl(fal_ctx* ctx, const fal_ivf* ivf, int n_probe, int k_ann,
     // ---- C'. fine scan with the float16 prefilter (ivf16.hip): f16-MFMA scan to 16-bit keys, k-th key per query, exact tail
     // (select16_kernel holds at most 4,096 keys of a query in registers; coarser indexes keep the exact staged scan rather
     // than sending every query through the exact fallback)
-    if (want_rows && ivf->X && ivf16_supports(d) && max_total <= 4096) {
+    if (key_path) {
         // the IVF buckets in sorted-row order, 32-query tiles, sorted by decreasing size and dealt to the 8 XCD lists
         std::vector<size_t> ord(coarse.size());
         for (size_t j = 0; j < ord.size(); ++j) ord[j] = j;
