@@ -557,8 +557,22 @@ class PartitionRunner:
     def run(self, datasets, *args, shard: Optional[Tuple[int, int]] = None, **kwargs):
         """-> [(labels, medoids), ...] in the order of `datasets` (largest partition is started first).  `shard = (rank,
         world)`: every partition is one dataset shared by `world` GPUs, as in `ClusterPipeline.run_many`."""
+        return self.collect(self.submit(datasets, *args, shard=shard, **kwargs))
+
+    def collect(self, handle):
+        """the results of a `submit`: waits for its partitions (each slot has synchronised its own stream)"""
+        futs, n, nothing = handle
+        res = [futs[i].result()[::2] if i in futs else nothing() for i in range(n)]
+        self.lasts = [r[1] for r in res]                           # every partition's `last`, in the order of `datasets`
+        return [r[0] for r in res]
+
+    def submit(self, datasets, *args, shard: Optional[Tuple[int, int]] = None, inputs_ready: bool = False, **kwargs):
+        """`run` without the wait: the partitions are queued on the slots (behind whatever the slots are still working on -- a
+        stream of jobs keeps the GPU busy across job boundaries) and a handle for `collect` comes back.  `inputs_ready`: the
+        datasets were complete on the device before the call (no wait for the caller's stream)."""
         import torch
-        torch.cuda.current_stream(self.device).synchronize()      # inputs produced on the caller's stream
+        if not inputs_ready:
+            torch.cuda.current_stream(self.device).synchronize()      # inputs produced on the caller's stream
         order = sorted(range(len(datasets)), key=lambda i: -len(datasets[i]))
         shards = [shard] * len(datasets)
         p = args[5]
@@ -588,9 +602,7 @@ class PartitionRunner:
         futs = {i: self._pool.submit(self._run_one, datasets[i], args, kwargs, shards[i], arrived.get(i)) for i in order}
         nothing = lambda: ((torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev)),
                            {"rows": torch.empty(0, dtype=torch.int64, device=dev)})
-        res = [futs[i].result()[::2] if i in futs else nothing() for i in range(len(datasets))]
-        self.lasts = [r[1] for r in res]                           # every partition's `last`, in the order of `datasets`
-        return [r[0] for r in res]
+        return futs, len(datasets), nothing
 
     def plan(self, datasets, *args, **kwargs):
         """Before the first pass of a fresh process: create every slot's thread, stream and context and `fal_ctx_plan` each for the
