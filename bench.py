@@ -132,7 +132,7 @@ def cpu_baseline(hosts, params, budget_s=75.0):
 def pmc_traffic(workload):
     """HBM bytes per launch of a workload's dominant cosine kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md).  Counters cannot be read from inside the run, so
-    the figure is only reported for the workloads it was measured on (profiles/r5_pmc_traffic.json -- r4 / r3 as the fallback --, written by
+    the figure is only reported for the workloads it was measured on (profiles/r6_pmc_traffic.json -- r5 / r4 / r3 as the fallback --, written by
     tools/pmc_traffic.sh on the GPU box).  -> (bytes per launch or None, source file or None)"""
     for fn in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
@@ -805,9 +805,9 @@ def main():
             # `issued` = machine flops actually run through the matrix pipe, tile padding included
             roof.update({"issued_tflops": s["issued_tflops"], "issued_frac": s["issued_tflops"] / PEAK_MFMA_F32_TFLOPS})
         roof["profile"] = ("avg_launch_ms comes from a serial per-stage pass (HIP events); it agrees with the kernel's average in "
-                           "profiles/r5_bench_1M_pipelined_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py "
-                           "--partitions pipelined --no-configs --no-cpu-baseline`: one stream); in the default two-stream run "
-                           "(profiles/r5_bench_1M_kernel_stats.csv) the two partitions' kernels overlap and stretch each other")
+                           "profiles/r6_bench_1M_pipelined_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py "
+                           "--partitions pipelined --no-configs --no-cpu-baseline --no-cold`: one stream); in the default two-stream run "
+                           "(round 5's trace: profiles/r5_bench_1M_kernel_stats.csv) the two partitions' kernels overlap and stretch each other")
         out = {
             "metric": "spectra clustered/sec @1/2/4/8 GPU; cosine-kernel HBM GB/s vs roofline",
             "value": n_total * args.steps / dt,
