@@ -48,9 +48,9 @@ typedef _Float16 half8s __attribute__((ext_vector_type(8)));
 // 3 = 2 + a wave-private LDS transposition in quarter rounds in front of them
 template <int STEPS, int KN = 0>
 __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16Args a) {
-    constexpr int kStores = KN == 0 ? 16 : KN == 1 ? 0 : 4;
+    constexpr int kStores = (KN == 0 || KN == 4 || KN == 5) ? 16 : (KN == 1 || KN == 6) ? 0 : 4;      // (4: no expansion, 5: no record DMAs, 6: neither, no stores)
     constexpr int D = STEPS * 16, DH = D / 2;
-    constexpr int kRowOps = 2;                            // row DMAs per step and wave (4 records of 256 B each)
+    constexpr int kRowOps = (KN == 5 || KN == 6) ? 0 : 2;  // row DMAs per step and wave (4 records of 256 B each)
     constexpr int NB = STEPS < 4 ? STEPS : 4;             // LDS operand reads in flight ahead of the MFMAs
     constexpr int RS = D * 2 + 16;                        // LDS row stride of the operand tiles in bytes (the last 16: dump slot)
     __shared__ __attribute__((aligned(16))) unsigned char tile0[32 * RS];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
     };
     auto epilogue = [&]() {
         const int left = nq - 32 * prev_c - 4 * h;         // queries q0 < left of this chunk exist (all 32, except in a list's last chunk)
-        if (KN == 1) return;
+        if (KN == 1 || KN == 6) return;
         if (KN >= 2) {
             const int32_t* md = &meta[prev_c & 7][32];
             unsigned char* xp = xpose + (KN == 3 ? 576 * w : 0);
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
             if (active) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAllow) : "memory");   \
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAllowIdle) : "memory");      \
         }                                                                                                      \
-        issue_rows((C) + 3, STG_FILL);                                                                         \
-        if ((C) + 1 < n_chunks) expand(STG_NEXT, TILE_NEXT, PREV_NEXT);                                        \
+        if (kRowOps) issue_rows((C) + 3, STG_FILL);                                                            \
+        if (KN != 4 && KN != 6 && (C) + 1 < n_chunks) expand(STG_NEXT, TILE_NEXT, PREV_NEXT);                  \
         if (active) compute(TILE_CUR, C);                                                                      \
         issue_meta((C) + 6);                                                                                   \
     }
@@ -260,9 +260,11 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_rows(0, stage0);
-    issue_rows(1, stage1);
-    issue_rows(2, stage2);
+    if (kRowOps) {
+        issue_rows(0, stage0);
+        issue_rows(1, stage1);
+        issue_rows(2, stage2);
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kRowOps) : "memory");   // the records of chunk 0 have landed
     expand(stage0, tile0, prev0);
     FAL_STEP_S(0, stage0, stage1, tile0, tile1, prev1, 0)
@@ -303,6 +305,9 @@ int launch_list16s(fal_ctx* ctx, const List16Args& a) {
             if (kn == 1) hipLaunchKernelGGL((list16s_kernel<25, 1>), grid, block, 0, ctx->stream, a);
             else if (kn == 2) hipLaunchKernelGGL((list16s_kernel<25, 2>), grid, block, 0, ctx->stream, a);
             else if (kn == 3) hipLaunchKernelGGL((list16s_kernel<25, 3>), grid, block, 0, ctx->stream, a);
+            else if (kn == 4) hipLaunchKernelGGL((list16s_kernel<25, 4>), grid, block, 0, ctx->stream, a);
+            else if (kn == 5) hipLaunchKernelGGL((list16s_kernel<25, 5>), grid, block, 0, ctx->stream, a);
+            else if (kn == 6) hipLaunchKernelGGL((list16s_kernel<25, 6>), grid, block, 0, ctx->stream, a);
             else hipLaunchKernelGGL((list16s_kernel<25>), grid, block, 0, ctx->stream, a);
             break;
         }
