@@ -47,17 +47,18 @@ typedef _Float16 half8s __attribute__((ext_vector_type(8)));
 // lane at addresses rounded down to 8 bytes (the store shape a padded key stream would allow, without the transposition),
 // 3 = 2 + a wave-private LDS transposition in quarter rounds in front of them
 template <int STEPS, int KN = 0>
-__global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16Args a) {
-    constexpr int kStores = (KN == 0 || KN == 4 || KN == 5) ? 16 : (KN == 1 || KN == 6) ? 0 : 4;      // (4: no expansion, 5: no record DMAs, 6: neither, no stores)
+__global__ __launch_bounds__(256, STEPS > 32 ? 1 : (KN == 7 ? 3 : 2)) void list16s_kernel(List16Args a) {
+    constexpr int kStores = (KN == 0 || KN == 4 || KN == 5) ? 16 : (KN == 1 || KN == 6 || KN == 7) ? 0 : 4;      // (4: no expansion, 5: no record DMAs, 6: neither, no stores)
     constexpr int D = STEPS * 16, DH = D / 2;
-    constexpr int kRowOps = (KN == 5 || KN == 6) ? 0 : 2;  // row DMAs per step and wave (4 records of 256 B each)
+    constexpr int kRowOps = (KN == 5 || KN == 6 || KN == 7) ? 0 : 2;  // row DMAs per step and wave (4 records of 256 B each)
     constexpr int NB = STEPS < 4 ? STEPS : 4;             // LDS operand reads in flight ahead of the MFMAs
     constexpr int RS = D * 2 + 16;                        // LDS row stride of the operand tiles in bytes (the last 16: dump slot)
     __shared__ __attribute__((aligned(16))) unsigned char tile0[32 * RS];
-    __shared__ __attribute__((aligned(16))) unsigned char tile1[32 * RS];
-    __shared__ __attribute__((aligned(16))) unsigned char stage0[32 * 256];
-    __shared__ __attribute__((aligned(16))) unsigned char stage1[32 * 256];
-    __shared__ __attribute__((aligned(16))) unsigned char stage2[32 * 256];
+    // (KN == 7: the bare matrix loop of KN == 6 with ONE operand tile and no stages -- 28 KB of LDS: does a third workgroup per CU help it?)
+    __shared__ __attribute__((aligned(16))) unsigned char tile1[KN == 7 ? 16 : 32 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned char stage0[KN == 7 ? 16 : 32 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char stage1[KN == 7 ? 16 : 32 * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char stage2[KN == 7 ? 16 : 32 * 256];
     __shared__ int32_t meta[8][64];                       // per chunk: [0, 32) sorted row of query r, [32, 64) its destination (low dword)
     __shared__ __attribute__((aligned(16))) unsigned char xpose[KN == 3 ? 4 * 576 : 16];
     const int64_t per_xcd = (a.n_tiles_max + 7) / 8;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
     };
     auto epilogue = [&]() {
         const int left = nq - 32 * prev_c - 4 * h;         // queries q0 < left of this chunk exist (all 32, except in a list's last chunk)
-        if (KN == 1 || KN == 6) return;
+        if (KN == 1 || KN == 6 || KN == 7) return;
         if (KN >= 2) {
             const int32_t* md = &meta[prev_c & 7][32];
             unsigned char* xp = xpose + (KN == 3 ? 576 * w : 0);
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
             else asm volatile("global_store_short %0, %1, %2" ::"v"(off), "v"(pk[i >> 1]), "s"(a.keys) : "memory");
         }
     };
+    uint32_t prev0[4], prev1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) prev0[j] = prev1[j] = (uint32_t)(2 * D) | ((uint32_t)(2 * D) << 16);     // (the dump slot of row 0)
     auto compute = [&](const unsigned char* buf, int c) {
         constexpr int kMid = STEPS / 2;
         const unsigned char* sb = buf + r * RS + h * (DH * 2);
@@ -224,9 +228,6 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
     // (chunk c + 3: issued last in step c - 3) is older than that.  Steps 0 and 1 have less behind them.
     constexpr int kAllow = (kStores + 1) + (kRowOps + kStores + 1), kAllowIdle = 1 + (kRowOps + 1);
     constexpr int kFirst = kRowOps + kStores + 1, kFirstIdle = kRowOps + 1;
-    uint32_t prev0[4], prev1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) prev0[j] = prev1[j] = (uint32_t)(2 * D) | ((uint32_t)(2 * D) << 16);     // (the dump slot of row 0)
     // WAIT: 0 = step 0 (records of chunk 1: only chunk 2's DMAs behind them), 1 = step 1, 2 = steady state
 #define FAL_STEP_S(C, STG_FILL, STG_NEXT, TILE_CUR, TILE_NEXT, PREV_NEXT, WAIT)                                \
     {                                                                                                          \
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAllowIdle) : "memory");      \
         }                                                                                                      \
         if (kRowOps) issue_rows((C) + 3, STG_FILL);                                                            \
-        if (KN != 4 && KN != 6 && (C) + 1 < n_chunks) expand(STG_NEXT, TILE_NEXT, PREV_NEXT);                  \
-        if (active) compute(TILE_CUR, C);                                                                      \
+        if (KN != 4 && KN != 6 && KN != 7 && (C) + 1 < n_chunks) expand(STG_NEXT, TILE_NEXT, PREV_NEXT);       \
+        if (active) compute(KN == 7 ? tile0 : TILE_CUR, C);                                                    \
         issue_meta((C) + 6);                                                                                   \
     }
     const int n_chunks = (nq + 31) >> 5;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         for (int i = lane; i < 8 * RS / 16; i += 64) {
             *reinterpret_cast<uint4*>(tile0 + (8 * w) * RS + 16 * i) = z;
-            *reinterpret_cast<uint4*>(tile1 + (8 * w) * RS + 16 * i) = z;
+            if (KN != 7) *reinterpret_cast<uint4*>(tile1 + (8 * w) * RS + 16 * i) = z;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, STEPS > 32 ? 1 : 2) void list16s_kernel(List16
         issue_rows(2, stage2);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kRowOps) : "memory");   // the records of chunk 0 have landed
-    expand(stage0, tile0, prev0);
+    if (KN != 7) expand(stage0, tile0, prev0);
     FAL_STEP_S(0, stage0, stage1, tile0, tile1, prev1, 0)
     if (1 < n_chunks) {
         FAL_STEP_S(1, stage1, stage2, tile1, tile0, prev0, 1)
@@ -308,6 +309,7 @@ int launch_list16s(fal_ctx* ctx, const List16Args& a) {
             else if (kn == 4) hipLaunchKernelGGL((list16s_kernel<25, 4>), grid, block, 0, ctx->stream, a);
             else if (kn == 5) hipLaunchKernelGGL((list16s_kernel<25, 5>), grid, block, 0, ctx->stream, a);
             else if (kn == 6) hipLaunchKernelGGL((list16s_kernel<25, 6>), grid, block, 0, ctx->stream, a);
+            else if (kn == 7) hipLaunchKernelGGL((list16s_kernel<25, 7>), grid, block, 0, ctx->stream, a);
             else hipLaunchKernelGGL((list16s_kernel<25>), grid, block, 0, ctx->stream, a);
             break;
         }

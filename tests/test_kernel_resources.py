@@ -32,7 +32,7 @@ def asm_dir(tmp_path_factory):
     ("scan16.hip", "scan16_kernel", 10),
     ("ivf_fine.hip", "ivf_list4_kernel", 7),   # DH4 in {8,16,32,50,64} + the two K-half passes
     ("ivf16.hip", "list16_kernel", 5),
-    ("list16s.hip", "list16s_kernel", 11),
+    ("list16s.hip", "list16s_kernel", 12),
     ("assign.hip", "assign_kernel", 5),
     ("assign.hip", "assign_wave_kernel", 5),
 ])
