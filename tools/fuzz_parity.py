@@ -1,7 +1,9 @@
 """Randomised end-to-end parity: GPU pipeline vs the oracle's generate_clusters over random option sets.
 Labels are expected IDENTICAL (medoids up to exact score ties); with IVF buckets a coarse near-tie may move a handful
-of rows (ARI >= 0.99 is the contract).  Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
-import sys, time, warnings
+of rows (ARI >= 0.99 is the contract).  Usage: python tools/fuzz_parity.py [n_cases] [seed]
+FALCON_FUZZ_IVF=1: every case squeezes its precursors into 2 or 20 m/z (indexed buckets in nearly every case), the low_dim
+choices include values off the kernels' grid (200, 333) and the sizes grow to 30,000 spectra."""
+import os, sys, time, warnings
 import numpy as np
 sys.path.insert(0, ".")
 from oracle import falcon_oracle as fo
@@ -12,18 +14,19 @@ from sklearn.metrics import adjusted_rand_score
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ivf_mode = os.environ.get("FALCON_FUZZ_IVF") == "1"
 ctx = Context(0)
 pipe = ClusterPipeline(ctx)
 bad = 0
 for case in range(n_cases):
-    n = int(rng.choice([3000, 9000, 20000]))
+    n = int(rng.choice([9000, 20000, 30000] if ivf_mode else [3000, 9000, 20000]))
     skew = bool(rng.random() < 0.25)                          # log-normal window occupancy, 5..50 peaks per spectrum
     big = bool(rng.random() < 0.06)                           # one window of ~45 k rows kept whole: n_list 1,024 (batch_size 2^16)
     if big:
         n, skew = 65000, False
     d = synth.select_charge(synth.generate(n, seed=int(rng.integers(1, 10 ** 6)), skew=skew), 2 if big else int(rng.choice([2, 3])))
     batch_size = 2 ** 16 if big else 2 ** 15
-    opts = dict(eps=float(rng.choice([0.05, 0.1, 0.3])), low_dim=int(rng.choice([64, 128, 256, 400])),
+    opts = dict(eps=float(rng.choice([0.05, 0.1, 0.3])), low_dim=int(rng.choice([64, 128, 200, 256, 333, 400] if ivf_mode else [64, 128, 256, 400])),
                 n_probe=int(rng.choice([2, 5, 16, 32])), n_neighbors=int(rng.choice([8, 64])),
                 n_neighbors_ann=int(rng.choice([16, 128, 200])), mz_interval=float(rng.choice([0.0, 1.0])),
                 kmeans_iters=int(rng.choice([2, 10])))
@@ -33,7 +36,7 @@ for case in range(n_cases):
         pm = d["precursor_mz"]
         d["precursor_mz"] = (600.02 + (pm - pm.min()) / np.ptp(pm) * 0.96).astype(np.float32)
         opts.update(low_dim=int(rng.choice([128, 400])), n_probe=32, kmeans_iters=int(rng.choice([2, 10])), mz_interval=1.0)
-    elif rng.random() < 0.3:                                 # squeeze the precursors: large (IVF) buckets
+    elif ivf_mode or rng.random() < 0.3:                     # squeeze the precursors: large (IVF) buckets
         pm = d["precursor_mz"]
         d["precursor_mz"] = (600.0 + (pm - pm.min()) / np.ptp(pm) * float(rng.choice([2.0, 20.0]))).astype(np.float32)
     ds = SpectrumDataset(d["precursor_mz"], d["retention_time"], d["mz"], d["intensity"], d["indptr"])
