@@ -25,9 +25,32 @@ namespace {
 
 constexpr int kMaxPasses = FAL_MAX_LOW_DIM / 256;
 
+// lane ^ X exchange of a 32-bit value: DPP quad_perm for X = 1, 2 (no LDS), ds_swizzle in bit-mask mode for X = 4, 8, 16 (no address
+// register), ds_bpermute for 32 (select.h lane_xor)
+template <int X>
+__device__ __forceinline__ uint32_t vec_lane_xor(uint32_t v) {
+    if (X == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    if (X == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    if (X == 4 || X == 8 || X == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (X << 10));
+    return (uint32_t)__shfl_xor((int)v, X, 64);
+}
+template <int X>
+__device__ __forceinline__ double vec_lane_xor_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = vec_lane_xor<X>((uint32_t)b), hi = vec_lane_xor<X>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// the butterfly sum of the 64 lanes' doubles, levels 32, 16, 8, 4, 2, 1 (the oracle's tree: the order is part of the result).  The
+// generic __shfl_xor cost five address instructions, two ds_bpermute and a full LDS round trip per level -- six dependent round trips
+// per row in a kernel whose VALU instructions x 4 cycles are 0.67 of its SIMD cycles (round 6 counters)
 __device__ __forceinline__ double wave_xor_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += vec_lane_xor_f64<32>(v);
+    v += vec_lane_xor_f64<16>(v);
+    v += vec_lane_xor_f64<8>(v);
+    v += vec_lane_xor_f64<4>(v);
+    v += vec_lane_xor_f64<2>(v);
+    v += vec_lane_xor_f64<1>(v);
     return v;
 }
 
