@@ -229,6 +229,15 @@ __device__ __forceinline__ int row16_sum(int v) {
     return v;
 }
 
+// inclusive prefix sum inside the 16 lanes of a DPP row: row_shr 1, 2, 4, 8 with zeros shifted in (bound_ctrl)
+__device__ __forceinline__ int row16_prefix_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    return v;
+}
+
 // Workgroup barrier behind LDS-DMA (`global_load_lds`): s_barrier does not wait for a wave's outstanding DMA, and hipcc's own
 // s_waitcnt insertion for the builtin lost the wait on a loop back-edge (round 3, assign.hip).  Every wave drains its vector
 // memory queue, then arrives: past the barrier every wave's DMA issued before it has landed in LDS.

@@ -103,13 +103,8 @@ __global__ __launch_bounds__(256) void sparsify_rows_kernel(const float* __restr
                 neg |= !(xs[j] >= 0.f) || xs[j] > 65504.f;
                 wide |= __half2float(__float2half_rn(xs[j])) != xs[j];
             }
-            int pre = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int y = __shfl_up(pre, off, 64);
-                if (lane >= off) pre += y;
-            }
-            const int tot = __shfl(pre, 63, 64);
+            const int pre = wave_prefix_sum(c);                  // (DPP: the generic shuffles were six LDS round trips per row)
+            const int tot = __builtin_amdgcn_readlane(pre, 63);
             if (base + tot <= kSparseW) {
                 int pos = base + pre - c;
 #pragma unroll

@@ -53,14 +53,9 @@ __device__ __forceinline__ void kept16_query(const Kept16Args& a, bool live, int
             e = a.list_off[lbase + l + 1];
         }
         const int len = (int)(e - b);
-        int incl = len;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const int o = __shfl_up(incl, off, 16);
-            if (sub >= off) incl += o;
-        }
+        const int incl = row16_prefix_sum(len);                  // (DPP inside the query's 16 lanes: no LDS round trips)
         const int seg = run + incl - len;                        // where this list's keys start in the query's stream
-        run += __shfl(incl, 15, 16);
+        run += row16_sum(len);
         // first position with pmz >= lob
         int64_t lo = b, hi = e;
         while (lo < hi) {
@@ -86,13 +81,8 @@ __device__ __forceinline__ void kept16_query(const Kept16Args& a, bool live, int
         // walked max-window-length steps with a third of the lanes busy -- the walk was two thirds of this kernel).  Row t of
         // the group belongs to the list whose exclusive prefix of window lengths is the last one <= t.
         const int wlen = (int)(lo - wa);
-        int wincl = wlen;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const int o = __shfl_up(wincl, off, 16);
-            if (sub >= off) wincl += o;
-        }
-        const int wtotal = __shfl(wincl, 15, 16);
+        const int wincl = row16_prefix_sum(wlen);
+        const int wtotal = row16_sum(wlen);
         const int wexcl = wincl - wlen;
         const int wa_lo = (int)(uint32_t)wa, wa_hi = (int)(wa >> 32);
         const int rel = (int)(wa - b) + seg;                     // key-stream position of the window's first row

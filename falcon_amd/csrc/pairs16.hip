@@ -74,12 +74,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const int i0 = a.gkcnt[(row_t + q) * 2], i1 = a.gkcnt[(row_t + q) * 2 + 1];
             if (((i0 | i1) & 0x200) == 0) c = (i0 & 0xFF) + (i1 & 0xFF);
         }
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (q >= o) incl += v;
-        }
+        const int incl = wave_prefix_sum(c);
         if (q < 32) off[q + 1] = incl;
         if (q == 0) off[0] = 0;
     }
@@ -179,12 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int i0 = a.gkcnt[(row_t + q) * 2], i1 = a.gkcnt[(row_t + q) * 2 + 1];
             if (((i0 | i1) & 0x200) == 0) c = (i0 & 0xFF) + (i1 & 0xFF);
         }
-        int incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (q >= o) incl += v;
-        }
+        const int incl = wave_prefix_sum(c);
         if (q < 32) off[q + 1] = incl;
         if (q == 0) off[0] = 0;
     }
