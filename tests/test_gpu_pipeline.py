@@ -407,6 +407,12 @@ def test_partition_runner_concurrent_streams_equal_run(ctx):
                 outs = runner.run(dss, *args)
                 for (lab, med), (rl, rm) in zip(outs, ref):
                     assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm), (form, rep)
+        # a STREAM of jobs: three jobs queued on the two slots before the first is collected (`submit` / `collect`: the slots take
+        # the next job's partitions as they finish the current one's) -- every job's results are those of `run`
+        handles = [runner.submit(forms["device"], *args, inputs_ready=True) for _ in range(3)]
+        for h in handles:
+            for (lab, med), (rl, rm) in zip(runner.collect(h), ref):
+                assert np.array_equal(lab.cpu().numpy(), rl) and np.array_equal(med.cpu().numpy(), rm)
         # host partitions WITHOUT retention times (rt_tol None: the column is never read) and with float64 precursors
         no_rt = [SpectrumDataset(ds.precursor_mz.astype(np.float64), None, ds.mz, ds.intensity, ds.indptr) for ds in parts]
         outs = runner.run(no_rt, *args)
