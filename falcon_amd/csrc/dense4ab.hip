@@ -201,7 +201,8 @@ int launch_dense4ab(fal_ctx* ctx, const float* X, int d, const DenseJob* jobs, c
     FAL_CHECK_HIP(hipMemsetAsync(cursors, 0, sizeof(int32_t) * 8, ctx->stream));
     FAL_CHECK_HIP(hipFuncSetAttribute((const void*)dense4ab_kernel<DQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const char* ke = getenv("FALCON_AB_KNOCK");             // timing experiments (wrong results): 1 no stores, 2 no row DMAs, 4 no operand reads
-    const int knock = ke ? atoi(ke) : 0;
+    const char* te = getenv("FALCON_TIMING_EXPERIMENTS");   // (the knock-outs are honoured only together with it)
+    const int knock = (ke && te && te[0] == '1') ? atoi(ke) : 0;
     if (knock & 8) FAL_CHECK_HIP(hipMemsetAsync(cursors + 16, 0, sizeof(int32_t) * 32, ctx->stream));
     hipLaunchKernelGGL((dense4ab_kernel<DQ>), grid, block, lds, ctx->stream, X, jobs, sims, sims_base, cursors, table_dev, knock);
     if (knock & 8) {

@@ -302,7 +302,9 @@ int launch_list16s(fal_ctx* ctx, const List16Args& a) {
         case 16: hipLaunchKernelGGL((list16s_kernel<16>), grid, block, 0, ctx->stream, a); break;
         case 25: {
             const char* ke = getenv("FALCON_L16_KNOCK");      // timing experiments (wrong results)
-            const int kn = ke ? atoi(ke) : 0;
+            // (honoured only together with FALCON_TIMING_EXPERIMENTS=1: a stray variable must not cost a production run its results)
+            const char* te = getenv("FALCON_TIMING_EXPERIMENTS");
+            const int kn = (ke && te && te[0] == '1') ? atoi(ke) : 0;
             if (kn == 1) hipLaunchKernelGGL((list16s_kernel<25, 1>), grid, block, 0, ctx->stream, a);
             else if (kn == 2) hipLaunchKernelGGL((list16s_kernel<25, 2>), grid, block, 0, ctx->stream, a);
             else if (kn == 3) hipLaunchKernelGGL((list16s_kernel<25, 3>), grid, block, 0, ctx->stream, a);

@@ -14,6 +14,7 @@ modes = [("4", 0), ("ab", 0), ("4", 0), ("ab", 0)] + ([("ab", k) for k in (1, 2,
 for mode, knock in modes:
     os.environ["FALCON_DENSE4"] = mode
     os.environ["FALCON_AB_KNOCK"] = str(knock)
+    os.environ["FALCON_TIMING_EXPERIMENTS"] = "1"
     idx = ctx.ivf_build(X, off, nl)
     idx.search(1, 128); ctx.sync()
     ctx.enable_timing(True)

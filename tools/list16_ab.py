@@ -37,6 +37,7 @@ def one_pass(form):
     elif form[0] == "k":             # k1 / k2 / k3: the default form with FALCON_L16_KNOCK (timing experiments, wrong results)
         os.environ.pop("FALCON_LIST16", None)
         os.environ["FALCON_L16_KNOCK"] = form[1:]
+        os.environ["FALCON_TIMING_EXPERIMENTS"] = "1"
     else:
         os.environ["FALCON_LIST16"] = form
     tot = {k: 0.0 for k in STAGES}
